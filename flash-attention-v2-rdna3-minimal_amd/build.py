@@ -1,0 +1,91 @@
+"""Ahead-of-time build of the gfx950 FlashAttention-2 forward library (libfa2_gfx950.so).
+
+The reference JIT-builds its extension at import time with the arch pinned to gfx1100
+(rocwmma_fattn/FlashAttn.py:16-41).  Here the library is a plain C-ABI shared object compiled once,
+in-tree, with `hipcc --offload-arch=gfx950`; hipcc cross-compiles without a GPU, so the same command
+runs in CI containers and on the MI355X box.
+
+    python flash-attention-v2-rdna3-minimal_amd/build.py [--force] [--verbose]
+"""
+import argparse
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.realpath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+LIB_NAME = "libfa2_gfx950.so"
+LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+STAMP_PATH = LIB_PATH + ".stamp"
+
+SOURCES = ["host.cpp"]
+HEADERS = ["fa2_fwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h")]
+
+HIPCC_FLAGS = [
+    "-x", "hip",
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-fno-honor-nans",          # no canonicalising v_max before fmaxf on MFMA outputs; +-inf still honoured
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm); the gfx950 library cannot be built")
+
+
+def _source_digest():
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    for name in SOURCES + HEADERS:
+        path = name if os.path.isabs(name) else os.path.join(CSRC, name)
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_current():
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+        return False
+    with open(STAMP_PATH) as f:
+        return f.read().strip() == _source_digest()
+
+
+def build(force=False, verbose=False):
+    """Compile libfa2_gfx950.so in-tree unless it is already up to date.  Returns its path."""
+    digest = _source_digest()
+    if not force and is_current():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd += ["-o", tmp]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError("hipcc failed (%d):\n%s\n%s" % (res.returncode, res.stdout or "", res.stderr or ""))
+    os.replace(tmp, LIB_PATH)
+    with open(STAMP_PATH, "w") as f:
+        f.write(digest + "\n")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(force=a.force, verbose=a.verbose))

@@ -1,0 +1,136 @@
+// host.cpp — C-ABI shim of the gfx950 FlashAttention-2 forward path (compiled with hipcc -x hip).
+//
+// Counterpart of the reference's host layer:
+//   rocwmma_fattn/host.cpp:30-45        dtype switch forward()        -> fa2_fwd
+//   rocwmma_fattn/kernel_fp16.cu:744-876 forward_fp16 host launcher   -> fa2_fwd_f16
+//   rocwmma_fattn/kernel_bf16.cu:802-941 forward_bf16 host launcher   -> fa2_fwd_bf16
+// Unlike the reference this layer owns no tensors and allocates nothing: padding, output allocation
+// and the 6-tensor return contract live in the Python operator (rocwmma_fattn/FlashAttn.py), the
+// launch is asynchronous on the caller's stream, and failures are returned, not printf'ed
+// (reference: kernel_fp16.cu:854-863).
+#include "fa2_fwd_kernel.hip.h"
+
+#include <cmath>
+#include <cstdio>
+
+#include "fa2_gfx950.h"
+
+namespace {
+
+constexpr int kHeadDims[] = {64, 128};
+constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
+
+template <int HD, bool BF16>
+int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    constexpr int lds = 4 * fa2::Geo<HD>::TILEB;
+    const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk));
+    const dim3 block(fa2::kThreads);
+    if (causal)
+        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, false>), grid, block, lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool strides_ok(const int64_t* s) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0 && s[2] > 0; }
+
+}  // namespace
+
+extern "C" {
+
+int fa2_supported_head_dims(int* dims, int cap) {
+    for (int i = 0; i < kNumHeadDims && i < cap; ++i)
+        if (dims) dims[i] = kHeadDims[i];
+    return kNumHeadDims;
+}
+
+int fa2_padded_head_dim(int D) {
+    if (D < 1) return -1;
+    for (int i = 0; i < kNumHeadDims; ++i)
+        if (D <= kHeadDims[i]) return kHeadDims[i];
+    return -1;
+}
+
+int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
+    if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
+    if (q_rows_per_block) *q_rows_per_block = fa2::kQBlock;
+    if (kv_rows_per_tile) *kv_rows_per_tile = fa2::kKvTile;
+    return FA2_OK;
+}
+
+const char* fa2_error_string(int code) {
+    switch (code) {
+        case FA2_OK: return "ok";
+        case FA2_ERR_NULL_POINTER: return "fa2: null pointer argument";
+        case FA2_ERR_BAD_SHAPE: return "fa2: B, H, Nq, Nkv, D must be >= 1 and one head's K/V must span < 4 GiB";
+        case FA2_ERR_HEAD_DIM: return "fa2: head dim not supported (pad D to fa2_padded_head_dim(D))";
+        case FA2_ERR_ALIGNMENT: return "fa2: pointers must be 16-byte aligned, strides multiples of 8 elements, last dim contiguous";
+        case FA2_ERR_DTYPE: return "fa2: dtype must be FA2_DTYPE_F16 or FA2_DTYPE_BF16";
+        case FA2_ERR_SCALE: return "fa2: scale must be finite";
+        case FA2_ERR_GRID: return "fa2: B*H*ceil(Nq/256) exceeds the grid limit";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "fa2: unknown error code";
+}
+
+const char* fa2_version(void) { return "fa2_gfx950 0.1 (8-wave 256x64 mfma32x32x16, lds double buffer)"; }
+
+int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+            int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+            const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+            float scale, int causal, void* hip_stream) {
+    if (!q || !k || !v || !o || !lse || !q_strides || !k_strides || !v_strides || !o_strides || !lse_strides)
+        return FA2_ERR_NULL_POINTER;
+    if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
+    if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
+    if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
+    if (!std::isfinite(scale)) return FA2_ERR_SCALE;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !strides_ok(q_strides) ||
+        !strides_ok(k_strides) || !strides_ok(v_strides) || !strides_ok(o_strides))
+        return FA2_ERR_ALIGNMENT;
+    const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2;
+    const int64_t v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
+    if (k_bytes > 0xffffffffLL || v_bytes > 0xffffffffLL) return FA2_ERR_BAD_SHAPE;
+
+    fa2::FwdParams p;
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv;
+    for (int i = 0; i < 3; ++i) {
+        p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; p.os[i] = o_strides[i];
+    }
+    p.ls[0] = lse_strides[0]; p.ls[1] = lse_strides[1];
+    p.c = std::fabs(scale) * 1.4426950408889634f;  // fold log2(e): reference kernel_fp16.cu:827
+    p.negate_q = scale < 0.f;
+    p.nqblk = (Nq + fa2::kQBlock - 1) / fa2::kQBlock;
+    p.k_bytes = (uint32_t)k_bytes;
+    p.v_bytes = (uint32_t)v_bytes;
+    if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
+
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool bf16 = dtype == FA2_DTYPE_BF16;
+    switch (D) {
+        case 64: return bf16 ? launch<64, true>(p, causal != 0, stream) : launch<64, false>(p, causal != 0, stream);
+        case 128: return bf16 ? launch<128, true>(p, causal != 0, stream) : launch<128, false>(p, causal != 0, stream);
+        default: return FA2_ERR_HEAD_DIM;
+    }
+}
+
+int fa2_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq,
+                int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+                const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+                float scale, int causal, void* hip_stream) {
+    return fa2_fwd(FA2_DTYPE_F16, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides,
+                   o_strides, lse_strides, scale, causal, hip_stream);
+}
+
+int fa2_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq,
+                 int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+                 const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+                 float scale, int causal, void* hip_stream) {
+    return fa2_fwd(FA2_DTYPE_BF16, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides,
+                   o_strides, lse_strides, scale, causal, hip_stream);
+}
+
+}  // extern "C"

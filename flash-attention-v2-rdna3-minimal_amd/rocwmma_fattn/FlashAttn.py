@@ -1,0 +1,164 @@
+"""FlashAttention-2 forward operator for MI355X — same entry point as the reference's
+rocwmma_fattn/FlashAttn.py (class FlashAttentionFunction, positional signature
+`apply(q, k, v, mask, causal, scale, BNHD_fmt)`, FlashAttn.py:45-49), so bench_with_sdpa.py:99,
+precision_test.py:63 and the external ComfyUI / sd-webui hooks keep working unchanged.
+
+Layers (reference counterpart in brackets):
+  FlashAttentionFunction.forward   [FlashAttn.py:47-76]      operator: shapes, default scale, save for bwd
+  flash_attn_wmma.forward          [host.cpp:30-45 +
+                                    kernel_fp16.cu:744-876]  dtype switch, D padding, O/L allocation,
+                                                             6-tensor return, calls the C-ABI
+  libfa2_gfx950.so : fa2_fwd_*     [fwd_kernel, kernel_fp16.cu:306-544]  hand-written gfx950 kernel
+
+The host is PyTorch-ROCm for memory and streams only; the compute is the C-ABI library
+(include/fa2_gfx950.h).  There is no CPU path: tensors must live on a ROCm device.
+"""
+import torch
+
+from . import _fa2_lib
+
+__all__ = ["FlashAttentionFunction", "flash_attn_wmma"]
+
+
+class _FlashAttnWmma:
+    """Stand-in for the reference's JIT-built pybind module `flash_attn_wmma` (FlashAttn.py:23-41):
+    same attribute names, argument order and return contract (host.cpp:60-64)."""
+
+    @staticmethod
+    def forward(q, k, v, Br, Bc, causal, scale, permute_NH):
+        """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16
+        (kernel_fp16.cu:744-876).  Br/Bc only size the N padding of O and L exactly as the
+        reference does (kernel_fp16.cu:761, :793-796); the gfx950 kernel picks its own tiles."""
+        lib = _fa2_lib.load()
+        if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+            raise RuntimeError("fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)")
+        if not q.is_cuda or not k.is_cuda or not v.is_cuda:
+            raise RuntimeError("fa2: q, k, v must be on a ROCm device (no CPU path in this operator)")
+        if k.device != q.device or v.device != q.device:
+            raise RuntimeError("fa2: q, k, v must be on the same device")
+        # dtype switch (host.cpp:30-45): half stays half, everything else runs (and returns) as bf16
+        if q.dtype == torch.float16:
+            dtype_code = _fa2_lib.FA2_DTYPE_F16
+            if k.dtype != q.dtype or v.dtype != q.dtype:
+                raise RuntimeError("fa2: q, k, v must share one dtype")
+        else:
+            dtype_code = _fa2_lib.FA2_DTYPE_BF16
+            if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+                q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+
+        n_ax, h_ax = (1, 2) if permute_NH else (2, 1)
+        b, h, n, d = q.size(0), q.size(h_ax), q.size(n_ax), q.size(3)
+        n_kv = k.size(n_ax)
+        if k.size(0) != b or v.size(0) != b or k.size(h_ax) != h or v.size(h_ax) != h or \
+                k.size(3) != d or v.size(3) != d or v.size(n_ax) != n_kv:
+            raise RuntimeError("fa2: inconsistent q/k/v shapes %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(v.shape)))
+        Br, Bc = int(Br), int(Bc)
+        d_kernel = lib.fa2_padded_head_dim(d)
+        if d_kernel < 0:
+            raise RuntimeError("fa2: head dim %d is larger than the largest gfx950 kernel" % d)
+        nq_pad = (Br - n % Br) % Br
+        d_pad = d_kernel - d
+
+        # padding (kernel_fp16.cu:767-779): Q in N and D, K/V in D only
+        q_pad, k_pad, v_pad = q, k, v
+        if nq_pad or d_pad:
+            pad = (0, d_pad, 0, 0, 0, nq_pad) if permute_NH else (0, d_pad, 0, nq_pad)
+            q_pad = torch.nn.functional.pad(q_pad, pad)
+        if d_pad:
+            k_pad = torch.nn.functional.pad(k_pad, (0, d_pad))
+            v_pad = torch.nn.functional.pad(v_pad, (0, d_pad))
+        q_pad, k_pad, v_pad = (_kernel_ready(t) for t in (q_pad, k_pad, v_pad))
+
+        # outputs (kernel_fp16.cu:793-796) — on q's device; only the N-padding tail is zero-filled
+        O = torch.empty_like(q_pad)
+        if not _strides_ok(O):
+            O = torch.empty(q_pad.shape, dtype=q_pad.dtype, device=q_pad.device)
+        L = torch.empty((b, h, n + nq_pad), dtype=torch.float32, device=q.device)
+        if nq_pad:
+            O.narrow(n_ax, n, nq_pad).zero_()
+            L[:, :, n:].zero_()
+
+        def s3(t):
+            return _fa2_lib.strides3(t.stride(0), t.stride(h_ax), t.stride(n_ax))
+
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
+                b, h, n, n_kv, d_kernel, s3(q_pad), s3(k_pad), s3(v_pad), s3(O),
+                _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0, stream)
+        if q.device.index != torch.cuda.current_device():
+            with torch.cuda.device(q.device):
+                rc = lib.fa2_fwd(*args)
+        else:
+            rc = lib.fa2_fwd(*args)
+        _fa2_lib.check(rc)
+
+        # O_fwd is a view into the padded O (kernel_fp16.cu:865-875)
+        if nq_pad or d_pad:
+            O_fwd = O[:, :n, :, :d] if permute_NH else O[:, :, :n, :d]
+        else:
+            O_fwd = O
+        return [O_fwd, q_pad, k_pad, v_pad, O, L]
+
+    @staticmethod
+    def backward(*args, **kwargs):
+        raise NotImplementedError(
+            "fa2: the gfx950 build covers the forward path only; backward "
+            "(reference kernel_fp16.cu:547-740) is the next row of the scope table")
+
+
+def _strides_ok(t):
+    return t.stride(3) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.stride(2) % 8 == 0 \
+        and t.data_ptr() % 16 == 0
+
+
+def _kernel_ready(t):
+    """kernel_fp16.cu:780-787 makes a tensor contiguous iff its last stride is not 1; the gfx950
+    kernel additionally wants 16-byte aligned rows (strides multiple of 8 elements)."""
+    return t if _strides_ok(t) else t.contiguous()
+
+
+flash_attn_wmma = _FlashAttnWmma()
+
+
+class FlashAttentionFunction(torch.autograd.Function):
+
+    @staticmethod
+    @torch.no_grad()
+    def forward(ctx, q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, **kwargs):
+        # reference: FlashAttn.py:47-76.  `mask` is accepted and ignored there too (only stored).
+        D = q.shape[3]
+        N = q.shape[2]
+        Nkv = k.shape[2]
+
+        Br = 64
+        Bc = 128
+
+        if BNHD_fmt:
+            N = q.shape[1]
+            Nkv = k.shape[1]
+
+        if scale is None:
+            scale = D ** -0.5
+        if D > 384:
+            Br = 32
+            Bc = 128
+
+        ret = flash_attn_wmma.forward(q, k, v, Br, Bc, bool(causal), scale, BNHD_fmt)
+
+        o, q_bwd, k_bwd, v_bwd, o_bwd, L = ret
+
+        if q.requires_grad:
+            ctx.args = (causal, scale, mask, N, Nkv, D, BNHD_fmt)
+            ctx.save_for_backward(q_bwd, k_bwd, v_bwd, o_bwd, L)
+        return o
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, do):
+        # reference: FlashAttn.py:78-92
+        causal, scale, mask, N, Nkv, D, BNHD_fmt = ctx.args
+        q, k, v, o, L = ctx.saved_tensors
+        Br = 128
+        Bc = 128
+        dQ, dK, dV = flash_attn_wmma.backward(q, k, v, o, do, L, N, Nkv, D, Br, Bc, causal, scale, BNHD_fmt)
+        return dQ, dK, dV, None, None, None, None

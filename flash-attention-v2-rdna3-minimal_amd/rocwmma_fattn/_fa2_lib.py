@@ -1,0 +1,79 @@
+"""ctypes binding of libfa2_gfx950.so — the C-ABI declared in include/fa2_gfx950.h.
+
+There is deliberately NO fallback: if the shared library is missing and cannot be built, or a call is
+made with tensors that are not on a ROCm device, this module raises.  (The CPU restatement under
+oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes
+import importlib.util
+import os
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libfa2_gfx950.so")
+
+FA2_DTYPE_F16 = 0
+FA2_DTYPE_BF16 = 1
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_FWD_ARGTYPES = [
+    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,  # q k v o lse
+    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,                  # B H Nq Nkv D
+    _i64p, _i64p, _i64p, _i64p, _i64p,                                                     # strides
+    ctypes.c_float, ctypes.c_int, ctypes.c_void_p,                                         # scale causal stream
+]
+
+# every symbol include/fa2_gfx950.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "fa2_fwd_f16": (ctypes.c_int, _FWD_ARGTYPES),
+    "fa2_fwd_bf16": (ctypes.c_int, _FWD_ARGTYPES),
+    "fa2_fwd": (ctypes.c_int, [ctypes.c_int] + _FWD_ARGTYPES),
+    "fa2_supported_head_dims": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
+    "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "fa2_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "fa2_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def _build_module():
+    spec = importlib.util.spec_from_file_location("_fa2_build", os.path.join(_PKG_DIR, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load(build_if_missing=True):
+    """dlopen the in-tree library (building it with hipcc first when absent) and type its symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RuntimeError("fa2: %s is missing; run `python %s`" % (LIB_PATH, os.path.join(_PKG_DIR, "build.py")))
+        _build_module().build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def error_string(code):
+    return load().fa2_error_string(int(code)).decode()
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError("fa2_fwd failed (%d): %s" % (code, error_string(code)))
+
+
+def strides3(a, b, c):
+    return (ctypes.c_int64 * 3)(a, b, c)
+
+
+def strides2(a, b):
+    return (ctypes.c_int64 * 2)(a, b)

@@ -1,0 +1,111 @@
+/*
+ * fa2_gfx950.h — C-ABI of the MI355X (gfx950 / CDNA4) FlashAttention-2 forward path.
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * Repeerc/flash-attention-v2-RDNA3-minimal: the forward attention operator behind
+ * rocwmma_fattn/FlashAttn.py.  Citations are relative to the reference tree.
+ *
+ * What each entry point replaces in the reference:
+ *
+ *   fa2_fwd_f16   <->  forward_fp16(q,k,v,Br,Bc,causal,scale,permute_NH)
+ *                      declared rocwmma_fattn/host.cpp:24-28, defined
+ *                      rocwmma_fattn/kernel_fp16.cu:744-876 (launcher) + :306-544 (fwd_kernel)
+ *   fa2_fwd_bf16  <->  forward_bf16(...), rocwmma_fattn/host.cpp:24-28,
+ *                      rocwmma_fattn/kernel_bf16.cu:802-941 + :329-577
+ *   fa2_fwd       <->  the dtype switch `forward(...)`, rocwmma_fattn/host.cpp:30-45
+ *
+ * Differences from the reference's C++ symbols (deliberate):
+ *   - plain pointers / sizes / strides, no torch types, no allocation: the CALLER owns q,k,v,o,lse;
+ *   - asynchronous launch on the hipStream_t handed in (reference: null stream, kernel_fp16.cu:844);
+ *   - 64-bit element strides (reference: 32-bit `int` offsets, kernel_fp16.cu:324);
+ *   - returns an error code (reference: printf only, kernel_fp16.cu:854-863);
+ *   - Br/Bc are not parameters: tile sizes are an internal choice of the gfx950 kernel.
+ *
+ * Layout contract
+ *   q   : [B, H, Nq , D]  element (b,h,i,c) at q + b*q_strides[0] + h*q_strides[1] + i*q_strides[2] + c
+ *   k,v : [B, H, Nkv, D]  likewise with k_strides / v_strides
+ *   o   : [B, H, Nq , D]  likewise with o_strides
+ *   lse : f32, element (b,h,i) at lse + b*lse_strides[0] + h*lse_strides[1] + i
+ *   Strides are in ELEMENTS; the last (D) dimension is contiguous.  The reference's BNHD
+ *   ("permute_NH", kernel_fp16.cu:328-333) layout is the same call with the head and row strides
+ *   of the [B,N,H,D] tensor: strides = {N*H*D, D, H*D}.
+ *   All base pointers must be 16-byte aligned and every stride a multiple of 8 elements.
+ *
+ * Numerics contract (reference: kernel_fp16.cu:434-490, :510-543)
+ *   S = (Q K^T) * scale * log2(e)   (f32 accumulate on MFMA)
+ *   causal: (i, j) masked iff j > i, top-left aligned (kernel_fp16.cu:403-410)
+ *   online softmax in f32 (running max m, running sum l), P rounded to the I/O dtype (RNE) for P·V,
+ *   O accumulated in f32 registers, O = O / l rounded once to the I/O dtype,
+ *   lse[i] = m + log2(l)  — the LOG2-domain log-sum-exp of the scaled scores, i.e.
+ *   natural LSE * log2(e), the reference kernel's convention (kernel_fp16.cu:541-542).
+ */
+#ifndef FA2_GFX950_H
+#define FA2_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dtype codes for fa2_fwd */
+#define FA2_DTYPE_F16  0
+#define FA2_DTYPE_BF16 1
+
+/* return codes: 0 = launched; >0 = hipError_t from the runtime; <0 = argument validation */
+#define FA2_OK                 0
+#define FA2_ERR_NULL_POINTER  -1
+#define FA2_ERR_BAD_SHAPE     -2   /* B,H,Nq,Nkv,D < 1 */
+#define FA2_ERR_HEAD_DIM      -3   /* D not one of fa2_supported_head_dims() */
+#define FA2_ERR_ALIGNMENT     -4   /* pointer not 16-B aligned or stride not a multiple of 8 */
+#define FA2_ERR_DTYPE         -5
+#define FA2_ERR_SCALE         -6   /* scale is NaN/inf */
+#define FA2_ERR_GRID          -7   /* B*H*ceil(Nq/256) exceeds the 2^31-1 grid limit */
+
+/* Forward attention, fp16 I/O.  Replaces forward_fp16 (rocwmma_fattn/host.cpp:24-28). */
+int fa2_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse,
+                int B, int H, int Nq, int Nkv, int D,
+                const int64_t q_strides[3], const int64_t k_strides[3],
+                const int64_t v_strides[3], const int64_t o_strides[3],
+                const int64_t lse_strides[2],
+                float scale, int causal, void* hip_stream);
+
+/* Forward attention, bf16 I/O.  Replaces forward_bf16 (rocwmma_fattn/host.cpp:24-28). */
+int fa2_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse,
+                 int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3],
+                 const int64_t v_strides[3], const int64_t o_strides[3],
+                 const int64_t lse_strides[2],
+                 float scale, int causal, void* hip_stream);
+
+/* dtype-switched entry.  Replaces forward() (rocwmma_fattn/host.cpp:30-45). */
+int fa2_fwd(int dtype,
+            const void* q, const void* k, const void* v, void* o, float* lse,
+            int B, int H, int Nq, int Nkv, int D,
+            const int64_t q_strides[3], const int64_t k_strides[3],
+            const int64_t v_strides[3], const int64_t o_strides[3],
+            const int64_t lse_strides[2],
+            float scale, int causal, void* hip_stream);
+
+/* Head dims the kernels are instantiated for (ascending).  Writes up to `cap` entries into
+ * `dims`, returns the total count.  A caller with another D zero-pads the last dimension up to the
+ * next supported value — the reference pads D the same way (kernel_fp16.cu:763, :767-779). */
+int fa2_supported_head_dims(int* dims, int cap);
+
+/* Smallest supported head dim >= D, or -1 if D is larger than the largest kernel. */
+int fa2_padded_head_dim(int D);
+
+/* Q rows per workgroup / KV rows per tile of the kernel chosen for head dim D (informational:
+ * the counterparts of the reference's Br / Bc, FlashAttn.py:56-67). */
+int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
+
+/* Text for a return code of this library (validation codes and hipError_t values). */
+const char* fa2_error_string(int code);
+
+/* "fa2_gfx950 <major>.<minor> (<kernel variant>)" */
+const char* fa2_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA2_GFX950_H */

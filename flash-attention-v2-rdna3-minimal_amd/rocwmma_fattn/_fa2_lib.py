@@ -8,6 +8,11 @@ import ctypes
 import importlib.util
 import os
 
+# PyTorch-ROCm must be loaded first: it brings its own libamdhip64.so.7, and the kernel library has
+# to bind to that SAME runtime instance (it is handed torch's streams and device pointers).  Loading
+# libfa2_gfx950.so before torch would pull in the system runtime under the same soname instead.
+import torch  # noqa: F401
+
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "libfa2_gfx950.so")
 

@@ -1,0 +1,115 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/fa2_gfx950.h declares, argument validation returns the documented codes before anything
+touches a GPU, and the Python operator mirrors the reference's rocwmma_fattn/FlashAttn.py surface."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+from rocwmma_fattn import _fa2_lib
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attn_wmma
+
+HEADER = os.path.join(ROOT, "include", "fa2_gfx950.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa2_\w+)\s*\(", text)))
+
+
+def _codes():
+    text = open(HEADER).read()
+    return {m[0]: int(m[1]) for m in re.findall(r"#define\s+(FA2_\w+)\s+(-?\d+)", text)}
+
+
+def test_library_is_in_tree_and_exports_every_declared_symbol():
+    lib = _fa2_lib.load()
+    assert os.path.dirname(_fa2_lib.LIB_PATH) == PKG
+    declared = _declared_symbols()
+    assert "fa2_fwd_f16" in declared and "fa2_fwd_bf16" in declared and "fa2_fwd" in declared
+    assert set(declared) == set(_fa2_lib.SYMBOLS), "ctypes binding and header disagree"
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_informational_entry_points():
+    lib = _fa2_lib.load()
+    dims = (ctypes.c_int * 8)()
+    n = lib.fa2_supported_head_dims(dims, 8)
+    got = list(dims[:n])
+    assert got == sorted(got) and 64 in got and 128 in got
+    assert lib.fa2_padded_head_dim(40) == 64 and lib.fa2_padded_head_dim(64) == 64
+    assert lib.fa2_padded_head_dim(111) == 128 and lib.fa2_padded_head_dim(0) == -1
+    assert lib.fa2_padded_head_dim(max(got) + 1) == -1
+    qr, kr = ctypes.c_int(), ctypes.c_int()
+    assert lib.fa2_tile_rows(128, ctypes.byref(qr), ctypes.byref(kr)) == 0
+    assert qr.value % 32 == 0 and kr.value % 32 == 0
+    assert lib.fa2_version().decode().startswith("fa2_gfx950")
+    assert _fa2_lib.error_string(0) == "ok"
+
+
+def test_validation_codes_without_a_gpu():
+    """Every rejected call returns before the launch, so this runs on a machine with no GPU."""
+    lib = _fa2_lib.load()
+    c = _codes()
+    buf = ctypes.create_string_buffer(4096 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    s3 = _fa2_lib.strides3(2 * 16 * 64, 16 * 64, 64)
+    s2 = _fa2_lib.strides2(32, 16)
+
+    def call(dtype=0, q=p, k=p, v=p, o=p, lse=p, B=1, H=2, Nq=16, Nkv=16, D=64, qs=s3, scale=0.125):
+        return lib.fa2_fwd(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, qs, s3, s3, s3, s2, scale, 0, None)
+
+    assert call(q=None) == c["FA2_ERR_NULL_POINTER"]
+    assert call(dtype=7) == c["FA2_ERR_DTYPE"]
+    assert call(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
+    assert call(D=40) == c["FA2_ERR_HEAD_DIM"]
+    assert call(D=4096) == c["FA2_ERR_HEAD_DIM"]
+    assert call(q=p + 2) == c["FA2_ERR_ALIGNMENT"]
+    assert call(qs=_fa2_lib.strides3(2048, 1024, 68)) == c["FA2_ERR_ALIGNMENT"]
+    assert call(scale=float("nan")) == c["FA2_ERR_SCALE"]
+    for code in c.values():
+        assert _fa2_lib.error_string(code)
+    with pytest.raises(RuntimeError, match="fa2_fwd failed"):
+        _fa2_lib.check(c["FA2_ERR_HEAD_DIM"])
+    assert lib.fa2_fwd_f16(None, p, p, p, p, 1, 1, 1, 1, 64, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_NULL_POINTER"]
+    assert lib.fa2_fwd_bf16(p, p, p, p, p, 1, 1, 1, 1, 48, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_HEAD_DIM"]
+
+
+def test_operator_surface_matches_reference():
+    # reference: rocwmma_fattn/FlashAttn.py:45-49 forward(ctx, q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, **kwargs)
+    sig = inspect.signature(FlashAttentionFunction.forward)
+    names = list(sig.parameters)
+    assert names[:8] == ["ctx", "q", "k", "v", "mask", "causal", "scale", "BNHD_fmt"]
+    assert sig.parameters["mask"].default is None and sig.parameters["causal"].default is None
+    assert sig.parameters["scale"].default is None and sig.parameters["BNHD_fmt"].default is False
+    assert issubclass(FlashAttentionFunction, torch.autograd.Function)
+    # reference: host.cpp:3-8 forward(q,k,v,Br,Bc,causal,scale,permute_NH)
+    fsig = inspect.signature(flash_attn_wmma.forward)
+    assert list(fsig.parameters) == ["q", "k", "v", "Br", "Bc", "causal", "scale", "permute_NH"]
+    assert hasattr(flash_attn_wmma, "backward")
+
+
+def test_operator_refuses_cpu_tensors_loudly():
+    q = torch.rand(1, 2, 16, 64, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        FlashAttentionFunction.apply(q, q, q, None, False)
+    with pytest.raises(RuntimeError, match="4-D"):
+        flash_attn_wmma.forward(q[0], q[0], q[0], 64, 128, False, 1.0, False)
+    with pytest.raises(NotImplementedError):
+        flash_attn_wmma.backward()
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package may import or link it."""
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), (dirpath, f)
+                assert "fa2_oracle" not in text and "libfa2_oracle" not in text, (dirpath, f)

@@ -1,0 +1,176 @@
+"""CPU tests: pin the oracle (oracle/) against the golden vectors generated from the reference's
+pure_torch_ver.py (tests/golden/make_golden.py) and against dense float64 attention."""
+import numpy as np
+import pytest
+
+from conftest import ATOL, FLOOR, LSE_TOL, RTOL, load_golden
+from oracle import fa2_oracle as fo
+
+
+def _f32(bits, dt):
+    return fo.bits_to_f32(bits, dt)
+
+
+# ---------------------------------------------------------------- number formats
+
+def test_f16_converters_bit_exact_against_numpy():
+    lib = fo._load()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.standard_normal(4000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 4000).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 2.99e-8, 6.1e-5, 6.0e-5,
+                  np.inf, -np.inf, 1.00048828125, 1.000244140625, 0.333251953125], dtype=np.float32)])
+    want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([lib.fa2_oracle_f32_to_f16(float(x)) for x in xs], dtype=np.uint16)
+    assert np.array_equal(got, want)
+    allbits = np.arange(0, 65536, 7, dtype=np.uint16)
+    back = np.array([lib.fa2_oracle_f16_to_f32(int(b)) for b in allbits], dtype=np.float32)
+    ref = allbits.view(np.float16).astype(np.float32)
+    assert np.array_equal(back.view(np.uint32)[~np.isnan(ref)], ref.view(np.uint32)[~np.isnan(ref)])
+
+
+def test_bf16_converters_match_torch():
+    torch = pytest.importorskip("torch")
+    lib = fo._load()
+    rng = np.random.default_rng(1)
+    xs = (rng.standard_normal(4000) * 10.0 ** rng.integers(-20, 20, 4000)).astype(np.float32)
+    xs = np.concatenate([xs, np.array([1.00390625, 1.0078125, 1.01171875, 0.0, -0.0, 3.3895314e38], dtype=np.float32)])
+    want = torch.from_numpy(xs).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    got = np.array([lib.fa2_oracle_f32_to_bf16(float(x), 0) for x in xs], dtype=np.uint16)
+    assert np.array_equal(got, want)
+    assert np.array_equal(fo.f32_to_bf16_bits(xs), want)
+    trunc = np.array([lib.fa2_oracle_f32_to_bf16(float(x), 1) for x in xs], dtype=np.uint16)
+    assert np.array_equal(trunc, (xs.view(np.uint32) >> 16).astype(np.uint16))  # kernel_bf16.cu:62-72
+
+
+# ---------------------------------------------------------------- golden vectors
+
+def test_c_oracle_against_golden(golden):
+    """f32-state oracle (the gfx950 contract): within the stated tolerance of truth, never worse
+    than the reference's own oracle, LSE equal to the dense log2-LSE and to the reference's L."""
+    dt = golden["dtype"]
+    for causal, var in golden["variants"].items():
+        o_bits, lse = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal, Br=32, Bc=64)
+        o = _f32(o_bits, dt)
+        o_ref = _f32(var["o_ref"], dt)
+        err = np.abs(o - var["o_true"]).max()
+        ref_err = np.abs(o_ref - var["o_true"]).max()
+        assert err <= max(2 * ref_err, FLOOR[dt]), (golden["name"], causal, err, ref_err)
+        assert err <= ref_err * 1.001 + 1e-7, "f32-state oracle should not be worse than the 16-bit-state reference"
+        # agreement with the reference oracle's output itself: both within their error of truth
+        assert np.abs(o - o_ref).max() <= err + ref_err + 1e-6
+        assert np.abs(lse - var["lse2_true"]).max() <= LSE_TOL
+        # reference L is natural-log and computed in the input dtype (pure_torch_ver.py:84): coarse
+        n = golden["N"]
+        l_ref2 = var["l_ref"][:, :, :n] * fo.LOG2E
+        assert np.abs(lse - l_ref2).max() <= (2e-2 if dt == 0 else 1.6e-1)
+
+
+def test_c_oracle_reference_rounding_mode_tracks_reference(golden):
+    """With the reference's rounding points switched on (16-bit S and O accumulator) the restatement
+    lands in the reference oracle's own error class."""
+    dt = golden["dtype"]
+    for causal, var in golden["variants"].items():
+        o_bits, _ = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal, Br=64, Bc=256,
+                             flags=fo.ROUND_S | fo.ROUND_O)
+        o = _f32(o_bits, dt)
+        o_ref = _f32(var["o_ref"], dt)
+        ref_err = np.abs(o_ref - var["o_true"]).max()
+        assert np.abs(o - var["o_true"]).max() <= 1.5 * ref_err + FLOOR[dt] / 4
+        ulp = 2.0 ** (-10 if dt == 0 else -7)
+        assert np.abs(o - o_ref).max() <= 2 * ulp * max(1.0, np.abs(o_ref).max())
+
+
+@pytest.mark.parametrize("name", ["c1_f16", "mt_f16", "ragged_f16", "cross_f16", "signed_f16"])
+def test_numpy_tiled_restatement_reproduces_reference_oracle(name):
+    """Line-by-line numpy restatement of pure_torch_ver.py:22-90 (fp16): identical up to the matmul
+    summation order, i.e. at most one fp16 ulp apart and mostly bit-identical."""
+    g = load_golden(name)
+    q, k, v = (_f32(g[t], 0) for t in "qkv")
+    for causal, var in g["variants"].items():
+        o, L = fo.fwd_numpy_tiled(q, k, v, causal)
+        o_ref = _f32(var["o_ref"], 0)
+        d = np.abs(o.astype(np.float32) - o_ref)
+        assert d.max() <= 2.0 ** -10 * max(1.0, np.abs(o_ref).max())
+        assert (d == 0).mean() > 0.5
+        n = g["N"]
+        assert np.abs(L[:, :, :n] - var["l_ref"][:, :, :n]).max() <= 1.6e-2
+
+
+def test_numpy_dense_matches_truth(golden):
+    dt = golden["dtype"]
+    q, k, v = (_f32(golden[t], dt) for t in "qkv")
+    for causal, var in golden["variants"].items():
+        o, lse = fo.fwd_numpy(q, k, v, causal)
+        assert np.abs(o - var["o_true"]).max() <= 1e-6
+        assert np.abs(lse - var["lse2_true"]).max() <= 1e-5
+
+
+# ---------------------------------------------------------------- properties and edge cases
+
+def _rand_bits(rng, shape, dt, signed=False):
+    x = rng.standard_normal(shape) if signed else rng.random(shape)
+    return fo.f32_to_bits(x.astype(np.float32), dt)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_tiling_invariance(dt, causal):
+    """The result must not depend on Br/Bc beyond summation-order noise (FA2 is exact attention)."""
+    rng = np.random.default_rng(10 + dt)
+    q, k, v = (_rand_bits(rng, (1, 2, 150, 64), dt, signed=True) for _ in range(3))
+    base_o, base_l = fo.fwd_c(q, k, v, dt, causal, Br=150, Bc=150)
+    for br, bc in ((32, 64), (64, 128), (64, 256), (7, 13), (1, 1)):
+        o, l = fo.fwd_c(q, k, v, dt, causal, Br=br, Bc=bc)
+        a, b = _f32(o, dt), _f32(base_o, dt)
+        assert np.all(np.abs(a - b) <= ATOL[dt] + RTOL[dt] * np.abs(b))
+        assert np.abs(l - base_l).max() <= 1e-4
+
+
+@pytest.mark.parametrize("shape,nkv", [((1, 1, 1, 64), 1), ((1, 1, 1, 128), 300), ((2, 3, 65, 64), 1),
+                                       ((1, 2, 257, 128), 63), ((1, 1, 5, 40), 9)])
+def test_edge_shapes_against_dense(shape, nkv):
+    rng = np.random.default_rng(3)
+    B, H, N, D = shape
+    q = _rand_bits(rng, shape, 0, signed=True)
+    k = _rand_bits(rng, (B, H, nkv, D), 0, signed=True)
+    v = _rand_bits(rng, (B, H, nkv, D), 0, signed=True)
+    o, lse = fo.fwd_c(q, k, v, 0, False)
+    o_true, lse_true = fo.fwd_numpy(_f32(q, 0), _f32(k, 0), _f32(v, 0), False)
+    assert np.all(np.abs(_f32(o, 0) - o_true) <= ATOL[0] + RTOL[0] * np.abs(o_true))
+    assert np.abs(lse - lse_true).max() <= LSE_TOL
+
+
+def test_causal_first_row_and_constant_v():
+    rng = np.random.default_rng(4)
+    q, k = (_rand_bits(rng, (1, 2, 70, 64), 0, signed=True) for _ in range(2))
+    v = _rand_bits(rng, (1, 2, 70, 64), 0, signed=True)
+    o, lse = fo.fwd_c(q, k, v, 0, True)
+    assert np.array_equal(o[:, :, 0], v[:, :, 0])            # row 0 sees only column 0: O = V[0] exactly
+    vc = np.full((1, 2, 70, 64), np.float16(0.75).view(np.uint16), dtype=np.uint16)
+    o, _ = fo.fwd_c(q, k, vc, 0, False)
+    assert np.abs(_f32(o, 0) - 0.75).max() <= 2.0 ** -11      # convex combination of a constant
+
+
+def test_large_logits_do_not_overflow():
+    """Scores of +-several hundred: the running-max subtraction keeps exp2 in range (the reference
+    hints at this stress with its q*5 / k*75 comments, pure_torch_ver.py:166-168)."""
+    rng = np.random.default_rng(5)
+    q = fo.f32_to_bits((rng.standard_normal((1, 1, 40, 64)) * 6).astype(np.float32), 0)
+    k = fo.f32_to_bits((rng.standard_normal((1, 1, 90, 64)) * 40).astype(np.float32), 0)
+    v = _rand_bits(rng, (1, 1, 90, 64), 0, signed=True)
+    o, lse = fo.fwd_c(q, k, v, 0, False)
+    o_true, lse_true = fo.fwd_numpy(_f32(q, 0), _f32(k, 0), _f32(v, 0), False)
+    assert np.isfinite(_f32(o, 0)).all() and np.isfinite(lse).all()
+    assert np.all(np.abs(_f32(o, 0) - o_true) <= 2e-3 + 4e-3 * np.abs(o_true))
+    assert np.abs(lse - lse_true).max() <= 2e-2 * (1 + np.abs(lse_true).max() / 1000)
+
+
+def test_negative_scale_and_explicit_scale():
+    rng = np.random.default_rng(6)
+    q, k, v = (_rand_bits(rng, (1, 2, 33, 64), 0, signed=True) for _ in range(3))
+    for scale in (0.3, -0.2):
+        o, lse = fo.fwd_c(q, k, v, 0, False, scale=scale)
+        o_true, lse_true = fo.fwd_numpy(_f32(q, 0), _f32(k, 0), _f32(v, 0), False, scale=scale)
+        assert np.all(np.abs(_f32(o, 0) - o_true) <= ATOL[0] + RTOL[0] * np.abs(o_true))
+        assert np.abs(lse - lse_true).max() <= LSE_TOL

@@ -1,0 +1,269 @@
+"""GPU parity tests (`-m gpu`): the HIP path, called through the C-ABI (ctypes -> libfa2_gfx950.so),
+against the golden fixtures, the C oracle on seeded inputs, and size-independent properties at the
+BASELINE.json configurations.  Nothing here reads /root/reference."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ATOL, FLOOR, LSE_TOL, RTOL
+from oracle import fa2_oracle as fo
+from rocwmma_fattn import _fa2_lib
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attn_wmma
+
+pytestmark = pytest.mark.gpu
+
+TORCH_DT = {0: torch.float16, 1: torch.bfloat16}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run the CPU suite with -m 'not gpu'"
+    return torch.device("cuda", 0)
+
+
+def _to_dev(bits, dt):
+    return torch.from_numpy(bits.view(np.int16).copy()).view(TORCH_DT[dt]).to(_dev())
+
+
+def _bits(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def _cabi_forward(q, k, v, causal, scale=None):
+    """Straight through the C-ABI (fa2_fwd_f16 / fa2_fwd_bf16), caller-owned buffers."""
+    lib = _fa2_lib.load(build_if_missing=False)
+    B, H, N, D = q.shape
+    Nkv = k.shape[2]
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    fn = lib.fa2_fwd_f16 if q.dtype == torch.float16 else lib.fa2_fwd_bf16
+    s3 = lambda t: _fa2_lib.strides3(t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, Nkv, D,
+            s3(q), s3(k), s3(v), s3(o), _fa2_lib.strides2(lse.stride(0), lse.stride(1)),
+            float(D ** -0.5 if scale is None else scale), int(causal),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _fa2_lib.check(rc)
+    torch.cuda.synchronize()
+    return o, lse
+
+
+def _assert_close_to_oracle(o, lse, q, k, v, dt, causal, scale=None):
+    o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), dt, causal, scale=scale)
+    o_ref = fo.bits_to_f32(o_ref_bits, dt)
+    got = o.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
+    assert not bad.any(), "max diff %.3e at %s" % (np.abs(got - o_ref).max(), np.argwhere(bad)[:4])
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= LSE_TOL
+
+
+# ---------------------------------------------------------------- golden fixtures
+
+def test_golden_fixtures_through_cabi(golden):
+    dt = golden["dtype"]
+    q, k, v = (_to_dev(golden[t], dt) for t in "qkv")
+    n = golden["N"]
+    for causal, var in golden["variants"].items():
+        o, lse = _cabi_forward(q, k, v, causal)
+        got = o.float().cpu().numpy()
+        o_ref = fo.bits_to_f32(var["o_ref"], dt)
+        ref_err = np.abs(o_ref - var["o_true"]).max()
+        err = np.abs(got - var["o_true"]).max()
+        assert err <= max(2 * ref_err, FLOOR[dt]), (golden["name"], causal, err, ref_err)
+        assert np.abs(lse.cpu().numpy() - var["lse2_true"]).max() <= LSE_TOL
+        # the reference's L is natural-log, kept in the input dtype: compare coarsely after * log2(e)
+        assert np.abs(lse.cpu().numpy() - var["l_ref"][:, :, :n] * fo.LOG2E).max() <= (2e-2 if dt == 0 else 1.6e-1)
+        _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
+
+
+def test_golden_fixtures_through_operator(golden):
+    """Same data through FlashAttentionFunction.apply, the reference's call shape (bench_with_sdpa.py:99)."""
+    dt = golden["dtype"]
+    q, k, v = (_to_dev(golden[t], dt) for t in "qkv")
+    for causal, var in golden["variants"].items():
+        o = FlashAttentionFunction.apply(q, k, v, None, causal)
+        torch.cuda.synchronize()
+        assert o.shape == q.shape and o.dtype == q.dtype and o.device == q.device
+        err = np.abs(o.float().cpu().numpy() - var["o_true"]).max()
+        ref_err = np.abs(fo.bits_to_f32(var["o_ref"], dt) - var["o_true"]).max()
+        assert err <= max(2 * ref_err, FLOOR[dt])
+
+
+# ---------------------------------------------------------------- seeded inputs vs the C oracle
+
+SHAPES = [
+    # B, H, Nq, Nkv, D
+    (1, 1, 1, 1, 64), (1, 2, 1, 300, 128), (2, 3, 65, 1, 64), (1, 2, 31, 33, 64), (1, 3, 255, 257, 128),
+    (2, 2, 256, 256, 128), (1, 2, 257, 511, 64), (1, 1, 700, 700, 128), (3, 5, 130, 77, 64), (1, 8, 512, 512, 128),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_seeded_shapes_against_oracle(shape, dt, causal):
+    B, H, Nq, Nkv, D = shape
+    g = torch.Generator(device="cpu").manual_seed(hash(shape) % 1000 + 17 * dt)
+    q = torch.randn((B, H, Nq, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    k = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    v = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    o, lse = _cabi_forward(q, k, v, causal)
+    _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
+
+
+def test_explicit_and_negative_scale():
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q, k, v = (torch.randn((1, 2, 200, 64), generator=g).half().to(_dev()) for _ in range(3))
+    for scale in (0.3, -0.2):
+        o, lse = _cabi_forward(q, k, v, False, scale=scale)
+        _assert_close_to_oracle(o, lse, q, k, v, 0, False, scale=scale)
+
+
+def test_large_logits_and_forced_rescale():
+    """Spike one K row so the running max jumps late in the sweep (the online-softmax rescale branch),
+    and use logits of several hundred (cdna guide §5.4 rule 26: force the rare branch)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = (torch.randn((1, 2, 300, 128), generator=g) * 3).half()
+    k = (torch.randn((1, 2, 640, 128), generator=g) * 3).half()
+    v = torch.randn((1, 2, 640, 128), generator=g).half()
+    k[:, :, 517] = q[:, :, 11] * 4          # row 11's max jumps at kv tile 8
+    k[:, :, 70] = q[:, :, 200] * 2
+    q, k, v = q.to(_dev()), k.to(_dev()), v.to(_dev())
+    o, lse = _cabi_forward(q, k, v, False)
+    o_true, lse_true = fo.fwd_numpy(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), False)
+    got = o.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.all(np.abs(got - o_true) <= 2e-3 + 4e-3 * np.abs(o_true))
+    assert np.abs(lse.cpu().numpy() - lse_true).max() <= 2e-2
+    _assert_close_to_oracle(o, lse, q, k, v, 0, False)
+
+
+# ---------------------------------------------------------------- operator contract (reference quirks)
+
+def test_return_contract_padding_and_views():
+    """6-tensor return, O_fwd a view into padded O, L padded to a multiple of Br in log2 units
+    (reference: kernel_fp16.cu:761-796, :865-875); D=40 is zero-padded to a kernel head dim."""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    q = torch.rand((2, 3, 100, 40), generator=g).half().to(_dev())
+    k = torch.rand((2, 3, 77, 40), generator=g).half().to(_dev())
+    v = torch.rand((2, 3, 77, 40), generator=g).half().to(_dev())
+    O_fwd, q_pad, k_pad, v_pad, O, L = flash_attn_wmma.forward(q, k, v, 64, 128, False, 40 ** -0.5, False)
+    torch.cuda.synchronize()
+    assert O_fwd.shape == q.shape and O.shape == (2, 3, 128, 64) and L.shape == (2, 3, 128)
+    assert q_pad.shape == (2, 3, 128, 64) and k_pad.shape == (2, 3, 77, 64) and v_pad.shape == (2, 3, 77, 64)
+    assert O_fwd.data_ptr() == O.data_ptr() and L.dtype == torch.float32 and L.device == q.device
+    assert float(O[:, :, 100:].abs().max()) == 0.0 and float(L[:, :, 100:].abs().max()) == 0.0
+    o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), 0, False)
+    assert np.all(np.abs(O_fwd.float().cpu().numpy() - fo.bits_to_f32(o_ref_bits, 0)) <= 2e-3)
+    assert np.abs(L[:, :, :100].cpu().numpy() - lse_ref).max() <= LSE_TOL
+
+
+def test_bnhd_layout_is_zero_copy_and_matches_bhnd():
+    """BNHD_fmt=True (reference: kernel_fp16.cu:328-333, bench_with_sdpa_BNHD.py:106)."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q, k, v = (torch.rand((2, 4, 300, 64), generator=g).half().to(_dev()) for _ in range(3))
+    o_bhnd = FlashAttentionFunction.apply(q, k, v, None, True)
+    qn, kn, vn = (t.transpose(1, 2).contiguous() for t in (q, k, v))     # [B,N,H,D]
+    o_bnhd = FlashAttentionFunction.apply(qn, kn, vn, None, True, None, True)
+    torch.cuda.synchronize()
+    assert o_bnhd.shape == qn.shape
+    assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd)
+
+
+def test_non_half_inputs_run_as_bf16_like_the_reference():
+    """host.cpp:42-45: any other dtype is cast to bf16 and the bf16 result is returned."""
+    g = torch.Generator(device="cpu").manual_seed(12)
+    q, k, v = (torch.rand((1, 2, 64, 64), generator=g).to(_dev()) for _ in range(3))
+    o = FlashAttentionFunction.apply(q, k, v, None, False)
+    assert o.dtype == torch.bfloat16
+    o2 = FlashAttentionFunction.apply(q.bfloat16(), k.bfloat16(), v.bfloat16(), None, False)
+    assert torch.equal(o, o2)
+
+
+def test_requires_grad_saves_the_backward_tensors():
+    q, k, v = (torch.rand((1, 2, 64, 64), device=_dev(), dtype=torch.float16, requires_grad=True) for _ in range(3))
+    o = FlashAttentionFunction.apply(q, k, v, None, False)
+    assert o.requires_grad
+    with pytest.raises(NotImplementedError):
+        o.backward(torch.ones_like(o))
+
+
+def test_launch_is_on_the_callers_stream_and_device():
+    s = torch.cuda.Stream()
+    q, k, v = (torch.rand((1, 4, 512, 128), device=_dev(), dtype=torch.float16) for _ in range(3))
+    ref = FlashAttentionFunction.apply(q, k, v, None, False)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        o = FlashAttentionFunction.apply(q, k, v, None, False)
+    s.synchronize()
+    assert torch.equal(o, ref)
+
+
+# ---------------------------------------------------------------- BASELINE.json configurations (full size)
+
+CONFIGS = {
+    "c2": (2, 16, 4096, 128, 0, False),
+    "c3": (2, 16, 4096, 128, 1, True),
+    "c4": (1, 32, 8192, 128, 0, True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_full_size_config_properties(name):
+    """At full size the oracle checks a SAMPLE of heads; the whole tensor is covered by properties:
+    (a) determinism and batch/head independence: recomputing a head slice alone is bit-identical;
+    (b) row-block independence: a Q row subset gives bit-identical rows;
+    (c) rows are convex combinations: min(V) <= O <= max(V) per head and column, and constant V
+        returns that constant; (d) causal row 0 equals V[0] exactly;
+    (e) LSE consistency: lse equals the dense fp32 log2-sum-exp2 on sampled rows."""
+    B, H, N, D, dt, causal = CONFIGS[name]
+    g = torch.Generator(device=_dev()).manual_seed(1234)
+    q, k, v = (torch.rand((B, H, N, D), generator=g, device=_dev(), dtype=torch.float32).to(TORCH_DT[dt]) for _ in range(3))
+    o, lse = _cabi_forward(q, k, v, causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    # sampled heads against the oracle (first, last, one in the middle)
+    for (b, h) in {(0, 0), (B - 1, H - 1), (B // 2, H // 3)}:
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal)
+    # (a) head slice recomputed alone
+    o_h, lse_h = _cabi_forward(q[:, 3:5].contiguous(), k[:, 3:5].contiguous(), v[:, 3:5].contiguous(), causal)
+    assert torch.equal(o_h, o[:, 3:5]) and torch.equal(lse_h, lse[:, 3:5])
+    # (b) first rows recomputed alone (top-left causal alignment keeps rows [0, 1024) unchanged)
+    o_r, _ = _cabi_forward(q[:, :2, :1024].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), causal)
+    if causal:
+        o_r2, _ = _cabi_forward(q[:, :2, :1024].contiguous(), k[:, :2, :1024].contiguous(), v[:, :2, :1024].contiguous(), True)
+        assert torch.equal(o_r2, o[:, :2, :1024])
+    else:
+        assert torch.equal(o_r, o[:, :2, :1024])
+    # (c) convexity
+    vmin = v.float().amin(dim=2, keepdim=True)
+    vmax = v.float().amax(dim=2, keepdim=True)
+    ulp = 2.0 ** (-10 if dt == 0 else -7)
+    assert bool(((o.float() >= vmin - ulp) & (o.float() <= vmax + ulp)).all())
+    o_c, _ = _cabi_forward(q[:1, :2].contiguous(), k[:1, :2].contiguous(), torch.full_like(v[:1, :2], 0.75), causal)
+    assert float((o_c.float() - 0.75).abs().max()) <= ulp
+    # (d) causal first row
+    if causal:
+        assert torch.equal(o[:, :, 0], v[:, :, 0])
+    # (e) LSE on sampled rows
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, N // 2 + 5, N - 1], device=_dev())
+    s = torch.matmul(q[:, :, rows].float(), k.float().transpose(-1, -2)) * (D ** -0.5 * fo.LOG2E)
+    if causal:
+        col = torch.arange(N, device=_dev())
+        s = s.masked_fill(col[None, None, None, :] > rows[None, None, :, None], float("-inf"))
+    lse_rows = torch.logsumexp(s * 0.6931471805599453, dim=-1) * fo.LOG2E
+    assert float((lse[:, :, rows] - lse_rows).abs().max()) <= LSE_TOL
+
+
+def test_config5_shard_equals_slice_of_global_batch():
+    """BASELINE config 5 splits B=64 over ranks; a rank's slab must equal the slice of the unsplit
+    computation bit for bit (here: a 2-way split of B=4 at the full H16 N4096 D128 shape)."""
+    from rocwmma_fattn.shard import shard_bounds
+    g = torch.Generator(device=_dev()).manual_seed(77)
+    q, k, v = (torch.rand((4, 16, 4096, 128), generator=g, device=_dev(), dtype=torch.float32).half() for _ in range(3))
+    full = FlashAttentionFunction.apply(q, k, v, None, False)
+    for rank in range(2):
+        lo, hi = shard_bounds(4, 2, rank)
+        part = FlashAttentionFunction.apply(q[lo:hi], k[lo:hi], v[lo:hi], None, False)
+        assert torch.equal(part, full[lo:hi])

@@ -22,6 +22,10 @@
 //   kv = 16*ks + (j&3) + 8*(j>>2) + 4*hi, which is exactly how S^T leaves the QK^T MFMA, so P needs
 //   no cross-lane movement; V^T fragments with the same binding come from ds_read_b64_tr_b16.
 //
+// Software pipeline (per wave): iteration j issues the QK^T MFMAs of tile j+1 and, independent of
+// them, the softmax VALU work of tile j, then the PV MFMAs of tile j — so matrix and vector pipes
+// have independent work in the same instruction window.
+//
 // LDS images (row = kv row inside the tile, ROWB = HD*2 bytes per row)
 //   K: 16-byte granule gi of row r stored at r*ROWB + ((gi ^ fK(r)) << 4)   (conflict-free b128 reads
 //      by 16 lanes holding 16 different rows)
@@ -30,6 +34,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+
+// ---- tuning knobs (A/B-tested with tools/kbench.py) ----
+#ifndef FA2_DEFER_THR       // skip the O rescale while the row max grew by <= this (log2 units); <0: always rescale.
+#define FA2_DEFER_THR 8.0f  // 0 = exact FA2 (rescale whenever any row's max grows); 8 keeps P <= 2^8 (fp16/bf16 safe)
+#endif
+#ifndef FA2_PRIO_HI_HALF    // static s_setprio 1 for waves 4..7 (second wave of each SIMD)
+#define FA2_PRIO_HI_HALF 0
+#endif
+#ifndef FA2_SETPRIO_MFMA    // s_setprio 1 around the PV MFMA cluster
+#define FA2_SETPRIO_MFMA 0
+#endif
+#ifndef FA2_ABL              // developer-only ablation bitmask (results are WRONG when non-zero):
+#define FA2_ABL 0            // 1 no exp/fma, 2 no row sum, 4 no PV mfma, 8 no QK mfma, 16 no global->LDS staging,
+#endif                       // 32 no V transpose reads, 64 no K reads, 128 no max, 256 no barrier
+#ifndef FA2_SCHED_GROUPS    // explicit MFMA/VALU interleave via sched_group_barrier in the QK^T + softmax region
+#define FA2_SCHED_GROUPS 0
+#endif
 
 namespace fa2 {
 
@@ -84,9 +106,11 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
 }
 
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 __device__ __forceinline__ float half_swap_max(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float half_swap_sum(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -150,6 +174,10 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     const int qw0 = q0 + wave * kQRowsPerWave;  // first Q row of this wave
     const int qrow = qw0 + l31;                 // this lane's Q row (may be >= Nq)
 
+#if FA2_PRIO_HI_HALF
+    if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+
     // ---- Q fragments (B operand): lane reads 8 consecutive d of its row per k-step
     u32x4 qf[KS_QK];
     {
@@ -201,86 +229,124 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
         const int nt_c = qmax / kKvTile + 1;
         ntiles = nt_c < ntiles ? nt_c : ntiles;
     }
+    // causal: tiles this wave actually computes (the rest only stage + sync)
+    const int ntiles_w = CAUSAL ? ((qw0 + kQRowsPerWave - 1) / kKvTile + 1 < ntiles ? (qw0 + kQRowsPerWave - 1) / kKvTile + 1 : ntiles)
+                                : ntiles;
 
     f32x16 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-    float m_run = -INFINITY;  // running row max, raw (unscaled) score units
+    float m_run = -INFINITY;  // running row max reference, raw (unscaled) score units
     float l_run = 0.f;        // running row sum, this lane's half of the kv columns only
     const float c = p.c;
 
     u32x4 kreg[NPASS], vreg[NPASS];
-    auto stage_load = [&](int tile) {
-        const uint32_t ksoff = (uint32_t)tile * kKvTile * k_rowb;
-        const uint32_t vsoff = (uint32_t)tile * kKvTile * v_rowb;
+    auto load_k = [&](int tile) {
+        const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], ksoff, 0);
-            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], vsoff, 0);
-        }
+        for (int i = 0; i < NPASS; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
     };
-    auto stage_write = [&](int buf) {
+    auto load_v = [&](int tile) {
+        const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            *(u32x4*)(smem + buf * TILEB + kw_off[i]) = kreg[i];
-            *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
-        }
+        for (int i = 0; i < NPASS; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
+    };
+    auto write_k = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + buf * TILEB + kw_off[i]) = kreg[i];
+    };
+    auto write_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
     };
 
-    // one KV tile against this wave's 32 Q rows; BUF is the LDS buffer holding the tile
-    auto compute_tile = [&](int tile, int buf) {
-        const int kv0 = tile * kKvTile;
+    // S^T = K Q^T for one KV tile: two 32(kv) x 32(q) accumulators
+    auto qk = [&](int buf, f32x16& s0, f32x16& s1) {
         const char* kt = smem + buf * TILEB;
-        const char* vt = smem + (2 + buf) * TILEB;
-        // S^T = K Q^T : two 32(kv) x 32(q) tiles
-        f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
-            const u32x4 a0 = *(const u32x4*)(kt + kr_off[ks]);
-            const u32x4 a1 = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
-            s0 = mfma16<BF16>(a0, qf[ks], s0);
-            s1 = mfma16<BF16>(a1, qf[ks], s1);
-        }
-        // masks: causal diagonal and the ragged last KV tile (wave-uniform tests)
-        const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0);
-        const bool need_tail = kv0 + kKvTile > p.Nkv;
-        if (need_causal || need_tail) {
-            const int lim_c = CAUSAL ? qrow : 0x7fffffff;  // kv index must be <= lim_c
-            const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (kvi > lim) s0[r] = -INFINITY;
-                if (kvi + 32 > lim) s1[r] = -INFINITY;
+            u32x4 a0, a1;
+            if (FA2_ABL & 64) { a0 = qf[ks]; a1 = qf[(ks + 1) % KS_QK]; }
+            else {
+                a0 = *(const u32x4*)(kt + kr_off[ks]);
+                a1 = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
+            }
+            if (FA2_ABL & 8) {
+                s0[ks] += __uint_as_float(a0[0] ^ a0[1] ^ a0[2] ^ a0[3]);
+                s1[ks] += __uint_as_float(a1[0] ^ a1[1] ^ a1[2] ^ a1[3]);
+            } else {
+                s0 = mfma16<BF16>(a0, qf[ks], s0);
+                s1 = mfma16<BF16>(a1, qf[ks], s1);
             }
         }
-        // online softmax (reference: kernel_fp16.cu:434-490), all in f32 registers
-        float mx = fmaxf(s0[0], s1[0]);
+    };
+
+    // Scores of `tile` just left the MFMA: apply the masks (MASKED: causal diagonal / ragged last tile),
+    // reduce the row max and, when some row's max grew by more than the threshold, move the running
+    // reference max and rescale O and l (wave-uniform, rare branch).  With THR = 0 this is exact: rows
+    // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
+    // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
+    // (reference: kernel_fp16.cu:396-451)
+    auto finish_scores = [&](int tile, auto masked, f32x16& s0, f32x16& s1) {
+        if constexpr (decltype(masked)::value) {
+            const int kv0 = tile * kKvTile;
+            const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0);
+            const bool need_tail = kv0 + kKvTile > p.Nkv;
+            if (need_causal || need_tail) {
+                const int lim_c = CAUSAL ? qrow : 0x7fffffff;  // kv index must be <= lim_c
+                const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+                for (int r = 0; r < 16; ++r) {
+                    const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kvi > lim) s0[r] = -INFINITY;
+                    if (kvi + 32 > lim) s1[r] = -INFINITY;
+                }
+            }
+        }
+        float mx = max3(s0[0], s1[0], s0[1]);
+        if (!(FA2_ABL & 128)) {
+            mx = max3(mx, s1[1], s0[2]);
+#pragma unroll
+            for (int r = 2; r < 15; ++r) mx = max3(mx, s1[r], s0[r + 1]);
+            mx = __builtin_fmaxf(mx, s1[15]);
+        }
         mx = half_swap_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float mc = m_new * c;
-        const float alpha = __builtin_amdgcn_exp2f(m_run * c - mc);
-        m_run = m_new;
-        float rs = 0.f;
+        bool grow;
+        if (FA2_DEFER_THR < 0.f) grow = true;
+        else grow = __builtin_amdgcn_ballot_w64((mx - m_run) * c > FA2_DEFER_THR) != 0;
+        if (grow) {
+            const float m_new = __builtin_fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+        }
+    };
+
+    // P = 2^(S*c - m*c) against the current reference max, row sum, P -> 16-bit B fragments
+    // (reference: kernel_fp16.cu:455-479); k-step ks uses registers [8(ks&1), 8(ks&1)+8) of tile ks>>1
+    auto exp_scores = [&](f32x16& s0, f32x16& s1, u32x4 (&pf)[4]) {
+        const float mc = m_run * c;
+        float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
-            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
-            rs += s0[r] + s1[r];
+            if (!(FA2_ABL & 1)) {
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
+            }
+            if (!(FA2_ABL & 2)) {
+                rs0 += s0[r];
+                rs1 += s1[r];
+            }
         }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-        // P -> 16-bit B fragments; k-step ks uses registers [8(ks&1), 8(ks&1)+8) of tile ks>>1
-        u32x4 pf[4];
+        l_run += rs0 + rs1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             pf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
@@ -288,36 +354,94 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
             pf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
             pf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
         }
-        // O^T += V^T P^T
+    };
+
+    // O^T += V^T P^T
+    auto pv = [&](int buf, const u32x4 (&pf)[4]) {
+        const char* vt = smem + (2 + buf) * TILEB;
+#if FA2_SETPRIO_MFMA
+        __builtin_amdgcn_s_setprio(FA2_PRIO_HI_HALF ? 2 : 1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const char* va = vt + vr_off[dt] + 16 * ks * ROWB;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
-                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
-                const u32x4 a = {lo2[0], lo2[1], hi2[0], hi2[1]};
-                acc[dt] = mfma16<BF16>(a, pf[ks], acc[dt]);
+                u32x4 a;
+                if (FA2_ABL & 32) a = qf[(ks * DT + dt) % KS_QK];
+                else {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
+                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
+                    a = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
+                }
+                if (FA2_ABL & 4) acc[dt][ks] += __uint_as_float((a[0] ^ a[1] ^ a[2] ^ a[3]) & (pf[ks][0] ^ pf[ks][1] ^ pf[ks][2] ^ pf[ks][3]));
+                else acc[dt] = mfma16<BF16>(a, pf[ks], acc[dt]);
             }
         }
+#if FA2_SETPRIO_MFMA
+        __builtin_amdgcn_s_setprio(FA2_PRIO_HI_HALF ? (wave >= kWaves / 2 ? 1 : 0) : 0);
+#endif
     };
 
-    // ---- prologue: tile 0 -> LDS buffer 0
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
+    // One pipeline step.  PAR = tile & 1 selects the LDS buffers statically:
+    //   reads  K(tile+1) from K buf PAR^1, V(tile) from V buf PAR
+    //   writes K(tile+2) to   K buf PAR,   V(tile+1) to V buf PAR^1
+    // sc = finished scores of `tile` (QK^T one step earlier), sn receives the scores of tile+1.
+    // FAST = steady state: every load/compute condition is known true and tile+1 needs no mask, so
+    // the QK^T MFMAs of tile+1, the exp/pack VALU work of `tile` and the P.V MFMAs of `tile` form ONE
+    // basic block the scheduler can interleave; the only branch is the rare rescale at the end.
+    auto step = [&](int tile, auto par, auto fast, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FAST = decltype(fast)::value;
+        const bool more1 = FAST || tile + 1 < ntiles, more2 = FAST || tile + 2 < ntiles;
+        const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
+        if (more2 && !(FA2_ABL & 16)) load_k(tile + 2);  // global loads fly under the MFMA work below
+        if (more1 && !(FA2_ABL & 16)) load_v(tile + 1);
+        if (next_w) qk(PAR ^ 1, sn0, sn1);
+        if (cur_w) {
+            u32x4 pf[4];
+            exp_scores(sc0, sc1, pf);
+            pv(PAR, pf);
+        }
+        if (more2 && !(FA2_ABL & 16)) write_k(PAR);
+        if (more1 && !(FA2_ABL & 16)) write_v(PAR ^ 1);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn0, sn1);
+    };
 
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        const bool more = tile + 1 < ntiles;
-        if (more) stage_load(tile + 1);  // global loads fly under the MFMA work below
-        // causal: a wave whose rows all lie above this tile has nothing to do (still stages + syncs)
-        const bool active = !CAUSAL || (tile * kKvTile <= qw0 + kQRowsPerWave - 1);
-        if (active) compute_tile(tile, buf);
-        if (more) stage_write(buf ^ 1);
-        __syncthreads();
+    // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    if (ntiles > 1) { load_k(1); write_k(1); }
+    __syncthreads();
+    f32x16 sa0, sa1, sb0, sb1;
+    qk(0, sa0, sa1);
+    finish_scores(0, std::true_type{}, sa0, sa1);
+
+    // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
+    int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
+    {
+        const int unmasked_kv = p.Nkv / kKvTile;                       // tiles fully inside Nkv
+        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;  // tiles fully below the diagonal
+        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
+        n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;        // tile+1 <= unmasked-1
+        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
     }
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int tile = 0;
+    for (; tile < n_fast; tile += 2) {
+        step(tile, P0, std::true_type{}, sa0, sa1, sb0, sb1);
+        step(tile + 1, P1, std::true_type{}, sb0, sb1, sa0, sa1);
+    }
+    for (; tile + 1 < ntiles; tile += 2) {
+        step(tile, P0, std::false_type{}, sa0, sa1, sb0, sb1);
+        step(tile + 1, P1, std::false_type{}, sb0, sb1, sa0, sa1);
+    }
+    if (tile < ntiles) step(tile, P0, std::false_type{}, sa0, sa1, sb0, sb1);
 
     // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
     const float l_tot = half_swap_sum(l_run);

@@ -46,6 +46,20 @@
 #ifndef FA2_SETPRIO_MFMA    // s_setprio 1 around the PV MFMA cluster
 #define FA2_SETPRIO_MFMA 0
 #endif
+#ifndef FA2_PIPE             // 1: cross-tile software pipeline inside each wave (QK^T of tile+1 beside softmax of tile);
+#define FA2_PIPE 1           // 0: plain order, one barrier per tile; 2: ping-pong — the two waves of a SIMD run half a
+#endif                       //    tile apart (one in QK^T+softmax while the other is in P.V), two barriers per tile.
+                             // Measured at B2 H16 N4096 D128 fp16 (tools/kbench.py): 1 -> 1110-1125 TF, 0 -> 1060-1090,
+                             // 2 -> 1005-1055 (its QK^T -> softmax chain is serial per wave: ~970 + ~650 cycles).
+#ifndef FA2_PP_PRIO          // ping-pong: s_setprio levels for {QK^T, softmax, P.V} phases, packed as 0xQSP
+#define FA2_PP_PRIO 0x201
+#endif
+#ifndef FA2_PK_MATH          // softmax scale/subtract and row sums as packed f32 (v_pk_fma_f32 / v_pk_add_f32)
+#define FA2_PK_MATH 0
+#endif
+#ifndef FA2_TRACE            // developer-only: s_memtime stamps of the ping-pong phases of workgroup 0 into p.trace
+#define FA2_TRACE 0
+#endif
 #ifndef FA2_ABL              // developer-only ablation bitmask (results are WRONG when non-zero):
 #define FA2_ABL 0            // 1 no exp/fma, 2 no row sum, 4 no PV mfma, 8 no QK mfma, 16 no global->LDS staging,
 #endif                       // 32 no V transpose reads, 64 no K reads, 128 no max, 256 no barrier
@@ -65,11 +79,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWaves = 8;         // waves per workgroup
-constexpr int kQRowsPerWave = 32; // one 32-wide MFMA column block
-constexpr int kQBlock = kWaves * kQRowsPerWave;  // 256 Q rows per workgroup
+constexpr int kQBlock = 256;      // Q rows per workgroup (all kernel shapes)
 constexpr int kKvTile = 64;       // KV rows per tile
-constexpr int kThreads = kWaves * 64;
 
 struct FwdParams {
     const void* q;
@@ -84,6 +95,7 @@ struct FwdParams {
     int negate_q;                        // scale < 0: fold the sign into Q
     int nqblk;                           // ceil(Nq / kQBlock)
     uint32_t k_bytes, v_bytes;           // addressable bytes of one head's K / V matrix
+    unsigned long long* trace;           // FA2_TRACE builds only: [wave][tile][8] shader-clock stamps, else null
 };
 
 template <bool BF16>
@@ -119,8 +131,8 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-// LDS image geometry for head dim HD
-template <int HD>
+// LDS image geometry for head dim HD staged by NW waves
+template <int HD, int NW>
 struct Geo {
     static constexpr int ROWB = HD * 2;                       // bytes per tile row
     static constexpr int TILEB = kKvTile * ROWB;              // bytes per K (or V) tile
@@ -129,10 +141,10 @@ struct Geo {
     static constexpr int KMASK = (G < 16 ? G : 16) - 1;
     static constexpr int C = ROWB / 64;                       // 64-B chunks per row
     static constexpr int VMASK = (C < 4 ? C : 4) - 1;
-    static constexpr int NPASS = (kKvTile * G) / kThreads;    // 16-B staging loads per thread per tile
+    static constexpr int NPASS = (kKvTile * G) / (NW * 64);   // 16-B staging loads per thread per tile
     static constexpr int KS_QK = HD / 16;                     // MFMA k-steps of Q.K^T
     static constexpr int DT = HD / 32;                        // 32-wide d blocks of O
-    static_assert(NPASS >= 1, "head dim too small for the 512-thread staging pattern");
+    static_assert(NPASS >= 1, "head dim too small for the staging pattern");
     __device__ static __forceinline__ int k_off(int row, int gi) {
         return row * ROWB + ((gi ^ ((row / RPB) & KMASK)) << 4);
     }
@@ -141,11 +153,16 @@ struct Geo {
     }
 };
 
-template <int HD, bool BF16, bool CAUSAL>
-__global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
-    using G_ = Geo<HD>;
+// NW waves per workgroup, each owning QB consecutive 32-row Q blocks (NW * QB * 32 == 256):
+//   <8, 1>: two waves per SIMD, 256 VGPRs each;  <4, 2>: one wave per SIMD with the 512-register
+//   budget — every K / V^T fragment read from LDS then feeds two MFMAs instead of one.
+template <int HD, bool BF16, bool CAUSAL, int NW, int QB>
+__global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
+    static_assert(NW * QB * 32 == kQBlock, "workgroup must cover 256 Q rows");
+    using G_ = Geo<HD, NW>;
     constexpr int ROWB = G_::ROWB, TILEB = G_::TILEB, NPASS = G_::NPASS;
     constexpr int KS_QK = G_::KS_QK, DT = G_::DT;
+    constexpr int kThreads = NW * 64, kRowsPerWave = 32 * QB;
     // LDS: K buf0 | K buf1 | V buf0 | V buf1
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -159,36 +176,39 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     //      the head's K/V stay in that XCD's L2; causal runs the long (late) q blocks first.
     const int nbh = p.B * p.H;
     const int bid = blockIdx.x;
-    int bh, qb;
+    int bh, qblk;
     if ((nbh & 7) == 0) {
         const int slot = bid >> 3;
         bh = (bid & 7) + 8 * (slot / p.nqblk);
-        qb = slot % p.nqblk;
+        qblk = slot % p.nqblk;
     } else {
         bh = bid / p.nqblk;
-        qb = bid % p.nqblk;
+        qblk = bid % p.nqblk;
     }
-    if (CAUSAL) qb = p.nqblk - 1 - qb;
+    if (CAUSAL) qblk = p.nqblk - 1 - qblk;
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = qb * kQBlock;
-    const int qw0 = q0 + wave * kQRowsPerWave;  // first Q row of this wave
-    const int qrow = qw0 + l31;                 // this lane's Q row (may be >= Nq)
+    const int q0 = qblk * kQBlock;
+    const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave
+    int qrow[QB];                               // this lane's Q row in each of its blocks (may be >= Nq)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) qrow[qb] = qw0 + 32 * qb + l31;
 
 #if FA2_PRIO_HI_HALF
-    if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
     // ---- Q fragments (B operand): lane reads 8 consecutive d of its row per k-step
-    u32x4 qf[KS_QK];
-    {
-        const int qr = qrow < p.Nq ? qrow : p.Nq - 1;
+    u32x4 qf[QB][KS_QK];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
         const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
 #pragma unroll
-        for (int ks = 0; ks < KS_QK; ++ks) qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi);
+        for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi);
         if (p.negate_q) {
             const uint32_t sgn = 0x80008000u;
 #pragma unroll
-            for (int ks = 0; ks < KS_QK; ++ks) qf[ks] ^= (u32x4){sgn, sgn, sgn, sgn};
+            for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] ^= (u32x4){sgn, sgn, sgn, sgn};
         }
     }
 
@@ -230,57 +250,70 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
         ntiles = nt_c < ntiles ? nt_c : ntiles;
     }
     // causal: tiles this wave actually computes (the rest only stage + sync)
-    const int ntiles_w = CAUSAL ? ((qw0 + kQRowsPerWave - 1) / kKvTile + 1 < ntiles ? (qw0 + kQRowsPerWave - 1) / kKvTile + 1 : ntiles)
-                                : ntiles;
+    int ntiles_w = ntiles;
+    if (CAUSAL) {
+        const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
+        ntiles_w = nt_w < ntiles ? nt_w : ntiles;
+    }
 
-    f32x16 acc[DT];
+    f32x16 acc[QB][DT];
+    float m_run[QB], l_run[QB];  // running reference max (raw score units) / row sum (this lane's kv half)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-    float m_run = -INFINITY;  // running row max reference, raw (unscaled) score units
-    float l_run = 0.f;        // running row sum, this lane's half of the kv columns only
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
+    }
     const float c = p.c;
 
     u32x4 kreg[NPASS], vreg[NPASS];
-    auto load_k = [&](int tile) {
+    auto load_k = [&](int tile) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
     };
-    auto load_v = [&](int tile) {
+    auto load_v = [&](int tile) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
     };
-    auto write_k = [&](int buf) {
+    auto write_k = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + buf * TILEB + kw_off[i]) = kreg[i];
     };
-    auto write_v = [&](int buf) {
+    auto write_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
     };
 
-    // S^T = K Q^T for one KV tile: two 32(kv) x 32(q) accumulators
-    auto qk = [&](int buf, f32x16& s0, f32x16& s1) {
+    // S^T = K Q^T for one KV tile: per Q block two 32(kv) x 32(q) accumulators; each K fragment
+    // read from LDS feeds QB MFMAs
+    auto qk = [&](int buf, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
         const char* kt = smem + buf * TILEB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[qb][0][r] = 0.f; s[qb][1][r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
             u32x4 a0, a1;
-            if (FA2_ABL & 64) { a0 = qf[ks]; a1 = qf[(ks + 1) % KS_QK]; }
+            if (FA2_ABL & 64) { a0 = qf[0][ks]; a1 = qf[0][(ks + 1) % KS_QK]; }
             else {
                 a0 = *(const u32x4*)(kt + kr_off[ks]);
                 a1 = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
             }
-            if (FA2_ABL & 8) {
-                s0[ks] += __uint_as_float(a0[0] ^ a0[1] ^ a0[2] ^ a0[3]);
-                s1[ks] += __uint_as_float(a1[0] ^ a1[1] ^ a1[2] ^ a1[3]);
-            } else {
-                s0 = mfma16<BF16>(a0, qf[ks], s0);
-                s1 = mfma16<BF16>(a1, qf[ks], s1);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (FA2_ABL & 8) {
+                    s[qb][0][ks] += __uint_as_float(a0[0] ^ a0[1] ^ a0[2] ^ a0[3]);
+                    s[qb][1][ks] += __uint_as_float(a1[0] ^ a1[1] ^ a1[2] ^ a1[3]);
+                } else {
+                    s[qb][0] = mfma16<BF16>(a0, qf[qb][ks], s[qb][0]);
+                    s[qb][1] = mfma16<BF16>(a1, qf[qb][ks], s[qb][1]);
+                }
             }
         }
     };
@@ -291,76 +324,109 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
-    auto finish_scores = [&](int tile, auto masked, f32x16& s0, f32x16& s1) {
-        if constexpr (decltype(masked)::value) {
-            const int kv0 = tile * kKvTile;
-            const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0);
-            const bool need_tail = kv0 + kKvTile > p.Nkv;
-            if (need_causal || need_tail) {
-                const int lim_c = CAUSAL ? qrow : 0x7fffffff;  // kv index must be <= lim_c
-                const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
+        float mx[QB];
+        bool grow = FA2_DEFER_THR < 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kvi > lim) s0[r] = -INFINITY;
-                    if (kvi + 32 > lim) s1[r] = -INFINITY;
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x16& s0 = s[qb][0];
+            f32x16& s1 = s[qb][1];
+            if constexpr (decltype(masked)::value) {
+                const int kv0 = tile * kKvTile;
+                const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0 + 32 * qb);
+                const bool need_tail = kv0 + kKvTile > p.Nkv;
+                if (need_causal || need_tail) {
+                    const int lim_c = CAUSAL ? qrow[qb] : 0x7fffffff;  // kv index must be <= lim_c
+                    const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kvi > lim) s0[r] = -INFINITY;
+                        if (kvi + 32 > lim) s1[r] = -INFINITY;
+                    }
                 }
             }
-        }
-        float mx = max3(s0[0], s1[0], s0[1]);
-        if (!(FA2_ABL & 128)) {
-            mx = max3(mx, s1[1], s0[2]);
+            float m = max3(s0[0], s1[0], s0[1]);
+            if (!(FA2_ABL & 128)) {
+                m = max3(m, s1[1], s0[2]);
 #pragma unroll
-            for (int r = 2; r < 15; ++r) mx = max3(mx, s1[r], s0[r + 1]);
-            mx = __builtin_fmaxf(mx, s1[15]);
+                for (int r = 2; r < 15; ++r) m = max3(m, s1[r], s0[r + 1]);
+                m = __builtin_fmaxf(m, s1[15]);
+            }
+            mx[qb] = half_swap_max(m);
+            if (!(FA2_DEFER_THR < 0.f))
+                grow = grow || (__builtin_amdgcn_ballot_w64((mx[qb] - m_run[qb]) * c > FA2_DEFER_THR) != 0);
         }
-        mx = half_swap_max(mx);
-        bool grow;
-        if (FA2_DEFER_THR < 0.f) grow = true;
-        else grow = __builtin_amdgcn_ballot_w64((mx - m_run) * c > FA2_DEFER_THR) != 0;
         if (grow) {
-            const float m_new = __builtin_fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m_new = __builtin_fmaxf(m_run[qb], mx[qb]);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[qb][dt][r] *= alpha;
+            }
         }
     };
 
     // P = 2^(S*c - m*c) against the current reference max, row sum, P -> 16-bit B fragments
     // (reference: kernel_fp16.cu:455-479); k-step ks uses registers [8(ks&1), 8(ks&1)+8) of tile ks>>1
-    auto exp_scores = [&](f32x16& s0, f32x16& s1, u32x4 (&pf)[4]) {
-        const float mc = m_run * c;
-        float rs0 = 0.f, rs1 = 0.f;
+    auto exp_scores = [&](f32x16 (&s)[QB][2], u32x4 (&pf)[QB][4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (!(FA2_ABL & 1)) {
-                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
-                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
-            }
-            if (!(FA2_ABL & 2)) {
-                rs0 += s0[r];
-                rs1 += s1[r];
-            }
-        }
-        l_run += rs0 + rs1;
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x16& s0 = s[qb][0];
+            f32x16& s1 = s[qb][1];
+            const float mc = m_run[qb] * c;
+            float rs0 = 0.f, rs1 = 0.f;
+#if FA2_PK_MATH
+            const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            f32x2 ra = {0.f, 0.f}, rb = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
-            pf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
-            pf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
-            pf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 x0 = {s0[r], s0[r + 1]}, x1 = {s1[r], s1[r + 1]};
+                x0 = x0 * c2 + nmc2;
+                x1 = x1 * c2 + nmc2;
+                s0[r] = __builtin_amdgcn_exp2f(x0[0]);
+                s0[r + 1] = __builtin_amdgcn_exp2f(x0[1]);
+                s1[r] = __builtin_amdgcn_exp2f(x1[0]);
+                s1[r + 1] = __builtin_amdgcn_exp2f(x1[1]);
+                ra += (f32x2){s0[r], s0[r + 1]};
+                rb += (f32x2){s1[r], s1[r + 1]};
+            }
+            rs0 = ra[0] + ra[1];
+            rs1 = rb[0] + rb[1];
+#else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!(FA2_ABL & 1)) {
+                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
+                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
+                }
+                if (!(FA2_ABL & 2)) {
+                    rs0 += s0[r];
+                    rs1 += s1[r];
+                }
+            }
+#endif
+            l_run[qb] += rs0 + rs1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[qb][0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
+                pf[qb][1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
+                pf[qb][2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
+                pf[qb][3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            }
         }
     };
 
-    // O^T += V^T P^T
-    auto pv = [&](int buf, const u32x4 (&pf)[4]) {
+    // O^T += V^T P^T; each V^T fragment read from LDS feeds QB MFMAs
+    auto pv = [&](int buf, const u32x4 (&pf)[QB][4]) __attribute__((always_inline)) {
         const char* vt = smem + (2 + buf) * TILEB;
 #if FA2_SETPRIO_MFMA
-        __builtin_amdgcn_s_setprio(FA2_PRIO_HI_HALF ? 2 : 1);
+        __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -368,19 +434,24 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
             for (int dt = 0; dt < DT; ++dt) {
                 const char* va = vt + vr_off[dt] + 16 * ks * ROWB;
                 u32x4 a;
-                if (FA2_ABL & 32) a = qf[(ks * DT + dt) % KS_QK];
+                if (FA2_ABL & 32) a = qf[0][(ks * DT + dt) % KS_QK];
                 else {
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
                     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
                     const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
                     a = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
                 }
-                if (FA2_ABL & 4) acc[dt][ks] += __uint_as_float((a[0] ^ a[1] ^ a[2] ^ a[3]) & (pf[ks][0] ^ pf[ks][1] ^ pf[ks][2] ^ pf[ks][3]));
-                else acc[dt] = mfma16<BF16>(a, pf[ks], acc[dt]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (FA2_ABL & 4)
+                        acc[qb][dt][ks] += __uint_as_float((a[0] ^ a[1] ^ a[2] ^ a[3]) &
+                                                           (pf[qb][ks][0] ^ pf[qb][ks][1] ^ pf[qb][ks][2] ^ pf[qb][ks][3]));
+                    else acc[qb][dt] = mfma16<BF16>(a, pf[qb][ks], acc[qb][dt]);
+                }
             }
         }
 #if FA2_SETPRIO_MFMA
-        __builtin_amdgcn_s_setprio(FA2_PRIO_HI_HALF ? (wave >= kWaves / 2 ? 1 : 0) : 0);
+        __builtin_amdgcn_s_setprio(0);
 #endif
     };
 
@@ -391,25 +462,120 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     // FAST = steady state: every load/compute condition is known true and tile+1 needs no mask, so
     // the QK^T MFMAs of tile+1, the exp/pack VALU work of `tile` and the P.V MFMAs of `tile` form ONE
     // basic block the scheduler can interleave; the only branch is the rare rescale at the end.
-    auto step = [&](int tile, auto par, auto fast, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1) {
+    auto step = [&](int tile, auto par, auto fast, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
         constexpr bool FAST = decltype(fast)::value;
         const bool more1 = FAST || tile + 1 < ntiles, more2 = FAST || tile + 2 < ntiles;
         const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
         if (more2 && !(FA2_ABL & 16)) load_k(tile + 2);  // global loads fly under the MFMA work below
         if (more1 && !(FA2_ABL & 16)) load_v(tile + 1);
-        if (next_w) qk(PAR ^ 1, sn0, sn1);
+        if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
-            u32x4 pf[4];
-            exp_scores(sc0, sc1, pf);
+            u32x4 pf[QB][4];
+            exp_scores(sc, pf);
             pv(PAR, pf);
         }
         if (more2 && !(FA2_ABL & 16)) write_k(PAR);
         if (more1 && !(FA2_ABL & 16)) write_v(PAR ^ 1);
         if (!(FA2_ABL & 256)) __syncthreads();
-        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn0, sn1);
+        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn);
     };
 
+#if FA2_PIPE == 2
+    // ---- ping-pong schedule (needs two waves per SIMD: NW == 8).  Group A = waves 0..3, group B =
+    // waves 4..7; wave w and w+4 share a SIMD.  Every tile has two intervals separated by barriers:
+    //   interval 2j   : A: QK^T(j) + softmax(j)          B: P.V(j-1)
+    //   interval 2j+1 : A: P.V(j)                        B: QK^T(j) + softmax(j)     then all waves write
+    //                   tile j+1 (loaded during interval 2j) into LDS buffer (j+1)&1
+    // so one wave's softmax VALU work always runs beside its SIMD partner's P.V MFMAs, and the QK^T
+    // MFMAs (raised priority) never wait behind them.  LDS: K(j), V(j) live in buffer j&1; interval
+    // 2j+1 reads only buffer j&1, so the writes into buffer (j+1)&1 need no extra barrier.
+    static_assert(NW == 8 && QB == 1, "ping-pong needs two waves per SIMD");
+#if FA2_TRACE
+#define FA2_STAMP(tile, ev)                                                                          \
+    do {                                                                                             \
+        if (p.trace && bid == 0 && lane == 0 && (tile) < 64)                                         \
+            p.trace[((wave * 64) + (tile)) * 8 + (ev)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define FA2_STAMP(tile, ev) do { } while (0)
+#endif
+    const bool grp_b = wave >= NW / 2;
+    f32x16 sc[QB][2];
+    u32x4 pf[QB][4];
+    auto phase_qk_sm = [&](int tile, int buf) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 8) & 3);
+        qk(buf, sc);
+        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
+        FA2_STAMP(tile, 6);
+        finish_scores(tile, std::true_type{}, sc);
+        exp_scores(sc, pf);
+    };
+    auto phase_pv = [&](int buf) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(FA2_PP_PRIO & 3);
+        pv(buf, pf);
+        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
+    };
+    // Group A and group B run separate (rotated) copies of the tile loop; both execute exactly two
+    // barriers per tile, so the workgroup barrier pairs them up interval by interval.
+    auto tile_a = [&](int tile, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        const bool more1 = tile + 1 < ntiles;
+        FA2_STAMP(tile, 0);
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (tile < ntiles_w) phase_qk_sm(tile, PAR);               // interval 2*tile
+        FA2_STAMP(tile, 1);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 2);
+        if (tile < ntiles_w) phase_pv(PAR);                        // interval 2*tile + 1
+        FA2_STAMP(tile, 3);
+        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        FA2_STAMP(tile, 4);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 5);
+    };
+    auto tile_b = [&](int tile, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        const bool more1 = tile + 1 < ntiles;
+        FA2_STAMP(tile, 0);
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (tile >= 1 && tile - 1 < ntiles_w) phase_pv(PAR ^ 1);   // interval 2*tile: P.V of the previous tile
+        FA2_STAMP(tile, 1);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 2);
+        if (tile < ntiles_w) phase_qk_sm(tile, PAR);               // interval 2*tile + 1
+        FA2_STAMP(tile, 3);
+        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        FA2_STAMP(tile, 4);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 5);
+    };
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    __syncthreads();
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    if (!grp_b) {
+        int tile = 0;
+        for (; tile + 1 < ntiles; tile += 2) {
+            tile_a(tile, P0);
+            tile_a(tile + 1, P1);
+        }
+        if (tile < ntiles) tile_a(tile, P0);
+    } else {
+        int tile = 0;
+        for (; tile + 1 < ntiles; tile += 2) {
+            tile_b(tile, P0);
+            tile_b(tile + 1, P1);
+        }
+        if (tile < ntiles) tile_b(tile, P0);
+        // drain: group B still owes P.V of the last tile it computed
+        if (ntiles - 1 < ntiles_w) phase_pv((ntiles - 1) & 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#elif FA2_PIPE == 1
     // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
     load_k(0);
     load_v(0);
@@ -417,9 +583,9 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     write_v(0);
     if (ntiles > 1) { load_k(1); write_k(1); }
     __syncthreads();
-    f32x16 sa0, sa1, sb0, sb1;
-    qk(0, sa0, sa1);
-    finish_scores(0, std::true_type{}, sa0, sa1);
+    f32x16 sa[QB][2], sb[QB][2];
+    qk(0, sa);
+    finish_scores(0, std::true_type{}, sa);
 
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
@@ -434,38 +600,88 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const FwdParams p) {
     constexpr std::integral_constant<int, 1> P1{};
     int tile = 0;
     for (; tile < n_fast; tile += 2) {
-        step(tile, P0, std::true_type{}, sa0, sa1, sb0, sb1);
-        step(tile + 1, P1, std::true_type{}, sb0, sb1, sa0, sa1);
+        step(tile, P0, std::true_type{}, sa, sb);
+        step(tile + 1, P1, std::true_type{}, sb, sa);
     }
     for (; tile + 1 < ntiles; tile += 2) {
-        step(tile, P0, std::false_type{}, sa0, sa1, sb0, sb1);
-        step(tile + 1, P1, std::false_type{}, sb0, sb1, sa0, sa1);
+        step(tile, P0, std::false_type{}, sa, sb);
+        step(tile + 1, P1, std::false_type{}, sb, sa);
     }
-    if (tile < ntiles) step(tile, P0, std::false_type{}, sa0, sa1, sb0, sb1);
+    if (tile < ntiles) step(tile, P0, std::false_type{}, sa, sb);
+
+#else
+    // Plain order: tile's K and V both live in buffer PAR; next tile is staged into PAR^1.
+    auto step_plain = [&](int tile, auto par, auto fast, f32x16 (&sc)[QB][2]) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FAST = decltype(fast)::value;
+        const bool more1 = FAST || tile + 1 < ntiles;
+        const bool cur_w = FAST || tile < ntiles_w;
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (cur_w) {
+            qk(PAR, sc);
+            finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc);
+            u32x4 pf[QB][4];
+            exp_scores(sc, pf);
+            pv(PAR, pf);
+        }
+        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        if (!(FA2_ABL & 256)) __syncthreads();
+    };
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    __syncthreads();
+    f32x16 sa[QB][2];
+    int n_fast = ntiles - 1 < ntiles_w ? ntiles - 1 : ntiles_w;
+    {
+        const int unmasked_kv = p.Nkv / kKvTile;
+        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;
+        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
+        n_fast = n_fast < unmasked ? n_fast : unmasked;
+        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
+    }
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int tile = 0;
+    for (; tile < n_fast; tile += 2) {
+        step_plain(tile, P0, std::true_type{}, sa);
+        step_plain(tile + 1, P1, std::true_type{}, sa);
+    }
+    for (; tile + 1 < ntiles; tile += 2) {
+        step_plain(tile, P0, std::false_type{}, sa);
+        step_plain(tile + 1, P1, std::false_type{}, sa);
+    }
+    if (tile < ntiles) step_plain(tile, P0, std::false_type{}, sa);
+#endif
 
     // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
-    const float l_tot = half_swap_sum(l_run);
-    const float inv_l = 1.0f / l_tot;
-    if (qrow < p.Nq) {
-        uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow * p.os[2];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = half_swap_sum(l_run[qb]);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow[qb] < p.Nq) {
+            uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow[qb] * p.os[2];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4 += 2) {
-                // lane holds d = 32dt + 8*r4 + 4*hi + {0..3} (group r4) and the same for r4+1
-                uint32_t a0 = pack2<BF16>(acc[dt][4 * r4 + 0] * inv_l, acc[dt][4 * r4 + 1] * inv_l);
-                uint32_t a1 = pack2<BF16>(acc[dt][4 * r4 + 2] * inv_l, acc[dt][4 * r4 + 3] * inv_l);
-                uint32_t b0 = pack2<BF16>(acc[dt][4 * r4 + 4] * inv_l, acc[dt][4 * r4 + 5] * inv_l);
-                uint32_t b1 = pack2<BF16>(acc[dt][4 * r4 + 6] * inv_l, acc[dt][4 * r4 + 7] * inv_l);
-                // half exchange: lower lanes end with 8 consecutive d of group r4, upper of r4+1
-                auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
-                *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4 += 2) {
+                    const f32x16& a = acc[qb][dt];
+                    // lane holds d = 32dt + 8*r4 + 4*hi + {0..3} (group r4) and the same for r4+1
+                    uint32_t a0 = pack2<BF16>(a[4 * r4 + 0] * inv_l, a[4 * r4 + 1] * inv_l);
+                    uint32_t a1 = pack2<BF16>(a[4 * r4 + 2] * inv_l, a[4 * r4 + 3] * inv_l);
+                    uint32_t b0 = pack2<BF16>(a[4 * r4 + 4] * inv_l, a[4 * r4 + 5] * inv_l);
+                    uint32_t b1 = pack2<BF16>(a[4 * r4 + 6] * inv_l, a[4 * r4 + 7] * inv_l);
+                    // half exchange: lower lanes end with 8 consecutive d of group r4, upper of r4+1
+                    auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
+                    *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
+                }
             }
+            if (hi == 0)
+                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = m_run[qb] * c + __builtin_amdgcn_logf(l_tot);
         }
-        if (hi == 0)
-            p.lse[b * p.ls[0] + h * p.ls[1] + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);
     }
 }
 

@@ -20,17 +20,25 @@ namespace {
 constexpr int kHeadDims[] = {64, 128};
 constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 
+// Workgroup shape: NW waves x QB 32-row Q blocks per wave (NW * QB * 32 = 256 Q rows).
+#ifndef FA2_NW
+#define FA2_NW 8
+#endif
+constexpr int kNW = FA2_NW, kQB = 8 / FA2_NW;
+
 template <int HD, bool BF16>
 int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
-    constexpr int lds = 4 * fa2::Geo<HD>::TILEB;
+    constexpr int lds = 4 * fa2::Geo<HD, kNW>::TILEB;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk));
-    const dim3 block(fa2::kThreads);
+    const dim3 block(kNW * 64);
     if (causal)
-        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, true>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, true, kNW, kQB>), grid, block, lds, stream, p);
     else
-        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, false>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, false, kNW, kQB>), grid, block, lds, stream, p);
     return (int)hipGetLastError();
 }
+
+unsigned long long* g_trace = nullptr;  // developer builds (-DFA2_TRACE=1) only; always null otherwise
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 bool strides_ok(const int64_t* s) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0 && s[2] > 0; }
@@ -106,6 +114,7 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     p.nqblk = (Nq + fa2::kQBlock - 1) / fa2::kQBlock;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
+    p.trace = g_trace;
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -132,5 +141,10 @@ int fa2_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* ls
     return fa2_fwd(FA2_DTYPE_BF16, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides,
                    o_strides, lse_strides, scale, causal, hip_stream);
 }
+
+#if FA2_TRACE
+// developer-only (tools/trace_phases.py): device buffer of 8 waves x 64 tiles x 8 stamps
+void fa2_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+#endif
 
 }  // extern "C"

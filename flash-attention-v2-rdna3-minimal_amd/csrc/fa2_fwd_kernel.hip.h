@@ -54,6 +54,15 @@
 #ifndef FA2_PP_PRIO          // ping-pong: s_setprio levels for {QK^T, softmax, P.V} phases, packed as 0xQSP
 #define FA2_PP_PRIO 0x201
 #endif
+#ifndef FA2_LDS_DMA          // stage K/V tiles with buffer_load ... lds (no staging VGPRs, no ds_write); the LDS swizzle
+#define FA2_LDS_DMA 1        // is applied to the per-lane SOURCE address, the LDS image stays lane-linear.
+#endif                       // Measured (kbench): D=128 +3 % non-causal, +6 % causal; D=64 -3 % -> register staging there
+#ifndef FA2_LDS_DMA_MIN_HD
+#define FA2_LDS_DMA_MIN_HD 128
+#endif
+#ifndef FA2_LDS_PREFETCH     // issue ALL K (V^T) fragment reads of a tile before its first MFMA (the compiler otherwise keeps
+#define FA2_LDS_PREFETCH 0   // them one k-step ahead and every step eats the ~100-cycle LDS latency); costs 64 transient VGPRs
+#endif
 #ifndef FA2_PK_MATH          // softmax scale/subtract and row sums as packed f32 (v_pk_fma_f32 / v_pk_add_f32)
 #define FA2_PK_MATH 0
 #endif
@@ -130,6 +139,14 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// 16 bytes per lane, global (buffer descriptor, zero for out-of-range) -> LDS at wave-uniform `lds_dst` + lane*16
+template <typename RSRC>
+__device__ __forceinline__ void dma16_to_lds(RSRC rsrc, char* lds_dst, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
 
 // LDS image geometry for head dim HD staged by NW waves
 template <int HD, int NW>
@@ -269,24 +286,52 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     }
     const float c = p.c;
 
+    // Staging.  DMA form (head dims >= FA2_LDS_DMA_MIN_HD): buffer_load ... lds writes the tile image
+    // directly — no staging VGPRs, no ds_write; wave-instruction i of this wave fills the 1 KiB of the
+    // image starting at linear granule (wave*64 + kThreads*i), and lane l supplies the global address of
+    // the granule that belongs at image slot (wave*64 + kThreads*i + l), i.e. the inverse of the k_off /
+    // v_off swizzle (the image itself stays lane-linear).  The destination buffer must be free when the
+    // load is ISSUED.  Register form: global -> VGPRs at issue, ds_write_b128 at the end of the step.
+    constexpr bool kDma = FA2_LDS_DMA && HD >= FA2_LDS_DMA_MIN_HD;
+    static_assert(!(kDma && FA2_PIPE == 2), "2-phase ping-pong issues its loads while the destination buffer is still being read");
+    uint32_t kd_off[NPASS], vd_off[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int idx = tid + kThreads * i;
+        const int row = idx / G_::G, slot = idx % G_::G;
+        const int gk = slot ^ ((row / G_::RPB) & G_::KMASK);
+        const int gv = ((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3);
+        kd_off[i] = row * k_rowb + gk * 16;
+        vd_off[i] = row * v_rowb + gv * 16;
+    }
     u32x4 kreg[NPASS], vreg[NPASS];
-    auto load_k = [&](int tile) __attribute__((always_inline)) {
+    auto load_k = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
+        for (int i = 0; i < NPASS; ++i) {
+            if constexpr (kDma) dma16_to_lds(krs, smem + buf * TILEB + (wave * 64 + kThreads * i) * 16, kd_off[i], soff);
+            else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
+        }
     };
-    auto load_v = [&](int tile) __attribute__((always_inline)) {
+    auto load_v = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
+        for (int i = 0; i < NPASS; ++i) {
+            if constexpr (kDma) dma16_to_lds(vrs, smem + (2 + buf) * TILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
+            else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
+        }
     };
     auto write_k = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (!kDma) {
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + buf * TILEB + kw_off[i]) = kreg[i];
+            for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + buf * TILEB + kw_off[i]) = kreg[i];
+        }
     };
     auto write_v = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (!kDma) {
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
+            for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
+        }
     };
 
     // S^T = K Q^T for one KV tile: per Q block two 32(kv) x 32(q) accumulators; each K fragment
@@ -297,6 +342,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[qb][0][r] = 0.f; s[qb][1][r] = 0.f; }
+#if FA2_LDS_PREFETCH
+        u32x4 ka[KS_QK][2];
+#pragma unroll
+        for (int ks = 0; ks < KS_QK; ++ks) {
+            ka[ks][0] = *(const u32x4*)(kt + kr_off[ks]);
+            ka[ks][1] = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS_QK; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                s[qb][0] = mfma16<BF16>(ka[ks][0], qf[qb][ks], s[qb][0]);
+                s[qb][1] = mfma16<BF16>(ka[ks][1], qf[qb][ks], s[qb][1]);
+            }
+#else
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
             u32x4 a0, a1;
@@ -316,6 +377,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
         }
+#endif
     };
 
     // Scores of `tile` just left the MFMA: apply the masks (MASKED: causal diagonal / ragged last tile),
@@ -428,6 +490,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #if FA2_SETPRIO_MFMA
         __builtin_amdgcn_s_setprio(1);
 #endif
+#if FA2_LDS_PREFETCH
+        u32x4 va_[4][DT];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* va = vt + vr_off[dt] + 16 * ks * ROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
+                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
+                va_[ks][dt] = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) acc[qb][dt] = mfma16<BF16>(va_[ks][dt], pf[qb][ks], acc[qb][dt]);
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -450,6 +532,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
         }
+#endif
 #if FA2_SETPRIO_MFMA
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -467,8 +550,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         constexpr bool FAST = decltype(fast)::value;
         const bool more1 = FAST || tile + 1 < ntiles, more2 = FAST || tile + 2 < ntiles;
         const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
-        if (more2 && !(FA2_ABL & 16)) load_k(tile + 2);  // global loads fly under the MFMA work below
-        if (more1 && !(FA2_ABL & 16)) load_v(tile + 1);
+        if (more2 && !(FA2_ABL & 16)) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
+        if (more1 && !(FA2_ABL & 16)) load_v(tile + 1, PAR ^ 1);
         if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
             u32x4 pf[QB][4];
@@ -481,6 +564,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn);
     };
 
+#if FA2_TRACE
+#define FA2_STAMP(tile, ev)                                                                          \
+    do {                                                                                             \
+        if (p.trace && bid == 0 && lane == 0 && (tile) < 64)                                         \
+            p.trace[((wave * 64) + (tile)) * 8 + (ev)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define FA2_STAMP(tile, ev) do { } while (0)
+#endif
 #if FA2_PIPE == 2
     // ---- ping-pong schedule (needs two waves per SIMD: NW == 8).  Group A = waves 0..3, group B =
     // waves 4..7; wave w and w+4 share a SIMD.  Every tile has two intervals separated by barriers:
@@ -491,15 +583,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // MFMAs (raised priority) never wait behind them.  LDS: K(j), V(j) live in buffer j&1; interval
     // 2j+1 reads only buffer j&1, so the writes into buffer (j+1)&1 need no extra barrier.
     static_assert(NW == 8 && QB == 1, "ping-pong needs two waves per SIMD");
-#if FA2_TRACE
-#define FA2_STAMP(tile, ev)                                                                          \
-    do {                                                                                             \
-        if (p.trace && bid == 0 && lane == 0 && (tile) < 64)                                         \
-            p.trace[((wave * 64) + (tile)) * 8 + (ev)] = __builtin_amdgcn_s_memtime();               \
-    } while (0)
-#else
-#define FA2_STAMP(tile, ev) do { } while (0)
-#endif
     const bool grp_b = wave >= NW / 2;
     f32x16 sc[QB][2];
     u32x4 pf[QB][4];
@@ -522,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         constexpr int PAR = decltype(par)::value;
         const bool more1 = tile + 1 < ntiles;
         FA2_STAMP(tile, 0);
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
         if (tile < ntiles_w) phase_qk_sm(tile, PAR);               // interval 2*tile
         FA2_STAMP(tile, 1);
         if (!(FA2_ABL & 256)) __syncthreads();
@@ -538,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         constexpr int PAR = decltype(par)::value;
         const bool more1 = tile + 1 < ntiles;
         FA2_STAMP(tile, 0);
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
         if (tile >= 1 && tile - 1 < ntiles_w) phase_pv(PAR ^ 1);   // interval 2*tile: P.V of the previous tile
         FA2_STAMP(tile, 1);
         if (!(FA2_ABL & 256)) __syncthreads();
@@ -550,8 +633,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (!(FA2_ABL & 256)) __syncthreads();
         FA2_STAMP(tile, 5);
     };
-    load_k(0);
-    load_v(0);
+    load_k(0, 0);
+    load_v(0, 0);
     write_k(0);
     write_v(0);
     __syncthreads();
@@ -575,13 +658,111 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (ntiles - 1 < ntiles_w) phase_pv((ntiles - 1) & 1);
     }
     __builtin_amdgcn_s_setprio(0);
-#elif FA2_PIPE == 1
-    // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
-    load_k(0);
-    load_v(0);
+#elif FA2_PIPE == 3
+    // ---- three-phase ping-pong (needs two waves per SIMD: NW == 8).  Every wave cycles through
+    // QK^T -> softmax -> P.V; group B (waves 4..7) runs ONE PHASE behind group A (waves 0..3), and a
+    // barrier separates the phases, so on every SIMD
+    //   interval 3j   : A: QK^T(j)      B: P.V(j-1)     (both matrix)
+    //   interval 3j+1 : A: softmax(j)   B: QK^T(j)      (vector beside matrix)
+    //   interval 3j+2 : A: P.V(j)       B: softmax(j)   (matrix beside vector)
+    // LDS: K(j), V(j) live in buffer j&1.  K(j+1) may be written once interval 3j-2 is over, V(j+1) once
+    // interval 3j is over (B's P.V(j-1) read it); both must be visible at interval 3j+3.  DMA staging
+    // issues K(j+1) at the start of interval 3j and V(j+1) at the start of 3j+1; register staging loads
+    // at the tile start and writes at the end of interval 3j+2.  Only the barrier closing interval 3j+2
+    // orders memory (__syncthreads); the other two only align the phases (raw s_barrier).
+    static_assert(NW == 8 && QB == 1, "ping-pong needs two waves per SIMD");
+    const bool grp_b = wave >= NW / 2;
+    f32x16 sc[QB][2];
+    u32x4 pf[QB][4];
+    auto phase_qk = [&](int buf) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 8) & 3);
+        qk(buf, sc);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase_sm = [&](int tile) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
+        finish_scores(tile, std::true_type{}, sc);
+        exp_scores(sc, pf);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase_pv = [&](int buf) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(FA2_PP_PRIO & 3);
+        pv(buf, pf);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto align_phase = [&]() __attribute__((always_inline)) {
+        if (!(FA2_ABL & 256)) __builtin_amdgcn_s_barrier();
+    };
+    auto tile_a = [&](int tile, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        const bool more1 = tile + 1 < ntiles, cur = tile < ntiles_w;
+        FA2_STAMP(tile, 0);
+        if (more1) { load_k(tile + 1, PAR ^ 1); if (!kDma) load_v(tile + 1, PAR ^ 1); }
+        if (cur) phase_qk(PAR);                 // interval 3*tile
+        FA2_STAMP(tile, 1);
+        align_phase();
+        FA2_STAMP(tile, 2);
+        if (more1 && kDma) load_v(tile + 1, PAR ^ 1);
+        if (cur) phase_sm(tile);                // interval 3*tile + 1
+        FA2_STAMP(tile, 3);
+        align_phase();
+        FA2_STAMP(tile, 4);
+        if (cur) phase_pv(PAR);                 // interval 3*tile + 2
+        if (more1) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        FA2_STAMP(tile, 5);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 6);
+    };
+    auto tile_b = [&](int tile, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        const bool more1 = tile + 1 < ntiles, cur = tile < ntiles_w;
+        FA2_STAMP(tile, 0);
+        if (more1) { load_k(tile + 1, PAR ^ 1); if (!kDma) load_v(tile + 1, PAR ^ 1); }
+        if (tile >= 1 && tile - 1 < ntiles_w) phase_pv(PAR ^ 1);   // interval 3*tile: P.V of the previous tile
+        FA2_STAMP(tile, 1);
+        align_phase();
+        FA2_STAMP(tile, 2);
+        if (more1 && kDma) load_v(tile + 1, PAR ^ 1);
+        if (cur) phase_qk(PAR);                 // interval 3*tile + 1
+        FA2_STAMP(tile, 3);
+        align_phase();
+        FA2_STAMP(tile, 4);
+        if (cur) phase_sm(tile);                // interval 3*tile + 2
+        if (more1) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        FA2_STAMP(tile, 5);
+        if (!(FA2_ABL & 256)) __syncthreads();
+        FA2_STAMP(tile, 6);
+    };
+    load_k(0, 0);
+    load_v(0, 0);
     write_k(0);
     write_v(0);
-    if (ntiles > 1) { load_k(1); write_k(1); }
+    __syncthreads();
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    if (!grp_b) {
+        int tile = 0;
+        for (; tile + 1 < ntiles; tile += 2) {
+            tile_a(tile, P0);
+            tile_a(tile + 1, P1);
+        }
+        if (tile < ntiles) tile_a(tile, P0);
+    } else {
+        int tile = 0;
+        for (; tile + 1 < ntiles; tile += 2) {
+            tile_b(tile, P0);
+            tile_b(tile + 1, P1);
+        }
+        if (tile < ntiles) tile_b(tile, P0);
+        if (ntiles - 1 < ntiles_w) phase_pv((ntiles - 1) & 1);     // drain: P.V of the last tile
+    }
+#elif FA2_PIPE == 1
+    // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
+    load_k(0, 0);
+    load_v(0, 0);
+    write_k(0);
+    write_v(0);
+    if (ntiles > 1) { load_k(1, 1); write_k(1); }
     __syncthreads();
     f32x16 sa[QB][2], sb[QB][2];
     qk(0, sa);
@@ -616,7 +797,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         constexpr bool FAST = decltype(fast)::value;
         const bool more1 = FAST || tile + 1 < ntiles;
         const bool cur_w = FAST || tile < ntiles_w;
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1); load_v(tile + 1); }
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
         if (cur_w) {
             qk(PAR, sc);
             finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc);
@@ -627,8 +808,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
         if (!(FA2_ABL & 256)) __syncthreads();
     };
-    load_k(0);
-    load_v(0);
+    load_k(0, 0);
+    load_v(0, 0);
     write_k(0);
     write_v(0);
     __syncthreads();

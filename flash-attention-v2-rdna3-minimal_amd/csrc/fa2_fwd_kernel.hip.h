@@ -36,45 +36,24 @@
 #include <stdint.h>
 #include <type_traits>
 
-// ---- tuning knobs (A/B-tested with tools/kbench.py) ----
-#ifndef FA2_DEFER_THR       // skip the O rescale while the row max grew by <= this (log2 units); <0: always rescale.
-#define FA2_DEFER_THR 8.0f  // 0 = exact FA2 (rescale whenever any row's max grows); 8 keeps P <= 2^8 (fp16/bf16 safe)
-#endif
-#ifndef FA2_PRIO_HI_HALF    // static s_setprio 1 for waves 4..7 (second wave of each SIMD)
-#define FA2_PRIO_HI_HALF 0
-#endif
-#ifndef FA2_SETPRIO_MFMA    // s_setprio 1 around the PV MFMA cluster
-#define FA2_SETPRIO_MFMA 0
+// ---- tuning knobs (A/B-tested on MI355X with tools/kbench.py; numbers at B2 H16 N4096 D128 fp16) ----
+#ifndef FA2_DEFER_THR        // skip the O rescale while the row max grew by <= this (log2 units); <0: always rescale.
+#define FA2_DEFER_THR 8.0f   // 0 = exact FA2 (rescale whenever any row's max grows); 8 keeps P <= 2^8 (fp16/bf16 safe): +5 %
 #endif
 #ifndef FA2_PIPE             // 1: cross-tile software pipeline inside each wave (QK^T of tile+1 beside softmax of tile);
-#define FA2_PIPE 1           // 0: plain order, one barrier per tile; 2: ping-pong — the two waves of a SIMD run half a
-#endif                       //    tile apart (one in QK^T+softmax while the other is in P.V), two barriers per tile.
-                             // Measured at B2 H16 N4096 D128 fp16 (tools/kbench.py): 1 -> 1110-1125 TF, 0 -> 1060-1090,
-                             // 2 -> 1005-1055 (its QK^T -> softmax chain is serial per wave: ~970 + ~650 cycles).
-#ifndef FA2_PP_PRIO          // ping-pong: s_setprio levels for {QK^T, softmax, P.V} phases, packed as 0xQSP
-#define FA2_PP_PRIO 0x201
+#define FA2_PIPE 1           // 0: plain order.  1 -> 1130-1180 TF, 0 -> 1090-1125 TF
 #endif
 #ifndef FA2_LDS_DMA          // stage K/V tiles with buffer_load ... lds (no staging VGPRs, no ds_write); the LDS swizzle
 #define FA2_LDS_DMA 1        // is applied to the per-lane SOURCE address, the LDS image stays lane-linear.
-#endif                       // Measured (kbench): D=128 +3 % non-causal, +6 % causal; D=64 -3 % -> register staging there
+#endif                       // D=128: +3 % non-causal, +6 % causal; D=64: -3 % -> register staging below FA2_LDS_DMA_MIN_HD
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
-#endif
-#ifndef FA2_LDS_PREFETCH     // issue ALL K (V^T) fragment reads of a tile before its first MFMA (the compiler otherwise keeps
-#define FA2_LDS_PREFETCH 0   // them one k-step ahead and every step eats the ~100-cycle LDS latency); costs 64 transient VGPRs
-#endif
-#ifndef FA2_PK_MATH          // softmax scale/subtract and row sums as packed f32 (v_pk_fma_f32 / v_pk_add_f32)
-#define FA2_PK_MATH 0
-#endif
-#ifndef FA2_TRACE            // developer-only: s_memtime stamps of the ping-pong phases of workgroup 0 into p.trace
-#define FA2_TRACE 0
 #endif
 #ifndef FA2_ABL              // developer-only ablation bitmask (results are WRONG when non-zero):
 #define FA2_ABL 0            // 1 no exp/fma, 2 no row sum, 4 no PV mfma, 8 no QK mfma, 16 no global->LDS staging,
 #endif                       // 32 no V transpose reads, 64 no K reads, 128 no max, 256 no barrier
-#ifndef FA2_SCHED_GROUPS    // explicit MFMA/VALU interleave via sched_group_barrier in the QK^T + softmax region
-#define FA2_SCHED_GROUPS 0
-#endif
+// Tried and dropped (git history has the code; DESIGN.md §3 the measurements): s_setprio variants, 2- and 3-phase
+// ping-pong of the two waves of a SIMD, issuing all LDS fragment reads of a phase up front, packed-f32 softmax math.
 
 namespace fa2 {
 
@@ -104,7 +83,6 @@ struct FwdParams {
     int negate_q;                        // scale < 0: fold the sign into Q
     int nqblk;                           // ceil(Nq / kQBlock)
     uint32_t k_bytes, v_bytes;           // addressable bytes of one head's K / V matrix
-    unsigned long long* trace;           // FA2_TRACE builds only: [wave][tile][8] shader-clock stamps, else null
 };
 
 template <bool BF16>
@@ -210,10 +188,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) qrow[qb] = qw0 + 32 * qb + l31;
 
-#if FA2_PRIO_HI_HALF
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-
     // ---- Q fragments (B operand): lane reads 8 consecutive d of its row per k-step
     u32x4 qf[QB][KS_QK];
 #pragma unroll
@@ -293,7 +267,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // v_off swizzle (the image itself stays lane-linear).  The destination buffer must be free when the
     // load is ISSUED.  Register form: global -> VGPRs at issue, ds_write_b128 at the end of the step.
     constexpr bool kDma = FA2_LDS_DMA && HD >= FA2_LDS_DMA_MIN_HD;
-    static_assert(!(kDma && FA2_PIPE == 2), "2-phase ping-pong issues its loads while the destination buffer is still being read");
     uint32_t kd_off[NPASS], vd_off[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -342,22 +315,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[qb][0][r] = 0.f; s[qb][1][r] = 0.f; }
-#if FA2_LDS_PREFETCH
-        u32x4 ka[KS_QK][2];
-#pragma unroll
-        for (int ks = 0; ks < KS_QK; ++ks) {
-            ka[ks][0] = *(const u32x4*)(kt + kr_off[ks]);
-            ka[ks][1] = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS_QK; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                s[qb][0] = mfma16<BF16>(ka[ks][0], qf[qb][ks], s[qb][0]);
-                s[qb][1] = mfma16<BF16>(ka[ks][1], qf[qb][ks], s[qb][1]);
-            }
-#else
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
             u32x4 a0, a1;
@@ -377,7 +334,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
         }
-#endif
     };
 
     // Scores of `tile` just left the MFMA: apply the masks (MASKED: causal diagonal / ragged last tile),
@@ -443,24 +399,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             f32x16& s1 = s[qb][1];
             const float mc = m_run[qb] * c;
             float rs0 = 0.f, rs1 = 0.f;
-#if FA2_PK_MATH
-            const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
-            f32x2 ra = {0.f, 0.f}, rb = {0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 x0 = {s0[r], s0[r + 1]}, x1 = {s1[r], s1[r + 1]};
-                x0 = x0 * c2 + nmc2;
-                x1 = x1 * c2 + nmc2;
-                s0[r] = __builtin_amdgcn_exp2f(x0[0]);
-                s0[r + 1] = __builtin_amdgcn_exp2f(x0[1]);
-                s1[r] = __builtin_amdgcn_exp2f(x1[0]);
-                s1[r + 1] = __builtin_amdgcn_exp2f(x1[1]);
-                ra += (f32x2){s0[r], s0[r + 1]};
-                rb += (f32x2){s1[r], s1[r + 1]};
-            }
-            rs0 = ra[0] + ra[1];
-            rs1 = rb[0] + rb[1];
-#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!(FA2_ABL & 1)) {
@@ -472,7 +410,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                     rs1 += s1[r];
                 }
             }
-#endif
             l_run[qb] += rs0 + rs1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -487,29 +424,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // O^T += V^T P^T; each V^T fragment read from LDS feeds QB MFMAs
     auto pv = [&](int buf, const u32x4 (&pf)[QB][4]) __attribute__((always_inline)) {
         const char* vt = smem + (2 + buf) * TILEB;
-#if FA2_SETPRIO_MFMA
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#if FA2_LDS_PREFETCH
-        u32x4 va_[4][DT];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const char* va = vt + vr_off[dt] + 16 * ks * ROWB;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
-                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
-                va_[ks][dt] = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) acc[qb][dt] = mfma16<BF16>(va_[ks][dt], pf[qb][ks], acc[qb][dt]);
-#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -532,10 +446,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
         }
-#endif
-#if FA2_SETPRIO_MFMA
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // One pipeline step.  PAR = tile & 1 selects the LDS buffers statically:
@@ -564,199 +474,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn);
     };
 
-#if FA2_TRACE
-#define FA2_STAMP(tile, ev)                                                                          \
-    do {                                                                                             \
-        if (p.trace && bid == 0 && lane == 0 && (tile) < 64)                                         \
-            p.trace[((wave * 64) + (tile)) * 8 + (ev)] = __builtin_amdgcn_s_memtime();               \
-    } while (0)
-#else
-#define FA2_STAMP(tile, ev) do { } while (0)
-#endif
-#if FA2_PIPE == 2
-    // ---- ping-pong schedule (needs two waves per SIMD: NW == 8).  Group A = waves 0..3, group B =
-    // waves 4..7; wave w and w+4 share a SIMD.  Every tile has two intervals separated by barriers:
-    //   interval 2j   : A: QK^T(j) + softmax(j)          B: P.V(j-1)
-    //   interval 2j+1 : A: P.V(j)                        B: QK^T(j) + softmax(j)     then all waves write
-    //                   tile j+1 (loaded during interval 2j) into LDS buffer (j+1)&1
-    // so one wave's softmax VALU work always runs beside its SIMD partner's P.V MFMAs, and the QK^T
-    // MFMAs (raised priority) never wait behind them.  LDS: K(j), V(j) live in buffer j&1; interval
-    // 2j+1 reads only buffer j&1, so the writes into buffer (j+1)&1 need no extra barrier.
-    static_assert(NW == 8 && QB == 1, "ping-pong needs two waves per SIMD");
-    const bool grp_b = wave >= NW / 2;
-    f32x16 sc[QB][2];
-    u32x4 pf[QB][4];
-    auto phase_qk_sm = [&](int tile, int buf) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 8) & 3);
-        qk(buf, sc);
-        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
-        FA2_STAMP(tile, 6);
-        finish_scores(tile, std::true_type{}, sc);
-        exp_scores(sc, pf);
-    };
-    auto phase_pv = [&](int buf) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(FA2_PP_PRIO & 3);
-        pv(buf, pf);
-        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
-    };
-    // Group A and group B run separate (rotated) copies of the tile loop; both execute exactly two
-    // barriers per tile, so the workgroup barrier pairs them up interval by interval.
-    auto tile_a = [&](int tile, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        const bool more1 = tile + 1 < ntiles;
-        FA2_STAMP(tile, 0);
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
-        if (tile < ntiles_w) phase_qk_sm(tile, PAR);               // interval 2*tile
-        FA2_STAMP(tile, 1);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 2);
-        if (tile < ntiles_w) phase_pv(PAR);                        // interval 2*tile + 1
-        FA2_STAMP(tile, 3);
-        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
-        FA2_STAMP(tile, 4);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 5);
-    };
-    auto tile_b = [&](int tile, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        const bool more1 = tile + 1 < ntiles;
-        FA2_STAMP(tile, 0);
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
-        if (tile >= 1 && tile - 1 < ntiles_w) phase_pv(PAR ^ 1);   // interval 2*tile: P.V of the previous tile
-        FA2_STAMP(tile, 1);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 2);
-        if (tile < ntiles_w) phase_qk_sm(tile, PAR);               // interval 2*tile + 1
-        FA2_STAMP(tile, 3);
-        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
-        FA2_STAMP(tile, 4);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 5);
-    };
-    load_k(0, 0);
-    load_v(0, 0);
-    write_k(0);
-    write_v(0);
-    __syncthreads();
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    if (!grp_b) {
-        int tile = 0;
-        for (; tile + 1 < ntiles; tile += 2) {
-            tile_a(tile, P0);
-            tile_a(tile + 1, P1);
-        }
-        if (tile < ntiles) tile_a(tile, P0);
-    } else {
-        int tile = 0;
-        for (; tile + 1 < ntiles; tile += 2) {
-            tile_b(tile, P0);
-            tile_b(tile + 1, P1);
-        }
-        if (tile < ntiles) tile_b(tile, P0);
-        // drain: group B still owes P.V of the last tile it computed
-        if (ntiles - 1 < ntiles_w) phase_pv((ntiles - 1) & 1);
-    }
-    __builtin_amdgcn_s_setprio(0);
-#elif FA2_PIPE == 3
-    // ---- three-phase ping-pong (needs two waves per SIMD: NW == 8).  Every wave cycles through
-    // QK^T -> softmax -> P.V; group B (waves 4..7) runs ONE PHASE behind group A (waves 0..3), and a
-    // barrier separates the phases, so on every SIMD
-    //   interval 3j   : A: QK^T(j)      B: P.V(j-1)     (both matrix)
-    //   interval 3j+1 : A: softmax(j)   B: QK^T(j)      (vector beside matrix)
-    //   interval 3j+2 : A: P.V(j)       B: softmax(j)   (matrix beside vector)
-    // LDS: K(j), V(j) live in buffer j&1.  K(j+1) may be written once interval 3j-2 is over, V(j+1) once
-    // interval 3j is over (B's P.V(j-1) read it); both must be visible at interval 3j+3.  DMA staging
-    // issues K(j+1) at the start of interval 3j and V(j+1) at the start of 3j+1; register staging loads
-    // at the tile start and writes at the end of interval 3j+2.  Only the barrier closing interval 3j+2
-    // orders memory (__syncthreads); the other two only align the phases (raw s_barrier).
-    static_assert(NW == 8 && QB == 1, "ping-pong needs two waves per SIMD");
-    const bool grp_b = wave >= NW / 2;
-    f32x16 sc[QB][2];
-    u32x4 pf[QB][4];
-    auto phase_qk = [&](int buf) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 8) & 3);
-        qk(buf, sc);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto phase_sm = [&](int tile) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio((FA2_PP_PRIO >> 4) & 3);
-        finish_scores(tile, std::true_type{}, sc);
-        exp_scores(sc, pf);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto phase_pv = [&](int buf) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(FA2_PP_PRIO & 3);
-        pv(buf, pf);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto align_phase = [&]() __attribute__((always_inline)) {
-        if (!(FA2_ABL & 256)) __builtin_amdgcn_s_barrier();
-    };
-    auto tile_a = [&](int tile, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        const bool more1 = tile + 1 < ntiles, cur = tile < ntiles_w;
-        FA2_STAMP(tile, 0);
-        if (more1) { load_k(tile + 1, PAR ^ 1); if (!kDma) load_v(tile + 1, PAR ^ 1); }
-        if (cur) phase_qk(PAR);                 // interval 3*tile
-        FA2_STAMP(tile, 1);
-        align_phase();
-        FA2_STAMP(tile, 2);
-        if (more1 && kDma) load_v(tile + 1, PAR ^ 1);
-        if (cur) phase_sm(tile);                // interval 3*tile + 1
-        FA2_STAMP(tile, 3);
-        align_phase();
-        FA2_STAMP(tile, 4);
-        if (cur) phase_pv(PAR);                 // interval 3*tile + 2
-        if (more1) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
-        FA2_STAMP(tile, 5);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 6);
-    };
-    auto tile_b = [&](int tile, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        const bool more1 = tile + 1 < ntiles, cur = tile < ntiles_w;
-        FA2_STAMP(tile, 0);
-        if (more1) { load_k(tile + 1, PAR ^ 1); if (!kDma) load_v(tile + 1, PAR ^ 1); }
-        if (tile >= 1 && tile - 1 < ntiles_w) phase_pv(PAR ^ 1);   // interval 3*tile: P.V of the previous tile
-        FA2_STAMP(tile, 1);
-        align_phase();
-        FA2_STAMP(tile, 2);
-        if (more1 && kDma) load_v(tile + 1, PAR ^ 1);
-        if (cur) phase_qk(PAR);                 // interval 3*tile + 1
-        FA2_STAMP(tile, 3);
-        align_phase();
-        FA2_STAMP(tile, 4);
-        if (cur) phase_sm(tile);                // interval 3*tile + 2
-        if (more1) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
-        FA2_STAMP(tile, 5);
-        if (!(FA2_ABL & 256)) __syncthreads();
-        FA2_STAMP(tile, 6);
-    };
-    load_k(0, 0);
-    load_v(0, 0);
-    write_k(0);
-    write_v(0);
-    __syncthreads();
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    if (!grp_b) {
-        int tile = 0;
-        for (; tile + 1 < ntiles; tile += 2) {
-            tile_a(tile, P0);
-            tile_a(tile + 1, P1);
-        }
-        if (tile < ntiles) tile_a(tile, P0);
-    } else {
-        int tile = 0;
-        for (; tile + 1 < ntiles; tile += 2) {
-            tile_b(tile, P0);
-            tile_b(tile + 1, P1);
-        }
-        if (tile < ntiles) tile_b(tile, P0);
-        if (ntiles - 1 < ntiles_w) phase_pv((ntiles - 1) & 1);     // drain: P.V of the last tile
-    }
-#elif FA2_PIPE == 1
+#if FA2_PIPE == 1
     // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
     load_k(0, 0);
     load_v(0, 0);

@@ -38,8 +38,6 @@ int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-unsigned long long* g_trace = nullptr;  // developer builds (-DFA2_TRACE=1) only; always null otherwise
-
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 bool strides_ok(const int64_t* s) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0 && s[2] > 0; }
 
@@ -83,7 +81,7 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.1 (8-wave 256x64 mfma32x32x16, lds double buffer)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.2 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined)"; }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
             int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
@@ -114,7 +112,6 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     p.nqblk = (Nq + fa2::kQBlock - 1) / fa2::kQBlock;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
-    p.trace = g_trace;
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -141,10 +138,5 @@ int fa2_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* ls
     return fa2_fwd(FA2_DTYPE_BF16, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides,
                    o_strides, lse_strides, scale, causal, hip_stream);
 }
-
-#if FA2_TRACE
-// developer-only (tools/trace_phases.py): device buffer of 8 waves x 64 tiles x 8 stamps
-void fa2_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
-#endif
 
 }  // extern "C"

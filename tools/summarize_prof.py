@@ -49,6 +49,7 @@ if "FETCH_SIZE" in res:
     print("hbm_bytes_per_launch (2*FETCH_SIZE*1024 + WRITE_SIZE*1024) = %.4g" % (fetch_b + write_b))
     print(json.dumps({"fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b}))
 if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs (4 per CU, 256 CUs)
-    print("MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) = %.4f"
-          % (res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 1024)))
+    # SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs
+    cyc = res["GRBM_GUI_ACTIVE"] / 8.0
+    print("kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs) = %.0f; MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * cycles) = %.4f"
+          % (cyc, res["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)))

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 STAMP_PATH = LIB_PATH + ".stamp"
 
 SOURCES = ["host.cpp"]
-HEADERS = ["fa2_fwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h")]
+HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h")]
 
 HIPCC_FLAGS = [
     "-x", "hip",

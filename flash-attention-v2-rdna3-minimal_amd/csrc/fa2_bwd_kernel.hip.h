@@ -1,0 +1,445 @@
+// fa2_bwd_kernel.hip.h — FlashAttention-2 backward for MI355X (gfx950 / CDNA4), device side.
+//
+// Replaces the reference's bwd_kernel + mul_add_AT_B (rocwmma_fattn/kernel_fp16.cu:65-112, :547-740; bf16
+// twin kernel_bf16.cu:87-135, :580-798).  The reference accumulates dQ with an unsynchronised global
+// read-modify-write across KV blocks (kernel_fp16.cu:736, racy by design); here every output is owned by
+// exactly one workgroup, so the result is deterministic and needs no atomics, at the price of recomputing
+// S in each of the three passes:
+//
+//   bwd_delta_kernel                D_i = rowsum(dO_i * O_i)                  (kernel_fp16.cu:605-631)
+//   bwd_dq_kernel                   workgroup = 256 Q rows, sweeps KV tiles:   dQ  = sum_j dS_ij K_j
+//   bwd_dkv_kernel<WANT_DK=false>   workgroup = 256 KV rows, sweeps Q tiles:   dV  = sum_i P_ij^T dO_i
+//   bwd_dkv_kernel<WANT_DK=true>    same sweep:                               dK  = sum_i dS_ij^T Q_i
+// with P = 2^(S*c - L_i) (L = the forward's log2-domain LSE, so no running max is needed),
+// dP = dO V^T, dS = scale * P * (dP - D_i)                                    (kernel_fp16.cu:684-735).
+//
+// All products reuse the forward kernel's two MFMA forms (fa2_fwd_kernel.hip.h):
+//   "row" form   C^T[r, n] = A[r, :] . B[n, :]   A = 32 rows of an LDS tile (ds_read_b128, K-style image),
+//                                                B = register fragments of the wave's own 32 rows
+//   "tr" form    C^T[d, n] = sum_k T[k, d] X[k, n]  A = transpose-read of an LDS tile (V-style image),
+//                                                X = 16-bit fragments straight from a row-form result
+// In bwd_dq the wave's own rows are Q rows (lane = q: L_i, D_i are per-lane scalars, as in the forward);
+// in bwd_dkv they are KV rows (lane = kv) and L_i, D_i vary along the accumulator registers, so they are
+// staged through LDS and fetched as float4 per group of four consecutive q.
+#pragma once
+#include "fa2_fwd_kernel.hip.h"
+
+namespace fa2 {
+
+struct BwdParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* o;
+    const void* dout;
+    const float* lse;
+    float* delta;     // workspace [B,H,Nq] f32, same strides as lse
+    void* dq;
+    void* dk;
+    void* dv;
+    int B, H, Nq, Nkv;
+    int64_t qs[3], ks[3], vs[3], os[3], dos[3], dqs[3], dks[3], dvs[3];  // element strides: batch, head, row
+    int64_t ls[2];                                                       // lse / delta strides: batch, head
+    float scale, c;                                                      // scale, scale * log2(e)
+    int nblk;                                                            // row blocks (of 256) of the swept-over owner
+    uint32_t q_bytes, k_bytes, v_bytes, do_bytes, l_bytes;               // addressable bytes of one head's matrices
+};
+
+// 4 bytes per lane, global -> LDS at wave-uniform `lds_dst` + lane*4 (zero for out-of-range)
+template <typename RSRC>
+__device__ __forceinline__ void dma4_to_lds(RSRC rsrc, char* lds_dst, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, voff, soff, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// D_i = sum_d dO[i,d] * O[i,d]   (f32).  16 lanes per row (8 elements each), 4 rows per wave.
+template <bool BF16>
+__global__ __launch_bounds__(256) void bwd_delta_kernel(const BwdParams p, int D) {
+    const int lane16 = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // flattened (b, h, i)
+    const int64_t total = (int64_t)p.B * p.H * p.Nq;
+    float acc = 0.f;
+    if (row < total) {
+        const int i = (int)(row % p.Nq);
+        const int bh = (int)(row / p.Nq);
+        const int b = bh / p.H, h = bh % p.H;
+        const uint16_t* op = (const uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)i * p.os[2];
+        const uint16_t* gp = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1] + (int64_t)i * p.dos[2];
+        for (int d = lane16 * 8; d < D; d += 128) {
+            const u32x4 a = *(const u32x4*)(op + d), g = *(const u32x4*)(gp + d);
+            if constexpr (BF16) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    acc += __uint_as_float(a[w] << 16) * __uint_as_float(g[w] << 16) +
+                           __uint_as_float(a[w] & 0xffff0000u) * __uint_as_float(g[w] & 0xffff0000u);
+            } else {
+                // (whole-vector bit_cast: a per-element __builtin_bit_cast(f16x2, a[w]) in an unrolled loop was
+                // folded to element 0 by hipcc 7.2)
+                const f16x8 ah = __builtin_bit_cast(f16x8, a), gh = __builtin_bit_cast(f16x8, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)ah[e] * (float)gh[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (row < total && lane16 == 0) {
+        const int i = (int)(row % p.Nq);
+        const int bh = (int)(row / p.Nq);
+        p.delta[(bh / p.H) * p.ls[0] + (bh % p.H) * p.ls[1] + i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shared per-lane LDS offsets and DMA source permutations (see the forward kernel for the image layouts).
+template <int HD>
+struct BwdLane {
+    using G_ = Geo<HD, 8>;
+    static constexpr int NPASS = G_::NPASS, KS = G_::KS_QK, DT = G_::DT, ROWB = G_::ROWB, TILEB = G_::TILEB;
+    int kr_off[KS];              // row-form A fragment: row lane&31 of a 32-row half tile, k-step ks
+    int vr_off[DT];              // tr-form A fragment base for d block dt
+    uint32_t r_src[NPASS];       // DMA source byte offset (minus row pitch term) for a row-form image
+    uint32_t t_src[NPASS];       // ... for a tr-form image
+    int rowi[NPASS];             // tile row this lane's DMA piece belongs to
+    __device__ __forceinline__ void init(int tid, int lane) {
+        const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kr_off[ks] = G_::k_off(l31, 2 * ks + hi);
+        const int pp = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            vr_off[dt] = G_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int idx = tid + 512 * i;
+            const int row = idx / G_::G, slot = idx % G_::G;
+            rowi[i] = row;
+            r_src[i] = (slot ^ ((row / G_::RPB) & G_::KMASK)) * 16;
+            t_src[i] = (((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3)) * 16;
+        }
+    }
+};
+
+// 16-bit store of an O^T-layout accumulator (lane = column n = lane & 31, rows d) to row-major [n][d] memory
+template <bool BF16, int DT>
+__device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* rowp, int hi, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4 += 2) {
+            const f32x16& a = acc[dt];
+            uint32_t a0 = pack2<BF16>(a[4 * r4 + 0] * mul, a[4 * r4 + 1] * mul);
+            uint32_t a1 = pack2<BF16>(a[4 * r4 + 2] * mul, a[4 * r4 + 3] * mul);
+            uint32_t b0 = pack2<BF16>(a[4 * r4 + 4] * mul, a[4 * r4 + 5] * mul);
+            uint32_t b1 = pack2<BF16>(a[4 * r4 + 6] * mul, a[4 * r4 + 7] * mul);
+            auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
+            *(u32x4*)(rowp + 32 * dt + 8 * (r4 + hi)) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dQ: workgroup = 256 Q rows (8 waves x 32), sweep over KV tiles of 64.
+// LDS per stage: K row-form | V row-form | K tr-form; two stages.
+template <int HD, bool BF16, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
+    using L_ = BwdLane<HD>;
+    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int STAGEB = 3 * TILEB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbh = p.B * p.H, bid = blockIdx.x;
+    int bh, qblk;
+    if ((nbh & 7) == 0) { const int slot = bid >> 3; bh = (bid & 7) + 8 * (slot / p.nblk); qblk = slot % p.nblk; }
+    else { bh = bid / p.nblk; qblk = bid % p.nblk; }
+    if (CAUSAL) qblk = p.nblk - 1 - qblk;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * kQBlock, qw0 = q0 + 32 * wave, qrow = qw0 + l31;
+    const int qr = qrow < p.Nq ? qrow : p.Nq - 1;
+
+    L_ ln;
+    ln.init(tid, lane);
+    u32x4 qf[KS], gf[KS];
+    {
+        const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
+        const uint16_t* gp = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1] + (int64_t)qr * p.dos[2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi); gf[ks] = *(const u32x4*)(gp + 16 * ks + 8 * hi); }
+    }
+    const float Lq = p.lse[b * p.ls[0] + h * p.ls[1] + qr];
+    const float Dq = p.delta[b * p.ls[0] + h * p.ls[1] + qr];
+
+    const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
+    const uint16_t* vbase = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1];
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+    const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
+
+    int ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
+    if (CAUSAL) {
+        const int qmax = (q0 + kQBlock < p.Nq ? q0 + kQBlock : p.Nq) - 1;
+        const int nt_c = qmax / kKvTile + 1;
+        ntiles = nt_c < ntiles ? nt_c : ntiles;
+    }
+    int ntiles_w = ntiles;
+    if (CAUSAL) { const int nt_w = (qw0 + 31) / kKvTile + 1; ntiles_w = nt_w < ntiles ? nt_w : ntiles; }
+
+    auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGEB;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            char* dst = base + (wave * 64 + 512 * i) * 16;
+            const uint32_t krow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * k_rowb;
+            const uint32_t vrow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * v_rowb;
+            dma16_to_lds(krs, dst, krow + ln.r_src[i], 0);
+            dma16_to_lds(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
+            dma16_to_lds(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+        }
+    };
+
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const float c = p.c, scale = p.scale;
+
+    stage_load(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int st = tile & 1;
+        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
+        if (tile < ntiles_w) {
+            const char* kR = smem + st * STAGEB;
+            const char* vR = kR + TILEB;
+            const char* kT = kR + 2 * TILEB;
+            f32x16 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                     // S^T = K Q^T
+                s0 = mfma16<BF16>(*(const u32x4*)(kR + ln.kr_off[ks]), qf[ks], s0);
+                s1 = mfma16<BF16>(*(const u32x4*)(kR + ln.kr_off[ks] + 32 * ROWB), qf[ks], s1);
+            }
+            const int kv0 = tile * kKvTile;
+            const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0);
+            const bool need_tail = kv0 + kKvTile > p.Nkv;
+            int lim = 0x7fffffff;
+            if (need_causal || need_tail) {
+                const int lim_c = CAUSAL ? qrow : 0x7fffffff;
+                lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+            }
+            // P^T = 2^(S^T c - L); masked entries -> 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -Lq));
+                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -Lq));
+                s0[r] = kvi > lim ? 0.f : p0;
+                s1[r] = kvi + 32 > lim ? 0.f : p1;
+            }
+            f32x16 d0, d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                     // dP^T = V dO^T
+                d0 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks]), gf[ks], d0);
+                d1 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks] + 32 * ROWB), gf[ks], d1);
+            }
+            // dS^T = scale * P^T * (dP^T - D)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = s0[r] * (d0[r] - Dq) * scale;
+                s1[r] = s1[r] * (d1[r] - Dq) * scale;
+            }
+            u32x4 df[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                df[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
+                df[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
+                df[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
+                df[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)                         // dQ^T += K^T dS^T
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* va = kT + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
+                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                    acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, df[ks], acc[dt]);
+                }
+        }
+        __syncthreads();
+    }
+    if (qrow < p.Nq) {
+        uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
+        store_acc_t<BF16, DT>(acc, op, hi, 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dV (WANT_DK = false) or dK (WANT_DK = true): workgroup = 256 KV rows (8 waves x 32), sweep over Q tiles of 64.
+// LDS per stage: Q row-form | (dK: dO row-form | Q tr-form)  (dV: dO tr-form) | L[64] | D[64]; two stages.
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK>
+__global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
+    using L_ = BwdLane<HD>;
+    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NT = WANT_DK ? 3 : 2;
+    constexpr int STAGEB = NT * TILEB + 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbh = p.B * p.H, bid = blockIdx.x;
+    int bh, kblk;
+    if ((nbh & 7) == 0) { const int slot = bid >> 3; bh = (bid & 7) + 8 * (slot / p.nblk); kblk = slot % p.nblk; }
+    else { bh = bid / p.nblk; kblk = bid % p.nblk; }
+    const int b = bh / p.H, h = bh % p.H;
+    const int kv0 = kblk * kQBlock, kvw0 = kv0 + 32 * wave, kvrow = kvw0 + l31;   // this lane's KV row
+    const int kr = kvrow < p.Nkv ? kvrow : p.Nkv - 1;
+
+    L_ ln;
+    ln.init(tid, lane);
+    u32x4 kf[KS], vf[WANT_DK ? KS : 1];
+    {
+        const uint16_t* kp = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1] + (int64_t)kr * p.ks[2];
+        const uint16_t* vp = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1] + (int64_t)kr * p.vs[2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *(const u32x4*)(kp + 16 * ks + 8 * hi);
+            if constexpr (WANT_DK) vf[ks] = *(const u32x4*)(vp + 16 * ks + 8 * hi);
+        }
+    }
+    const uint16_t* qbase = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1];
+    const uint16_t* gbase = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1];
+    const auto qrs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
+    const auto grs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, p.do_bytes, 0x00020000);
+    const auto lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + b * p.ls[0] + h * p.ls[1]), 0, p.l_bytes, 0x00020000);
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + b * p.ls[0] + h * p.ls[1]), 0, p.l_bytes, 0x00020000);
+    const uint32_t q_rowb = (uint32_t)p.qs[2] * 2u, g_rowb = (uint32_t)p.dos[2] * 2u;
+
+    // Q tiles that can touch this workgroup's KV rows: causal keeps only q >= kv (top-left aligned)
+    const int ntiles = (p.Nq + kKvTile - 1) / kKvTile;
+    const int tile0 = CAUSAL ? kv0 / kKvTile : 0;
+    const int tile0_w = CAUSAL ? kvw0 / kKvTile : 0;     // this wave's first useful tile
+
+    auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGEB;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            char* dst = base + (wave * 64 + 512 * i) * 16;
+            const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
+            const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
+            dma16_to_lds(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
+            if constexpr (WANT_DK) {
+                dma16_to_lds(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                   // dO row-form
+                dma16_to_lds(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);               // Q tr-form
+            } else {
+                dma16_to_lds(grs, dst + TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
+            }
+        }
+        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+        if (WANT_DK && wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+    };
+
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const float c = p.c, scale = p.scale;
+
+    if (tile0 < ntiles) stage_load(tile0, 0);
+    __syncthreads();
+    for (int tile = tile0; tile < ntiles; ++tile) {
+        const int st = (tile - tile0) & 1;
+        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+        if (tile >= tile0_w) {
+            const char* qR = smem + st * STAGEB;
+            const char* lt = qR + NT * TILEB;
+            f32x16 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                     // S[q, kv] = Q K^T  (lane = kv)
+                s0 = mfma16<BF16>(*(const u32x4*)(qR + ln.kr_off[ks]), kf[ks], s0);
+                s1 = mfma16<BF16>(*(const u32x4*)(qR + ln.kr_off[ks] + 32 * ROWB), kf[ks], s1);
+            }
+            f32x16 d0, d1;
+            if constexpr (WANT_DK) {
+                const char* gR = qR + TILEB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {                 // dP[q, kv] = dO V^T
+                    d0 = mfma16<BF16>(*(const u32x4*)(gR + ln.kr_off[ks]), vf[ks], d0);
+                    d1 = mfma16<BF16>(*(const u32x4*)(gR + ln.kr_off[ks] + 32 * ROWB), vf[ks], d1);
+                }
+            }
+            const int q0t = tile * kKvTile;
+            const bool need_causal = CAUSAL && (kvw0 + 31 > q0t);   // some (q, kv) of this wave has kv > q
+            // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 L0 = *(const f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
+                const f32x4 L1 = *(const f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
+                f32x4 D0, D1;
+                if constexpr (WANT_DK) {
+                    D0 = *(const f32x4*)(lt + 256 + (8 * g4 + 4 * hi) * 4);
+                    D1 = *(const f32x4*)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int qi = q0t + e + 8 * g4 + 4 * hi;
+                    float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
+                    float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
+                    if (need_causal) {
+                        if (kvrow > qi) p0 = 0.f;
+                        if (kvrow > qi + 32) p1 = 0.f;
+                    }
+                    if constexpr (WANT_DK) {
+                        p0 = p0 * (d0[r] - D0[e]) * scale;
+                        p1 = p1 * (d1[r] - D1[e]) * scale;
+                    }
+                    s0[r] = p0;
+                    s1[r] = p1;
+                }
+            }
+            u32x4 xf[4];   // P (dV) or dS (dK) as B fragments: contraction index = q
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
+                xf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
+                xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
+                xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            }
+            const char* tT = qR + (WANT_DK ? 2 : 1) * TILEB;       // Q tr-form (dK) or dO tr-form (dV)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)                         // dK^T += Q^T dS   /   dV^T += dO^T P
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* va = tT + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
+                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                    acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], acc[dt]);
+                }
+        }
+        __syncthreads();
+    }
+    if (kvrow < p.Nkv) {
+        uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
+                               : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
+        store_acc_t<BF16, DT>(acc, op, hi, 1.0f);
+    }
+}
+
+}  // namespace fa2

@@ -4,11 +4,14 @@
 //   rocwmma_fattn/host.cpp:30-45        dtype switch forward()        -> fa2_fwd
 //   rocwmma_fattn/kernel_fp16.cu:744-876 forward_fp16 host launcher   -> fa2_fwd_f16
 //   rocwmma_fattn/kernel_bf16.cu:802-941 forward_bf16 host launcher   -> fa2_fwd_bf16
+//   rocwmma_fattn/host.cpp:47-58         dtype switch backward()       -> fa2_bwd
+//   rocwmma_fattn/kernel_fp16.cu:878-1028 backward_fp16 host launcher  -> fa2_bwd_f16 (bf16 twin -> fa2_bwd_bf16)
 // Unlike the reference this layer owns no tensors and allocates nothing: padding, output allocation
 // and the 6-tensor return contract live in the Python operator (rocwmma_fattn/FlashAttn.py), the
 // launch is asynchronous on the caller's stream, and failures are returned, not printf'ed
 // (reference: kernel_fp16.cu:854-863).
 #include "fa2_fwd_kernel.hip.h"
+#include "fa2_bwd_kernel.hip.h"
 
 #include <cmath>
 #include <cstdio>
@@ -36,6 +39,50 @@ int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     else
         hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, false, kNW, kQB>), grid, block, lds, stream, p);
     return (int)hipGetLastError();
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int HD, bool BF16, bool CAUSAL>
+int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
+    constexpr int TILEB = fa2::Geo<HD, 8>::TILEB;
+    const int64_t rows = (int64_t)p.B * p.H * p.Nq;
+    hipLaunchKernelGGL((fa2::bwd_delta_kernel<BF16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p, HD);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    {   // dQ: one workgroup per 256 Q rows
+        constexpr int lds = 2 * 3 * TILEB;
+        auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL>;
+        if ((rc = set_lds(kern, lds))) return rc;
+        p.nblk = (p.Nq + fa2::kQBlock - 1) / fa2::kQBlock;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    p.nblk = (p.Nkv + fa2::kQBlock - 1) / fa2::kQBlock;   // dV, dK: one workgroup per 256 KV rows
+    {
+        constexpr int lds = 2 * (2 * TILEB + 512);
+        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false>;
+        if ((rc = set_lds(kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    {
+        constexpr int lds = 2 * (3 * TILEB + 512);
+        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true>;
+        if ((rc = set_lds(kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    return 0;
+}
+
+template <int HD, bool BF16>
+int launch_bwd(const fa2::BwdParams& p, bool causal, hipStream_t stream) {
+    return causal ? launch_bwd_t<HD, BF16, true>(p, stream) : launch_bwd_t<HD, BF16, false>(p, stream);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -122,6 +169,65 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
         default: return FA2_ERR_HEAD_DIM;
     }
 }
+
+int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+            void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
+            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+            const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+            const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
+            int causal, void* hip_stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !delta_ws || !q_strides || !k_strides ||
+        !v_strides || !o_strides || !do_strides || !dq_strides || !dk_strides || !dv_strides || !lse_strides)
+        return FA2_ERR_NULL_POINTER;
+    if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
+    if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
+    if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
+    if (!std::isfinite(scale)) return FA2_ERR_SCALE;
+    const void* ptrs[] = {q, k, v, o, dout, dq, dk, dv};
+    const int64_t* strides[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
+    for (int i = 0; i < 8; ++i)
+        if (!aligned16(ptrs[i]) || !strides_ok(strides[i])) return FA2_ERR_ALIGNMENT;
+    const int64_t q_bytes = ((int64_t)(Nq - 1) * q_strides[2] + D) * 2, do_bytes = ((int64_t)(Nq - 1) * do_strides[2] + D) * 2;
+    const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2, v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
+    if (q_bytes > 0xffffffffLL || do_bytes > 0xffffffffLL || k_bytes > 0xffffffffLL || v_bytes > 0xffffffffLL)
+        return FA2_ERR_BAD_SHAPE;
+    const int64_t blocks = (int64_t)B * H * (((Nq > Nkv ? Nq : Nkv) + fa2::kQBlock - 1) / fa2::kQBlock);
+    if (blocks > 0x7fffffffLL || (int64_t)B * H * Nq / 16 > 0x7fffffffLL) return FA2_ERR_GRID;
+
+    fa2::BwdParams p;
+    p.q = q; p.k = k; p.v = v; p.o = o; p.dout = dout; p.lse = lse; p.delta = delta_ws; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv;
+    for (int i = 0; i < 3; ++i) {
+        p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; p.os[i] = o_strides[i];
+        p.dos[i] = do_strides[i]; p.dqs[i] = dq_strides[i]; p.dks[i] = dk_strides[i]; p.dvs[i] = dv_strides[i];
+    }
+    p.ls[0] = lse_strides[0]; p.ls[1] = lse_strides[1];
+    p.scale = scale;
+    p.c = scale * 1.4426950408889634f;
+    p.nblk = 0;
+    p.q_bytes = (uint32_t)q_bytes; p.k_bytes = (uint32_t)k_bytes; p.v_bytes = (uint32_t)v_bytes;
+    p.do_bytes = (uint32_t)do_bytes; p.l_bytes = (uint32_t)Nq * 4u;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool bf16 = dtype == FA2_DTYPE_BF16;
+    switch (D) {
+        case 64: return bf16 ? launch_bwd<64, true>(p, causal != 0, stream) : launch_bwd<64, false>(p, causal != 0, stream);
+        case 128: return bf16 ? launch_bwd<128, true>(p, causal != 0, stream) : launch_bwd<128, false>(p, causal != 0, stream);
+        default: return FA2_ERR_HEAD_DIM;
+    }
+}
+
+#define FA2_BWD_ARGS                                                                                                    \
+    const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse, void *dq, void *dk, \
+        void *dv, float *delta_ws, int B, int H, int Nq, int Nkv, int D, const int64_t q_strides[3],                    \
+        const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],                             \
+        const int64_t do_strides[3], const int64_t dq_strides[3], const int64_t dk_strides[3],                          \
+        const int64_t dv_strides[3], const int64_t lse_strides[2], float scale, int causal, void *hip_stream
+#define FA2_BWD_PASS                                                                                                  \
+    q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,        \
+        do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, hip_stream
+
+int fa2_bwd_f16(FA2_BWD_ARGS) { return fa2_bwd(FA2_DTYPE_F16, FA2_BWD_PASS); }
+int fa2_bwd_bf16(FA2_BWD_ARGS) { return fa2_bwd(FA2_DTYPE_BF16, FA2_BWD_PASS); }
 
 int fa2_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq,
                 int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],

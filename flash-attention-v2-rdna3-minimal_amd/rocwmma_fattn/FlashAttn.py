@@ -10,6 +10,9 @@ Layers (reference counterpart in brackets):
                                                              6-tensor return, calls the C-ABI
   libfa2_gfx950.so : fa2_fwd_*     [fwd_kernel, kernel_fp16.cu:306-544]  hand-written gfx950 kernel
 
+  FlashAttentionFunction.backward  [FlashAttn.py:78-92]      operator: dQ, dK, dV through flash_attn_wmma.backward
+  libfa2_gfx950.so : fa2_bwd_*     [bwd_kernel, kernel_fp16.cu:547-740]  gfx950 backward kernels
+
 The host is PyTorch-ROCm for memory and streams only; the compute is the C-ABI library
 (include/fa2_gfx950.h).  There is no CPU path: tensors must live on a ROCm device.
 """
@@ -100,10 +103,47 @@ class _FlashAttnWmma:
         return [O_fwd, q_pad, k_pad, v_pad, O, L]
 
     @staticmethod
-    def backward(*args, **kwargs):
-        raise NotImplementedError(
-            "fa2: the gfx950 build covers the forward path only; backward "
-            "(reference kernel_fp16.cu:547-740) is the next row of the scope table")
+    def backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH):
+        """Returns [dQ, dK, dV] sliced to the actual sizes, like backward_fp16/backward_bf16
+        (host.cpp:47-58, kernel_fp16.cu:878-1028).  Q, K, V, O, L are the tensors the forward returned
+        (D already padded to a kernel head dim, Q/O/L possibly padded in N); the gfx950 kernels take the
+        actual Nq / Nkv and mask in-kernel, so nothing is padded in N here."""
+        lib = _fa2_lib.load()
+        if not (Q.is_cuda and dO.is_cuda):
+            raise RuntimeError("fa2: tensors must be on a ROCm device (no CPU path in this operator)")
+        n_ax, h_ax = (1, 2) if permute_NH else (2, 1)
+        b, h, dk = Q.size(0), Q.size(h_ax), Q.size(3)
+        act_n, act_nkv, act_d = int(act_n), int(act_nkv), int(act_d)
+        dtype_code = _fa2_lib.FA2_DTYPE_F16 if Q.dtype == torch.float16 else _fa2_lib.FA2_DTYPE_BF16
+        if dO.dtype != Q.dtype:
+            dO = dO.to(Q.dtype)                       # host.cpp:47-58 dispatches on dO's dtype; Q's wins here
+        if dO.size(3) != dk:                          # kernel_fp16.cu:900-905: dO is padded in D like Q
+            dO = torch.nn.functional.pad(dO, (0, dk - dO.size(3)))
+        dO = _kernel_ready(dO)
+        dQ = torch.empty(Q.shape, dtype=Q.dtype, device=Q.device)   # every element [:act_n] is written by its owner
+        dK = torch.empty(K.shape, dtype=K.dtype, device=K.device)
+        dV = torch.empty(V.shape, dtype=V.dtype, device=V.device)
+        delta = torch.empty((b, h, L.size(2)), dtype=torch.float32, device=Q.device)
+        if L.stride() != delta.stride():
+            L = L.contiguous()
+
+        def s3(t):
+            return _fa2_lib.strides3(t.stride(0), t.stride(h_ax), t.stride(n_ax))
+
+        stream = torch.cuda.current_stream(Q.device).cuda_stream
+        args = (dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr(),
+                dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), delta.data_ptr(), b, h, act_n, act_nkv, dk,
+                s3(Q), s3(K), s3(V), s3(O), s3(dO), s3(dQ), s3(dK), s3(dV),
+                _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0, stream)
+        if Q.device.index != torch.cuda.current_device():
+            with torch.cuda.device(Q.device):
+                rc = lib.fa2_bwd(*args)
+        else:
+            rc = lib.fa2_bwd(*args)
+        _fa2_lib.check(rc)
+        if permute_NH:
+            return [dQ[:, :act_n, :, :act_d], dK[:, :act_nkv, :, :act_d], dV[:, :act_nkv, :, :act_d]]
+        return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
 
 
 def _strides_ok(t):

@@ -27,8 +27,13 @@ _FWD_ARGTYPES = [
     ctypes.c_float, ctypes.c_int, ctypes.c_void_p,                                         # scale causal stream
 ]
 
+_BWD_ARGTYPES = [ctypes.c_void_p] * 10 + [ctypes.c_int] * 5 + [_i64p] * 9 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+
 # every symbol include/fa2_gfx950.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "fa2_bwd_f16": (ctypes.c_int, _BWD_ARGTYPES),
+    "fa2_bwd_bf16": (ctypes.c_int, _BWD_ARGTYPES),
+    "fa2_bwd": (ctypes.c_int, [ctypes.c_int] + _BWD_ARGTYPES),
     "fa2_fwd_f16": (ctypes.c_int, _FWD_ARGTYPES),
     "fa2_fwd_bf16": (ctypes.c_int, _FWD_ARGTYPES),
     "fa2_fwd": (ctypes.c_int, [ctypes.c_int] + _FWD_ARGTYPES),
@@ -73,7 +78,7 @@ def error_string(code):
 
 def check(code):
     if code != 0:
-        raise RuntimeError("fa2_fwd failed (%d): %s" % (code, error_string(code)))
+        raise RuntimeError("fa2 call failed (%d): %s" % (code, error_string(code)))
 
 
 def strides3(a, b, c):

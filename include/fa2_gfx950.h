@@ -1,5 +1,5 @@
 /*
- * fa2_gfx950.h — C-ABI of the MI355X (gfx950 / CDNA4) FlashAttention-2 forward path.
+ * fa2_gfx950.h — C-ABI of the MI355X (gfx950 / CDNA4) FlashAttention-2 path (forward + backward).
  *
  * This is the drop-in boundary for the ONE hot path of
  * Repeerc/flash-attention-v2-RDNA3-minimal: the forward attention operator behind
@@ -85,6 +85,43 @@ int fa2_fwd(int dtype,
             const int64_t q_strides[3], const int64_t k_strides[3],
             const int64_t v_strides[3], const int64_t o_strides[3],
             const int64_t lse_strides[2],
+            float scale, int causal, void* hip_stream);
+
+/*
+ * Backward attention: dQ, dK, dV from dO.  Replaces backward_fp16 / backward_bf16 (rocwmma_fattn/host.cpp:24-28,
+ * :47-58; rocwmma_fattn/kernel_fp16.cu:878-1028 launcher + :547-740 bwd_kernel; bf16 twin kernel_bf16.cu).
+ *   o, lse   : the forward's outputs (lse in log2 units, as fa2_fwd writes it)
+ *   dout     : [B,H,Nq,D] upstream gradient, same dtype as q
+ *   dq/dk/dv : outputs, caller-owned, every element written (no zero-init needed)
+ *   delta_ws : caller-owned f32 workspace addressed like lse (lse_strides), >= Nq floats per (b,h):
+ *              receives D_i = rowsum(dO_i * O_i) (the reference's `Di`, kernel_fp16.cu:605-631)
+ * Four launches on `hip_stream` (D, dQ, dV, dK); deterministic: every output element has one owner — the
+ * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
+ * Gradients are those of O = softmax(scale * Q K^T [+ causal mask]) V, i.e. what torch autograd returns.
+ */
+int fa2_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                void* dq, void* dk, void* dv, float* delta_ws,
+                int B, int H, int Nq, int Nkv, int D,
+                const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
+                float scale, int causal, void* hip_stream);
+
+int fa2_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 void* dq, void* dk, void* dv, float* delta_ws,
+                 int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                 const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                 const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
+                 float scale, int causal, void* hip_stream);
+
+/* dtype-switched entry.  Replaces backward() (rocwmma_fattn/host.cpp:47-58). */
+int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+            void* dq, void* dk, void* dv, float* delta_ws,
+            int B, int H, int Nq, int Nkv, int D,
+            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+            const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+            const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
             float scale, int causal, void* hip_stream);
 
 /* Head dims the kernels are instantiated for (ascending).  Writes up to `cap` entries into

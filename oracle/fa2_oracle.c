@@ -239,6 +239,109 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
     return failed ? -1 : 0;
 }
 
+/*
+ * Backward attention on the CPU — restates the reference's backward recurrence
+ * (rocwmma_fattn/kernel_fp16.cu:547-740 bwd_kernel, pure_torch_ver.py:92-153):
+ *   D_i  = rowsum(dO_i * O_i)                                    (kernel_fp16.cu:605-631, pure_torch_ver.py:146)
+ *   P    = 2^(S*c - L_i)   with L the forward's log2-domain LSE   (kernel_fp16.cu:684-708), masked entries 0
+ *   dV  += P^T dO                                                 (:724, pure_torch_ver.py:144)
+ *   dP   = dO V^T                                                 (:725)
+ *   dS   = scale * P * (dP - D_i)                                 (:727-735)
+ *   dQ  += dS K,  dK += dS^T Q                                    (:736-737)
+ * f32 accumulation; P and dS are rounded to the I/O dtype before they enter a matrix product (both the
+ * reference kernels and the gfx950 kernels feed 16-bit operands to the matrix unit); one final rounding of
+ * dQ, dK, dV.  Layouts as fa2_oracle_fwd; lse = the forward's output (log2 domain), length >= Nq per head.
+ */
+int fa2_oracle_bwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* o,
+                   const uint16_t* dout, const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv,
+                   int B, int H, int Nq, int Nkv, int D,
+                   const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* dos,
+                   const int64_t* ls, const int64_t* dqs, const int64_t* dks, const int64_t* dvs,
+                   float scale, int causal, int flags, int nthreads) {
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return -1;
+    if (dtype != FA2_ORACLE_DTYPE_F16 && dtype != FA2_ORACLE_DTYPE_BF16) return -1;
+    const cvt_t cv = {dtype, (flags & FA2_ORACLE_BF16_TRUNC) != 0};
+    const float c = scale * 1.4426950408889634f;
+    int failed = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bh = 0; bh < B * H; ++bh) {
+        const int b = bh / H, h = bh % H;
+        float* qf = (float*)malloc((size_t)Nq * D * sizeof(float));
+        float* dof = (float*)malloc((size_t)Nq * D * sizeof(float));
+        float* kf = (float*)malloc((size_t)Nkv * D * sizeof(float));
+        float* vf = (float*)malloc((size_t)Nkv * D * sizeof(float));
+        float* dqa = (float*)calloc((size_t)Nq * D, sizeof(float));
+        float* dka = (float*)calloc((size_t)Nkv * D, sizeof(float));
+        float* dva = (float*)calloc((size_t)Nkv * D, sizeof(float));
+        float* delta = (float*)malloc((size_t)Nq * sizeof(float));
+        if (!qf || !dof || !kf || !vf || !dqa || !dka || !dva || !delta) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+            const uint16_t* qb = q + b * qs[0] + h * qs[1];
+            const uint16_t* ob = o + b * os[0] + h * os[1];
+            const uint16_t* gb = dout + b * dos[0] + h * dos[1];
+            const uint16_t* kb = k + b * ks[0] + h * ks[1];
+            const uint16_t* vb = v + b * vs[0] + h * vs[1];
+            const float* lb = lse + b * ls[0] + h * ls[1];
+            for (int i = 0; i < Nq; ++i) {
+                float dsum = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    qf[(size_t)i * D + d] = load16(cv, qb[(int64_t)i * qs[2] + d]);
+                    dof[(size_t)i * D + d] = load16(cv, gb[(int64_t)i * dos[2] + d]);
+                    dsum += dof[(size_t)i * D + d] * load16(cv, ob[(int64_t)i * os[2] + d]);
+                }
+                delta[i] = dsum;
+            }
+            for (int j = 0; j < Nkv; ++j)
+                for (int d = 0; d < D; ++d) {
+                    kf[(size_t)j * D + d] = load16(cv, kb[(int64_t)j * ks[2] + d]);
+                    vf[(size_t)j * D + d] = load16(cv, vb[(int64_t)j * vs[2] + d]);
+                }
+            for (int i = 0; i < Nq; ++i) {
+                const float* qi = qf + (size_t)i * D;
+                const float* gi = dof + (size_t)i * D;
+                float* dqi = dqa + (size_t)i * D;
+                const int jmax = causal ? (i < Nkv - 1 ? i : Nkv - 1) : Nkv - 1;   /* column > row masked */
+                for (int j = 0; j <= jmax; ++j) {
+                    const float* kj = kf + (size_t)j * D;
+                    const float* vj = vf + (size_t)j * D;
+                    float s = 0.f, dp = 0.f;
+#pragma omp simd reduction(+ : s, dp)
+                    for (int d = 0; d < D; ++d) { s += qi[d] * kj[d]; dp += gi[d] * vj[d]; }
+                    const float p = exp2f(s * c - lb[i]);
+                    const float p16 = round16(cv, p);
+                    const float ds16 = round16(cv, scale * p * (dp - delta[i]));
+                    float* dvj = dva + (size_t)j * D;
+                    float* dkj = dka + (size_t)j * D;
+                    for (int d = 0; d < D; ++d) {
+                        dvj[d] += p16 * gi[d];
+                        dqi[d] += ds16 * kj[d];
+                        dkj[d] += ds16 * qi[d];
+                    }
+                }
+            }
+            uint16_t* dqb = dq + b * dqs[0] + h * dqs[1];
+            uint16_t* dkb = dk + b * dks[0] + h * dks[1];
+            uint16_t* dvb = dv + b * dvs[0] + h * dvs[1];
+            for (int i = 0; i < Nq; ++i)
+                for (int d = 0; d < D; ++d) dqb[(int64_t)i * dqs[2] + d] = store16(cv, dqa[(size_t)i * D + d]);
+            for (int j = 0; j < Nkv; ++j)
+                for (int d = 0; d < D; ++d) {
+                    dkb[(int64_t)j * dks[2] + d] = store16(cv, dka[(size_t)j * D + d]);
+                    dvb[(int64_t)j * dvs[2] + d] = store16(cv, dva[(size_t)j * D + d]);
+                }
+        }
+        free(qf); free(dof); free(kf); free(vf); free(dqa); free(dka); free(dva); free(delta);
+    }
+    return failed ? -1 : 0;
+}
+
 int fa2_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -55,6 +55,9 @@ def _load():
         lib.fa2_oracle_fwd.restype = ctypes.c_int
         lib.fa2_oracle_fwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [i64p] * 5 + \
             [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.fa2_oracle_bwd.restype = ctypes.c_int
+        lib.fa2_oracle_bwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [i64p] * 9 + \
+            [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         lib.fa2_oracle_max_threads.restype = ctypes.c_int
         lib.fa2_oracle_f32_to_f16.restype = ctypes.c_uint16
         lib.fa2_oracle_f32_to_f16.argtypes = [ctypes.c_float]
@@ -121,6 +124,54 @@ def fwd_c(q_bits, k_bits, v_bits, dtype, causal=False, scale=None, Br=32, Bc=64,
     if rc != 0:
         raise RuntimeError("fa2_oracle_fwd failed (%d)" % rc)
     return o, lse
+
+
+def bwd_c(q_bits, k_bits, v_bits, o_bits, do_bits, lse, dtype, causal=False, scale=None, flags=0, nthreads=0):
+    """Backward oracle (fa2_oracle.c: fa2_oracle_bwd).  All *_bits are uint16 [B,H,N,D]; lse float32 [B,H,>=Nq]
+    in the log2 domain (the forward's output).  Returns (dq_bits, dk_bits, dv_bits)."""
+    lib = _load()
+    q, k, v, o, do = (np.ascontiguousarray(t, dtype=np.uint16) for t in (q_bits, k_bits, v_bits, o_bits, do_bits))
+    lse = np.ascontiguousarray(lse, dtype=np.float32)
+    B, H, Nq, D = q.shape
+    Nkv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    dq, dk, dv = np.empty_like(q), np.empty_like(k), np.empty_like(v)
+
+    def s3(n):
+        return (ctypes.c_int64 * 3)(H * n * D, n * D, D)
+
+    ls = (ctypes.c_int64 * 2)(H * lse.shape[2], lse.shape[2])
+    rc = lib.fa2_oracle_bwd(dtype, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, do.ctypes.data,
+                            lse.ctypes.data, dq.ctypes.data, dk.ctypes.data, dv.ctypes.data, B, H, Nq, Nkv, D,
+                            s3(Nq), s3(Nkv), s3(Nkv), s3(Nq), s3(Nq), ls, s3(Nq), s3(Nkv), s3(Nkv),
+                            float(scale), int(bool(causal)), int(flags), int(nthreads))
+    if rc != 0:
+        raise RuntimeError("fa2_oracle_bwd failed (%d)" % rc)
+    return dq, dk, dv
+
+
+def bwd_numpy(q, k, v, do, causal=False, scale=None):
+    """Dense float64 gradients of O = softmax(Q K^T scale [+mask]) V contracted with dO (pure_torch_ver.py:92-153
+    without the tiling): returns (dq, dk, dv)."""
+    q, k, v, do = (np.asarray(t, dtype=np.float64) for t in (q, k, v, do))
+    D = q.shape[-1]
+    if scale is None:
+        scale = D ** -0.5
+    s = np.einsum("bhid,bhjd->bhij", q, k) * scale
+    if causal:
+        nq, nk = s.shape[-2:]
+        s = np.where(np.triu(np.ones((nq, nk), dtype=bool), 1), -np.inf, s)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    o = np.einsum("bhij,bhjd->bhid", p, v)
+    dv = np.einsum("bhij,bhid->bhjd", p, do)
+    dp = np.einsum("bhid,bhjd->bhij", do, v)
+    delta = (do * o).sum(-1, keepdims=True)
+    ds = p * (dp - delta) * scale
+    dq = np.einsum("bhij,bhjd->bhid", ds, k)
+    dk = np.einsum("bhij,bhid->bhjd", ds, q)
+    return dq, dk, dv
 
 
 # ---------------------------------------------------------------- numpy restatements

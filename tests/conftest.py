@@ -13,6 +13,9 @@ measured errors of the reference's own oracle recorded in tests/golden/):
         |O - O_oracle| <= atol + rtol*|O_oracle|,  fp16: 1e-3 / 2e-3,  bf16: 8e-3 / 1.6e-2
     (one ulp of the I/O dtype: the two differ only in f32 summation order and exp2 rounding);
   * LSE (log2 domain, f32): <= 1e-3 absolute against oracle and truth.
+  * gradients (backward): max|g - g_true| <= max(2 * max|g_ref - g_true|, GRAD_TOL * max(1, max|g_true|)) against
+    float64 autograd, and |g - g_oracle| <= GRAD_TOL * max(1, max|g_oracle|) against the same-contract C oracle,
+    GRAD_TOL = 2e-3 (fp16) / 1.6e-2 (bf16): two ulps of the I/O dtype at the largest gradient magnitude.
 """
 import os
 import sys
@@ -33,6 +36,7 @@ FLOOR = {0: 1e-3, 1: 8e-3}          # vs truth, by dtype code (0 = fp16, 1 = bf1
 ATOL = {0: 1e-3, 1: 8e-3}           # vs same-contract oracle
 RTOL = {0: 2e-3, 1: 1.6e-2}
 LSE_TOL = 1e-3
+GRAD_TOL = {0: 2e-3, 1: 1.6e-2}
 
 
 def pytest_configure(config):
@@ -46,11 +50,29 @@ def load_golden(name):
             "q": z["q"], "k": z["k"], "v": z["v"], "variants": {}}
     for tag, causal in (("nc", False), ("c", True)):
         if "o_ref_" + tag in z.files:
-            case["variants"][causal] = {"o_ref": z["o_ref_" + tag], "l_ref": z["l_ref_" + tag],
-                                        "o_true": z["o_true_" + tag], "lse2_true": z["lse2_true_" + tag]}
+            var = {"o_ref": z["o_ref_" + tag], "l_ref": z["l_ref_" + tag],
+                   "o_true": z["o_true_" + tag], "lse2_true": z["lse2_true_" + tag]}
+            if "do_" + tag in z.files:      # backward fixtures (aligned self-attention cases)
+                for key in ("do", "dq_ref", "dk_ref", "dv_ref"):
+                    var[key] = z[key + "_" + tag]
+            case["variants"][causal] = var
     return case
 
 
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
     return load_golden(request.param)
+
+
+def grads_truth(q, k, v, do, causal, scale=None):
+    """float64 autograd of the dense formula (torch, CPU): independent of every restatement in this repo."""
+    import torch
+    qd, kd, vd = (torch.from_numpy(np.asarray(t, dtype=np.float64)).requires_grad_(True) for t in (q, k, v))
+    sc = qd.shape[-1] ** -0.5 if scale is None else scale
+    s = torch.matmul(qd, kd.transpose(-1, -2)) * sc
+    if causal:
+        nq, nk = s.shape[-2:]
+        s = s.masked_fill(torch.ones(nq, nk, dtype=torch.bool).triu(1), float("-inf"))
+    o = torch.matmul(torch.softmax(s, dim=-1), vd)
+    o.backward(torch.from_numpy(np.asarray(do, dtype=np.float64)))
+    return qd.grad.numpy(), kd.grad.numpy(), vd.grad.numpy()

@@ -13,7 +13,10 @@ For every case it records
   * `l_ref`  : its saved L (natural-log LSE, float32, padded length; pure_torch_ver.py:84-87);
   * `o_true` / `lse2_true`: dense float64 attention (torch) rounded to float32 — the ground truth the
                tolerance is stated against; lse2 is the log2-domain LSE the kernels store
-               (kernel_fp16.cu:541-542).
+               (kernel_fp16.cu:541-542);
+  * backward (aligned self-attention cases only — the reference oracle's -100 padding is only valid there):
+    `do` seeded upstream gradient (16-bit), `dq_ref/dk_ref/dv_ref` = pure_torch_ver backward
+    (pure_torch_ver.py:92-153), the float64 truth is recomputed by the tests with torch autograd (not stored).
 Nothing of the reference's source text is stored: fixtures are inputs and outputs only.
 """
 import importlib.util
@@ -53,20 +56,28 @@ class _Ctx:
     def save_for_backward(self, *t):
         self.saved = t
 
+    @property
+    def saved_tensors(self):
+        return self.saved
+
 
 def bits(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
 
 
-def dense_truth(q, k, v, causal):
-    qd, kd, vd = q.double(), k.double(), v.double()
+def dense_truth(q, k, v, causal, do=None):
+    qd, kd, vd = (t.double().requires_grad_(do is not None) for t in (q, k, v))
     s = torch.matmul(qd, kd.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     if causal:
         nq, nk = s.shape[-2:]
         s = s.masked_fill(torch.ones(nq, nk, dtype=torch.bool).triu(1), float("-inf"))
     lse = torch.logsumexp(s, dim=-1)
     o = torch.matmul(torch.softmax(s, dim=-1), vd)
-    return o.float().numpy(), (lse * LOG2E).float().numpy()
+    grads = None
+    if do is not None:
+        o.backward(do.double())
+        grads = tuple(t.grad.float().numpy() for t in (qd, kd, vd))
+    return o.detach().float().numpy(), (lse.detach() * LOG2E).float().numpy(), grads
 
 
 def main():
@@ -87,8 +98,18 @@ def main():
             ctx = _Ctx()
             o_ref = fwd(ctx, q.clone(), k.clone(), v.clone(), None, causal)
             l_ref = ctx.saved[4]
-            o_true, lse2_true = dense_truth(q, k, v, causal)
             tag = "c" if causal else "nc"
+            with_bwd = (Nkv == N) and (N % 64 == 0)
+            do = None
+            if with_bwd:
+                do = torch.randn((B, H, N, D), generator=g, dtype=torch.float32).to(dtype)
+                dq_ref, dk_ref, dv_ref = ref.FlashAttentionFunction.backward(ctx, do.clone())[:3]
+                out["do_" + tag] = bits(do)
+                out["dq_ref_" + tag], out["dk_ref_" + tag], out["dv_ref_" + tag] = bits(dq_ref), bits(dk_ref), bits(dv_ref)
+            o_true, lse2_true, grads = dense_truth(q, k, v, causal, do)
+            if with_bwd:   # float64 truth is NOT stored: tests recompute it with torch autograd
+                print("%-12s causal=%d reference-oracle bwd max err dq/dk/dv: %s" % (name, causal, " ".join(
+                    "%.2e" % np.abs(r.float().numpy() - t).max() for r, t in zip((dq_ref, dk_ref, dv_ref), grads))))
             out["o_ref_" + tag] = bits(o_ref)
             out["l_ref_" + tag] = l_ref.float().numpy()
             out["o_true_" + tag] = o_true

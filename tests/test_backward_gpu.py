@@ -1,0 +1,146 @@
+"""GPU parity tests of the backward path (`-m gpu`): fa2_bwd_* through the C-ABI and through
+FlashAttentionFunction's autograd, against the golden fixtures (reference oracle backward), float64 autograd
+and the C oracle.  Nothing here reads /root/reference."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GRAD_TOL, grads_truth
+from oracle import fa2_oracle as fo
+from rocwmma_fattn import _fa2_lib
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attn_wmma
+
+pytestmark = pytest.mark.gpu
+TORCH_DT = {0: torch.float16, 1: torch.bfloat16}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run the CPU suite with -m 'not gpu'"
+    return torch.device("cuda", 0)
+
+
+def _to_dev(bits, dt):
+    return torch.from_numpy(bits.view(np.int16).copy()).view(TORCH_DT[dt]).to(_dev())
+
+
+def _bits(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def _cabi_fwd_bwd(q, k, v, do, causal, scale=None):
+    """forward then backward straight through the C-ABI with caller-owned buffers."""
+    lib = _fa2_lib.load(build_if_missing=False)
+    B, H, N, D = q.shape
+    Nkv = k.shape[2]
+    scale = float(D ** -0.5 if scale is None else scale)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    s3 = lambda t: _fa2_lib.strides3(t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    s2 = _fa2_lib.strides2(lse.stride(0), lse.stride(1))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = 0 if q.dtype == torch.float16 else 1
+    _fa2_lib.check(lib.fa2_fwd(code, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, Nkv, D,
+                               s3(q), s3(k), s3(v), s3(o), s2, scale, int(causal), stream))
+    fn = lib.fa2_bwd_f16 if q.dtype == torch.float16 else lib.fa2_bwd_bf16
+    _fa2_lib.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, N, Nkv, D,
+                      s3(q), s3(k), s3(v), s3(o), s3(do), s3(dq), s3(dk), s3(dv), s2, scale, int(causal), stream))
+    torch.cuda.synchronize()
+    return o, lse, (dq, dk, dv)
+
+
+def _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal, scale=None):
+    want = fo.bwd_c(_bits(q), _bits(k), _bits(v), _bits(o), _bits(do), lse.cpu().numpy(), dt, causal, scale=scale)
+    for name, g, w_bits in zip("qkv", grads, want):
+        w = fo.bits_to_f32(w_bits, dt)
+        got = g.float().cpu().numpy()
+        assert np.isfinite(got).all(), "d%s has non-finite values" % name
+        assert np.abs(got - w).max() <= GRAD_TOL[dt] * max(1.0, np.abs(w).max()), (name, np.abs(got - w).max())
+
+
+def test_golden_backward_fixtures(golden):
+    dt = golden["dtype"]
+    q, k, v = (_to_dev(golden[t], dt) for t in "qkv")
+    qf, kf, vf = (fo.bits_to_f32(golden[t], dt) for t in "qkv")
+    for causal, var in golden["variants"].items():
+        if "do" not in var:
+            continue
+        do = _to_dev(var["do"], dt)
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+        truth = grads_truth(qf, kf, vf, fo.bits_to_f32(var["do"], dt), causal)
+        for name, g, g_true, ref_bits in zip("qkv", grads, truth, (var["dq_ref"], var["dk_ref"], var["dv_ref"])):
+            got = g.float().cpu().numpy()
+            ref_err = np.abs(fo.bits_to_f32(ref_bits, dt) - g_true).max()
+            err = np.abs(got - g_true).max()
+            assert err <= max(2 * ref_err, GRAD_TOL[dt] * max(1.0, np.abs(g_true).max())), (golden["name"], causal, name, err, ref_err)
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+
+
+SHAPES = [(1, 1, 1, 1, 64), (1, 2, 1, 300, 128), (2, 3, 65, 1, 64), (1, 2, 31, 33, 64), (1, 3, 255, 257, 128),
+          (2, 2, 256, 256, 128), (1, 2, 257, 511, 64), (1, 1, 700, 700, 128), (3, 5, 130, 77, 64), (1, 4, 512, 512, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_seeded_shapes_against_oracle(shape, dt, causal):
+    B, H, Nq, Nkv, D = shape
+    g = torch.Generator(device="cpu").manual_seed(hash(shape) % 1000 + 31 * dt)
+    mk = lambda n: torch.randn((B, H, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(Nq), mk(Nkv), mk(Nkv), mk(Nq)
+    o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+    _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+
+
+def test_autograd_through_the_operator_matches_torch():
+    """FlashAttentionFunction.apply(...).backward(dO) — the reference's training call shape (bench_with_sdpa.py:89-96)."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for dtype, causal, D, Nkv in ((torch.float16, False, 64, 300), (torch.bfloat16, True, 128, 200), (torch.float16, True, 40, 200)):
+        q = torch.randn((2, 3, 200, D), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+        k = torch.randn((2, 3, Nkv, D), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+        v = torch.randn((2, 3, Nkv, D), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+        do = torch.randn((2, 3, 200, D), generator=g).to(dtype).to(_dev())
+        o = FlashAttentionFunction.apply(q, k, v, None, causal)
+        o.backward(do)
+        torch.cuda.synchronize()
+        assert q.grad.shape == q.shape and k.grad.shape == k.shape and v.grad.shape == v.shape
+        truth = grads_truth(*(t.detach().float().cpu().numpy() for t in (q, k, v, do)), causal)
+        dt = 0 if dtype == torch.float16 else 1
+        for got, want in zip((q.grad, k.grad, v.grad), truth):
+            assert np.abs(got.float().cpu().numpy() - want).max() <= GRAD_TOL[dt] * max(1.0, np.abs(want).max())
+
+
+def test_backward_is_deterministic_and_bnhd_matches_bhnd():
+    g = torch.Generator(device="cpu").manual_seed(23)
+    q, k, v, do = (torch.randn((2, 4, 300, 64), generator=g).half().to(_dev()) for _ in range(4))
+    _, _, g1 = _cabi_fwd_bwd(q, k, v, do, True)
+    _, _, g2 = _cabi_fwd_bwd(q, k, v, do, True)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)        # one owner per output element: no atomics, no run-to-run noise
+    # BNHD: same numbers through the permuted layout (reference: kernel_fp16.cu:328-333)
+    qn, kn, vn = (t.transpose(1, 2).contiguous() for t in (q, k, v))
+    ret = flash_attn_wmma.forward(qn, kn, vn, 64, 128, True, 64 ** -0.5, True)
+    dq, dk, dv = flash_attn_wmma.backward(ret[1], ret[2], ret[3], ret[4], do.transpose(1, 2).contiguous(), ret[5],
+                                          300, 300, 64, 128, 128, True, 64 ** -0.5, True)
+    torch.cuda.synchronize()
+    for a, b in zip((dq, dk, dv), g1):
+        assert torch.equal(a.transpose(1, 2), b)
+
+
+def test_full_size_config2_backward_sampled_heads():
+    """BASELINE config 2 shape: two heads checked against the oracle, the whole tensor for finiteness and for
+    head-slice independence (a head recomputed alone is bit-identical)."""
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    q, k, v, do = (torch.randn((2, 16, 4096, 128), generator=g, device=_dev(), dtype=torch.float32).half() for _ in range(4))
+    o, lse, grads = _cabi_fwd_bwd(q, k, v, do, False)
+    for t in grads:
+        assert torch.isfinite(t.float()).all()
+    sl = (slice(1, 2), slice(5, 6))
+    _check_vs_oracle(q[sl], k[sl], v[sl], do[sl], o[sl], lse[sl], [t[sl] for t in grads], 0, False)
+    _, _, part = _cabi_fwd_bwd(q[:, 3:5].contiguous(), k[:, 3:5].contiguous(), v[:, 3:5].contiguous(), do[:, 3:5].contiguous(), False)
+    for a, b in zip(part, grads):
+        assert torch.equal(a, b[:, 3:5])

@@ -32,6 +32,7 @@ def test_library_is_in_tree_and_exports_every_declared_symbol():
     assert os.path.dirname(_fa2_lib.LIB_PATH) == PKG
     declared = _declared_symbols()
     assert "fa2_fwd_f16" in declared and "fa2_fwd_bf16" in declared and "fa2_fwd" in declared
+    assert "fa2_bwd_f16" in declared and "fa2_bwd_bf16" in declared and "fa2_bwd" in declared
     assert set(declared) == set(_fa2_lib.SYMBOLS), "ctypes binding and header disagree"
     for name in declared:
         assert getattr(lib, name) is not None
@@ -75,10 +76,22 @@ def test_validation_codes_without_a_gpu():
     assert call(scale=float("nan")) == c["FA2_ERR_SCALE"]
     for code in c.values():
         assert _fa2_lib.error_string(code)
-    with pytest.raises(RuntimeError, match="fa2_fwd failed"):
+    with pytest.raises(RuntimeError, match="fa2 call failed"):
         _fa2_lib.check(c["FA2_ERR_HEAD_DIM"])
     assert lib.fa2_fwd_f16(None, p, p, p, p, 1, 1, 1, 1, 64, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_NULL_POINTER"]
     assert lib.fa2_fwd_bf16(p, p, p, p, p, 1, 1, 1, 1, 48, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_HEAD_DIM"]
+    # backward: same validation, ten pointers and eight stride triples
+    bwd = lambda **kw: lib.fa2_bwd(kw.get("dtype", 0), kw.get("q", p), p, p, p, p, p, p, p, p, kw.get("ws", p), 1, 2, 16,  # noqa: E731
+                                   kw.get("Nkv", 16), kw.get("D", 64), s3, s3, s3, s3, kw.get("dos", s3), s3, s3, s3, s2,
+                                   kw.get("scale", 0.125), 0, None)
+    assert bwd(q=None) == c["FA2_ERR_NULL_POINTER"] and bwd(ws=None) == c["FA2_ERR_NULL_POINTER"]
+    assert bwd(dtype=3) == c["FA2_ERR_DTYPE"] and bwd(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
+    assert bwd(D=96) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
+    assert bwd(dos=_fa2_lib.strides3(2048, 1024, 66)) == c["FA2_ERR_ALIGNMENT"]
+    assert lib.fa2_bwd_f16(p, p, p, p, p, p, p, p, p, None, 1, 1, 1, 1, 64, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
+        == c["FA2_ERR_NULL_POINTER"]
+    assert lib.fa2_bwd_bf16(p, p, p, p, p, p, p, p, p, p, 1, 1, 1, 1, 7, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
+        == c["FA2_ERR_HEAD_DIM"]
 
 
 def test_operator_surface_matches_reference():
@@ -101,8 +114,8 @@ def test_operator_refuses_cpu_tensors_loudly():
         FlashAttentionFunction.apply(q, q, q, None, False)
     with pytest.raises(RuntimeError, match="4-D"):
         flash_attn_wmma.forward(q[0], q[0], q[0], 64, 128, False, 1.0, False)
-    with pytest.raises(NotImplementedError):
-        flash_attn_wmma.backward()
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        flash_attn_wmma.backward(q, q, q, q, q, torch.zeros(1, 2, 16), 16, 16, 64, 128, 128, False, 0.125, False)
 
 
 def test_product_package_never_touches_the_oracle():

@@ -3,7 +3,7 @@ pure_torch_ver.py (tests/golden/make_golden.py) and against dense float64 attent
 import numpy as np
 import pytest
 
-from conftest import ATOL, FLOOR, LSE_TOL, RTOL, load_golden
+from conftest import ATOL, FLOOR, GRAD_TOL, LSE_TOL, RTOL, grads_truth, load_golden
 from oracle import fa2_oracle as fo
 
 
@@ -174,3 +174,43 @@ def test_negative_scale_and_explicit_scale():
         o_true, lse_true = fo.fwd_numpy(_f32(q, 0), _f32(k, 0), _f32(v, 0), False, scale=scale)
         assert np.all(np.abs(_f32(o, 0) - o_true) <= ATOL[0] + RTOL[0] * np.abs(o_true))
         assert np.abs(lse - lse_true).max() <= LSE_TOL
+
+
+# ---------------------------------------------------------------- backward oracle
+
+def test_backward_oracle_against_golden(golden):
+    """fa2_oracle_bwd vs the reference oracle's backward (pure_torch_ver.py:92-153, fixtures) and float64 autograd."""
+    dt = golden["dtype"]
+    q, k, v = (_f32(golden[t], dt) for t in "qkv")
+    for causal, var in golden["variants"].items():
+        if "do" not in var:
+            continue
+        o_bits, lse = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal)
+        got = fo.bwd_c(golden["q"], golden["k"], golden["v"], o_bits, var["do"], lse, dt, causal)
+        truth = grads_truth(q, k, v, _f32(var["do"], dt), causal)
+        for name, g_bits, g_true, ref_bits in zip("qkv", got, truth, (var["dq_ref"], var["dk_ref"], var["dv_ref"])):
+            g, g_ref = _f32(g_bits, dt), _f32(ref_bits, dt)
+            err, ref_err = np.abs(g - g_true).max(), np.abs(g_ref - g_true).max()
+            mag = max(1.0, np.abs(g_true).max())
+            assert err <= max(2 * ref_err, GRAD_TOL[dt] * mag), (golden["name"], causal, name, err, ref_err)
+            assert np.abs(g - g_ref).max() <= err + ref_err + 1e-6
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape,nkv", [((1, 2, 70, 64), 70), ((2, 1, 33, 128), 150), ((1, 1, 1, 64), 5)])
+def test_backward_oracle_against_dense(dt, causal, shape, nkv):
+    if causal and nkv != shape[2]:
+        pytest.skip("causal is defined for self-attention shapes")
+    rng = np.random.default_rng(7)
+    B, H, N, D = shape
+    q = _rand_bits(rng, shape, dt, signed=True)
+    k, v = (_rand_bits(rng, (B, H, nkv, D), dt, signed=True) for _ in range(2))
+    do = _rand_bits(rng, shape, dt, signed=True)
+    o_bits, lse = fo.fwd_c(q, k, v, dt, causal)
+    got = fo.bwd_c(q, k, v, o_bits, do, lse, dt, causal)
+    want_np = fo.bwd_numpy(_f32(q, dt), _f32(k, dt), _f32(v, dt), _f32(do, dt), causal)
+    want_t = grads_truth(_f32(q, dt), _f32(k, dt), _f32(v, dt), _f32(do, dt), causal)
+    for g_bits, a, b in zip(got, want_np, want_t):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())       # numpy statement == torch autograd
+        assert np.abs(_f32(g_bits, dt) - b).max() <= GRAD_TOL[dt] * max(1.0, np.abs(b).max())

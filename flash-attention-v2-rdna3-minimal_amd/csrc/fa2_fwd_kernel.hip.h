@@ -151,14 +151,22 @@ struct Geo {
 // NW waves per workgroup, each owning QB consecutive 32-row Q blocks (NW * QB * 32 == 256):
 //   <8, 1>: two waves per SIMD, 256 VGPRs each;  <4, 2>: one wave per SIMD with the 512-register
 //   budget — every K / V^T fragment read from LDS then feeds two MFMAs instead of one.
-template <int HD, bool BF16, bool CAUSAL, int NW, int QB>
+//
+// HD = head dim of Q and K (the QK^T contraction); HDV = the V / O columns one workgroup produces.
+// HDV == HD except for D = 256, which is run as two column halves (blockIdx.y selects [0,128) or
+// [128,256)): a 256-wide f32 O accumulator plus the Q fragments would not fit 256 VGPRs, so QK^T is
+// recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
 __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
     static_assert(NW * QB * 32 == kQBlock, "workgroup must cover 256 Q rows");
-    using G_ = Geo<HD, NW>;
+    using G_ = Geo<HD, NW>;    // K tile image
+    using GV_ = Geo<HDV, NW>;  // V tile image
     constexpr int ROWB = G_::ROWB, TILEB = G_::TILEB, NPASS = G_::NPASS;
-    constexpr int KS_QK = G_::KS_QK, DT = G_::DT;
+    constexpr int VROWB = GV_::ROWB, VTILEB = GV_::TILEB, VNPASS = GV_::NPASS;
+    constexpr int KS_QK = G_::KS_QK, DT = GV_::DT;
+    constexpr int VBASE = 2 * TILEB;   // LDS: K buf0 | K buf1 | V buf0 | V buf1
+    const int vcol0 = blockIdx.y * HDV;   // first V / O column of this workgroup
     constexpr int kThreads = NW * 64, kRowsPerWave = 32 * QB;
-    // LDS: K buf0 | K buf1 | V buf0 | V buf1
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -209,16 +217,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
     const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
     const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
-    uint32_t kg_off[NPASS], vg_off[NPASS];  // per-lane byte offsets into the head matrix, tile 0
-    int kw_off[NPASS], vw_off[NPASS];       // per-lane LDS byte offsets inside a tile image
+    uint32_t kg_off[NPASS], vg_off[VNPASS];  // per-lane byte offsets into the head matrix, tile 0
+    int kw_off[NPASS], vw_off[VNPASS];       // per-lane LDS byte offsets inside a tile image
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / G_::G, gi = idx % G_::G;
         kg_off[i] = row * k_rowb + gi * 16;
-        vg_off[i] = row * v_rowb + gi * 16;
         kw_off[i] = G_::k_off(row, gi);
-        vw_off[i] = G_::v_off(row, gi * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < VNPASS; ++i) {
+        const int idx = tid + kThreads * i;
+        const int row = idx / GV_::G, gi = idx % GV_::G;
+        vg_off[i] = row * v_rowb + gi * 16 + vcol0 * 2;
+        vw_off[i] = GV_::v_off(row, gi * 16);
     }
 
     // ---- per-lane LDS read offsets
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const int pp = lane & 15, g1 = (lane >> 4) & 1;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            vr_off[dt] = G_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
+            vr_off[dt] = GV_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
     }
 
     // ---- KV sweep bounds
@@ -267,17 +280,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // v_off swizzle (the image itself stays lane-linear).  The destination buffer must be free when the
     // load is ISSUED.  Register form: global -> VGPRs at issue, ds_write_b128 at the end of the step.
     constexpr bool kDma = FA2_LDS_DMA && HD >= FA2_LDS_DMA_MIN_HD;
-    uint32_t kd_off[NPASS], vd_off[NPASS];
+    uint32_t kd_off[NPASS], vd_off[VNPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / G_::G, slot = idx % G_::G;
-        const int gk = slot ^ ((row / G_::RPB) & G_::KMASK);
-        const int gv = ((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3);
-        kd_off[i] = row * k_rowb + gk * 16;
-        vd_off[i] = row * v_rowb + gv * 16;
+        kd_off[i] = row * k_rowb + (slot ^ ((row / G_::RPB) & G_::KMASK)) * 16;
     }
-    u32x4 kreg[NPASS], vreg[NPASS];
+#pragma unroll
+    for (int i = 0; i < VNPASS; ++i) {
+        const int idx = tid + kThreads * i;
+        const int row = idx / GV_::G, slot = idx % GV_::G;
+        const int gv = ((((slot >> 2) ^ ((row / GV_::RPB) & GV_::VMASK))) << 2) | (slot & 3);
+        vd_off[i] = row * v_rowb + gv * 16 + vcol0 * 2;
+    }
+    u32x4 kreg[NPASS], vreg[VNPASS];
     auto load_k = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
@@ -289,8 +306,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     auto load_v = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            if constexpr (kDma) dma16_to_lds(vrs, smem + (2 + buf) * TILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
+        for (int i = 0; i < VNPASS; ++i) {
+            if constexpr (kDma) dma16_to_lds(vrs, smem + VBASE + buf * VTILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
             else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
         }
     };
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     auto write_v = [&](int buf) __attribute__((always_inline)) {
         if constexpr (!kDma) {
 #pragma unroll
-            for (int i = 0; i < NPASS; ++i) *(u32x4*)(smem + (2 + buf) * TILEB + vw_off[i]) = vreg[i];
+            for (int i = 0; i < VNPASS; ++i) *(u32x4*)(smem + VBASE + buf * VTILEB + vw_off[i]) = vreg[i];
         }
     };
 
@@ -423,17 +440,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 
     // O^T += V^T P^T; each V^T fragment read from LDS feeds QB MFMAs
     auto pv = [&](int buf, const u32x4 (&pf)[QB][4]) __attribute__((always_inline)) {
-        const char* vt = smem + (2 + buf) * TILEB;
+        const char* vt = smem + VBASE + buf * VTILEB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const char* va = vt + vr_off[dt] + 16 * ks * ROWB;
+                const char* va = vt + vr_off[dt] + 16 * ks * VROWB;
                 u32x4 a;
                 if (FA2_ABL & 32) a = qf[0][(ks * DT + dt) % KS_QK];
                 else {
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB));
                     const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
                     a = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
                 }
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const float l_tot = half_swap_sum(l_run[qb]);
         const float inv_l = 1.0f / l_tot;
         if (qrow[qb] < p.Nq) {
-            uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow[qb] * p.os[2];
+            uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow[qb] * p.os[2] + vcol0;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -578,7 +595,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                     *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
                 }
             }
-            if (hi == 0)
+            if (hi == 0 && vcol0 == 0)
                 p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = m_run[qb] * c + __builtin_amdgcn_logf(l_tot);
         }
     }

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int kHeadDims[] = {64, 128};
+constexpr int kHeadDims[] = {64, 128, 256};
 constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 
 // Workgroup shape: NW waves x QB 32-row Q blocks per wave (NW * QB * 32 = 256 Q rows).
@@ -29,22 +29,29 @@ constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 #endif
 constexpr int kNW = FA2_NW, kQB = 8 / FA2_NW;
 
-template <int HD, bool BF16>
-int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
-    constexpr int lds = 4 * fa2::Geo<HD, kNW>::TILEB;
-    const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk));
-    const dim3 block(kNW * 64);
-    if (causal)
-        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, true, kNW, kQB>), grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL((fa2::fwd_kernel<HD, BF16, false, kNW, kQB>), grid, block, lds, stream, p);
-    return (int)hipGetLastError();
-}
-
 template <typename K>
 int set_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return 0;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int HD, bool BF16>
+int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
+    constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
+    const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
+    const dim3 block(kNW * 64);
+    int rc;
+    if (causal) {
+        auto kern = fa2::fwd_kernel<HD, HDV, BF16, true, kNW, kQB>;
+        if ((rc = set_lds(kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    } else {
+        auto kern = fa2::fwd_kernel<HD, HDV, BF16, false, kNW, kQB>;
+        if ((rc = set_lds(kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    }
+    return (int)hipGetLastError();
 }
 
 template <int HD, bool BF16, bool CAUSAL>
@@ -166,6 +173,7 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     switch (D) {
         case 64: return bf16 ? launch<64, true>(p, causal != 0, stream) : launch<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch<128, true>(p, causal != 0, stream) : launch<128, false>(p, causal != 0, stream);
+        case 256: return bf16 ? launch<256, true>(p, causal != 0, stream) : launch<256, false>(p, causal != 0, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
 }
@@ -181,7 +189,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
         return FA2_ERR_NULL_POINTER;
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
-    if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
+    if (D != 64 && D != 128) return FA2_ERR_HEAD_DIM;   // backward kernels: D <= 128
     if (!std::isfinite(scale)) return FA2_ERR_SCALE;
     const void* ptrs[] = {q, k, v, o, dout, dq, dk, dv};
     const int64_t* strides[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};

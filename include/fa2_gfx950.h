@@ -98,6 +98,7 @@ int fa2_fwd(int dtype,
  * Four launches on `hip_stream` (D, dQ, dV, dK); deterministic: every output element has one owner — the
  * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
  * Gradients are those of O = softmax(scale * Q K^T [+ causal mask]) V, i.e. what torch autograd returns.
+ * Head dims: 64 and 128 (the forward additionally has a 256 kernel); other D return FA2_ERR_HEAD_DIM.
  */
 int fa2_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, float* delta_ws,

@@ -96,6 +96,7 @@ SHAPES = [
     # B, H, Nq, Nkv, D
     (1, 1, 1, 1, 64), (1, 2, 1, 300, 128), (2, 3, 65, 1, 64), (1, 2, 31, 33, 64), (1, 3, 255, 257, 128),
     (2, 2, 256, 256, 128), (1, 2, 257, 511, 64), (1, 1, 700, 700, 128), (3, 5, 130, 77, 64), (1, 8, 512, 512, 128),
+    (1, 2, 300, 300, 256), (2, 1, 65, 77, 256),     # D = 256: two 128-column halves per workgroup row
 ]
 
 
@@ -157,6 +158,18 @@ def test_return_contract_padding_and_views():
     o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), 0, False)
     assert np.all(np.abs(O_fwd.float().cpu().numpy() - fo.bits_to_f32(o_ref_bits, 0)) <= 2e-3)
     assert np.abs(L[:, :, :100].cpu().numpy() - lse_ref).max() <= LSE_TOL
+
+
+def test_head_dim_160_pads_to_the_256_kernel():
+    """SD1.5's deepest attention level has D = 160 (the reference pads D to a multiple of 32, kernel_fp16.cu:763)."""
+    g = torch.Generator(device="cpu").manual_seed(10)
+    q, k, v = (torch.randn((2, 8, 256, 160), generator=g).half().to(_dev()) for _ in range(3))
+    o = FlashAttentionFunction.apply(q, k, v, None, False)
+    torch.cuda.synchronize()
+    assert o.shape == q.shape
+    o_ref_bits, _ = fo.fwd_c(_bits(q), _bits(k), _bits(v), 0, False)
+    o_ref = fo.bits_to_f32(o_ref_bits, 0)
+    assert np.all(np.abs(o.float().cpu().numpy() - o_ref) <= ATOL[0] + RTOL[0] * np.abs(o_ref))
 
 
 def test_bnhd_layout_is_zero_copy_and_matches_bhnd():

@@ -61,7 +61,7 @@ def build(specs):
         lines = out.splitlines()
         info = []
         for i, l in enumerate(lines):
-            if "Function Name" in l and "ILi128ELb0ELb0EL" in l:
+            if "Function Name" in l and "ILi128ELi128ELb0ELb0EL" in l:
                 for m in lines[i + 1:i + 12]:
                     for key in ("VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "SGPRs:", "VGPRs Spill", "LDS Size"):
                         if key in m:

@@ -154,11 +154,15 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // block -> (head, q block): as in the forward kernel (causal: longest-first across heads)
     const int nbh = p.B * p.H, bid = blockIdx.x;
     int bh, qblk;
-    if ((nbh & 7) == 0) { const int slot = bid >> 3; bh = (bid & 7) + 8 * (slot / p.nblk); qblk = slot % p.nblk; }
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;
+        if (CAUSAL) { bh = (bid & 7) + 8 * (slot % hpx); qblk = p.nblk - 1 - slot / hpx; }
+        else { bh = (bid & 7) + 8 * (slot / p.nblk); qblk = slot % p.nblk; }
+    } else if (CAUSAL) { bh = bid % nbh; qblk = p.nblk - 1 - bid / nbh; }
     else { bh = bid / p.nblk; qblk = bid % p.nblk; }
-    if (CAUSAL) qblk = p.nblk - 1 - qblk;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * kQBlock, qw0 = q0 + 32 * wave, qrow = qw0 + l31;
     const int qr = qrow < p.Nq ? qrow : p.Nq - 1;
@@ -297,9 +301,14 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // block -> (head, kv block); causal: the FIRST kv block sweeps the most Q tiles -> ascending kv block, across heads
     const int nbh = p.B * p.H, bid = blockIdx.x;
     int bh, kblk;
-    if ((nbh & 7) == 0) { const int slot = bid >> 3; bh = (bid & 7) + 8 * (slot / p.nblk); kblk = slot % p.nblk; }
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;
+        if (CAUSAL) { bh = (bid & 7) + 8 * (slot % hpx); kblk = slot / hpx; }
+        else { bh = (bid & 7) + 8 * (slot / p.nblk); kblk = slot % p.nblk; }
+    } else if (CAUSAL) { bh = bid % nbh; kblk = bid / nbh; }
     else { bh = bid / p.nblk; kblk = bid % p.nblk; }
     const int b = bh / p.H, h = bh % p.H;
     const int kv0 = kblk * kQBlock, kvw0 = kv0 + 32 * wave, kvrow = kvw0 + l31;   // this lane's KV row

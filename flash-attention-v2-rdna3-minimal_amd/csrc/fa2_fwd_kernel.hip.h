@@ -175,20 +175,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
-    // ---- workgroup -> (batch*head, q block); blocks of one head share an XCD (bid % 8) so that
-    //      the head's K/V stay in that XCD's L2; causal runs the long (late) q blocks first.
+    // ---- workgroup -> (batch*head, q block).  blockIdx % 8 is the XCD a block lands on.
+    //   non-causal: all q blocks of a head run on one XCD, back to back, so the head's K/V stay in that
+    //               XCD's L2 (equal work per block: order is irrelevant for balance);
+    //   causal:     work grows with the q block index, and blocks are handed to CUs in launch order, so
+    //               the order is longest-first ACROSS heads (all heads' last q block, then the one before,
+    //               ...): with per-head ordering the long blocks of the later heads arrive last and the
+    //               makespan was 100 tile-steps instead of 68 at B2 H16 N4096.
     const int nbh = p.B * p.H;
     const int bid = blockIdx.x;
     int bh, qblk;
     if ((nbh & 7) == 0) {
-        const int slot = bid >> 3;
-        bh = (bid & 7) + 8 * (slot / p.nqblk);
-        qblk = slot % p.nqblk;
+        const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
+        if (CAUSAL) {
+            bh = (bid & 7) + 8 * (slot % hpx);
+            qblk = p.nqblk - 1 - slot / hpx;
+        } else {
+            bh = (bid & 7) + 8 * (slot / p.nqblk);
+            qblk = slot % p.nqblk;
+        }
+    } else if (CAUSAL) {
+        bh = bid % nbh;
+        qblk = p.nqblk - 1 - bid / nbh;
     } else {
         bh = bid / p.nqblk;
         qblk = bid % p.nqblk;
     }
-    if (CAUSAL) qblk = p.nqblk - 1 - qblk;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * kQBlock;
     const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave
@@ -469,12 +481,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     //   reads  K(tile+1) from K buf PAR^1, V(tile) from V buf PAR
     //   writes K(tile+2) to   K buf PAR,   V(tile+1) to V buf PAR^1
     // sc = finished scores of `tile` (QK^T one step earlier), sn receives the scores of tile+1.
-    // FAST = steady state: every load/compute condition is known true and tile+1 needs no mask, so
-    // the QK^T MFMAs of tile+1, the exp/pack VALU work of `tile` and the P.V MFMAs of `tile` form ONE
-    // basic block the scheduler can interleave; the only branch is the rare rescale at the end.
-    auto step = [&](int tile, auto par, auto fast, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
+    // MODE 1 = steady state: every load/compute condition is known true and tile+1 needs no mask, so the
+    // QK^T MFMAs of tile+1, the exp/pack VALU work of `tile` and the P.V MFMAs of `tile` form ONE basic
+    // block the scheduler can interleave; the only branch is the rare rescale at the end.  MODE 0 = generic
+    // (masked tiles, pipeline tail, waves above the causal diagonal that only stage and sync).  A masked
+    // steady-state variant for the diagonal tiles measured +0 % (and cost 23 VGPRs), so it is not kept.
+    auto step = [&](int tile, auto par, auto mode, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
-        constexpr bool FAST = decltype(fast)::value;
+        constexpr int MODE = decltype(mode)::value;
+        constexpr bool FAST = MODE != 0;
         const bool more1 = FAST || tile + 1 < ntiles, more2 = FAST || tile + 2 < ntiles;
         const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
         if (more2 && !(FA2_ABL & 16)) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (more2 && !(FA2_ABL & 16)) write_k(PAR);
         if (more1 && !(FA2_ABL & 16)) write_v(PAR ^ 1);
         if (!(FA2_ABL & 256)) __syncthreads();
-        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, !FAST>{}, sn);
+        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn);
     };
 
 #if FA2_PIPE == 1
@@ -506,24 +521,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
     {
-        const int unmasked_kv = p.Nkv / kKvTile;                       // tiles fully inside Nkv
+        const int unmasked_kv = p.Nkv / kKvTile;                           // tiles fully inside Nkv
         const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;  // tiles fully below the diagonal
         const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
-        n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;        // tile+1 <= unmasked-1
+        n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
         n_fast = n_fast < 0 ? 0 : n_fast & ~1;
     }
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::integral_constant<int, 0> GENERIC{};
+    constexpr std::integral_constant<int, 1> STEADY{};
     int tile = 0;
     for (; tile < n_fast; tile += 2) {
-        step(tile, P0, std::true_type{}, sa, sb);
-        step(tile + 1, P1, std::true_type{}, sb, sa);
+        step(tile, P0, STEADY, sa, sb);
+        step(tile + 1, P1, STEADY, sb, sa);
     }
     for (; tile + 1 < ntiles; tile += 2) {
-        step(tile, P0, std::false_type{}, sa, sb);
-        step(tile + 1, P1, std::false_type{}, sb, sa);
+        step(tile, P0, GENERIC, sa, sb);
+        step(tile + 1, P1, GENERIC, sb, sa);
     }
-    if (tile < ntiles) step(tile, P0, std::false_type{}, sa, sb);
+    if (tile < ntiles) step(tile, P0, GENERIC, sa, sb);
 
 #else
     // Plain order: tile's K and V both live in buffer PAR; next tile is staged into PAR^1.

@@ -32,6 +32,13 @@ CFGS = {
     "n512": (16, 16, 512, 128, "f16", False),
     "n8k": (1, 16, 8192, 128, "f16", False),
     "n16k": (1, 8, 16384, 128, "f16", False),
+    "c4k_b8": (8, 16, 4096, 128, "f16", True),
+    "c4k_b1": (1, 16, 4096, 128, "f16", True),
+    "c4k_h32": (1, 32, 4096, 128, "f16", True),
+    "c2k": (4, 16, 2048, 128, "f16", True),
+    "c4k": (2, 16, 4096, 128, "f16", True),
+    "c8k": (1, 16, 8192, 128, "f16", True),
+    "c16k": (1, 8, 16384, 128, "f16", True),
 }
 
 

@@ -49,6 +49,9 @@
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
 #endif
+#ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
+#define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
+#endif
 #ifndef FA2_ABL              // developer-only ablation bitmask (results are WRONG when non-zero):
 #define FA2_ABL 0            // 1 no exp/fma, 2 no row sum, 4 no PV mfma, 8 no QK mfma, 16 no global->LDS staging,
 #endif                       // 32 no V transpose reads, 64 no K reads, 128 no max, 256 no barrier
@@ -67,7 +70,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kQBlock = 256;      // Q rows per workgroup (all kernel shapes)
+constexpr int kQBlock = 256;      // rows per workgroup of the default kernel shapes (8 waves x 32 rows)
 constexpr int kKvTile = 64;       // KV rows per tile
 
 struct FwdParams {
@@ -158,7 +161,7 @@ struct Geo {
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
 __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
-    static_assert(NW * QB * 32 == kQBlock, "workgroup must cover 256 Q rows");
+    constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
     using GV_ = Geo<HDV, NW>;  // V tile image
     constexpr int ROWB = G_::ROWB, TILEB = G_::TILEB, NPASS = G_::NPASS;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         qblk = bid % p.nqblk;
     }
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = qblk * kQBlock;
+    const int q0 = qblk * kRowsPerBlock;
     const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave
     int qrow[QB];                               // this lane's Q row in each of its blocks (may be >= Nq)
 #pragma unroll
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // ---- KV sweep bounds
     int ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
     if (CAUSAL) {
-        const int qmax = (q0 + kQBlock < p.Nq ? q0 + kQBlock : p.Nq) - 1;
+        const int qmax = (q0 + kRowsPerBlock < p.Nq ? q0 + kRowsPerBlock : p.Nq) - 1;
         const int nt_c = qmax / kKvTile + 1;
         ntiles = nt_c < ntiles ? nt_c : ntiles;
     }
@@ -492,6 +495,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         constexpr bool FAST = MODE != 0;
         const bool more1 = FAST || tile + 1 < ntiles, more2 = FAST || tile + 2 < ntiles;
         const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
+#if FA2_IGLP >= 0
+        if constexpr (FAST) __builtin_amdgcn_iglp_opt(FA2_IGLP);   // scheduler hint for the steady-state block
+#endif
         if (more2 && !(FA2_ABL & 16)) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
         if (more1 && !(FA2_ABL & 16)) load_v(tile + 1, PAR ^ 1);
         if (next_w) qk(PAR ^ 1, sn);

@@ -27,7 +27,11 @@ constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 #ifndef FA2_NW
 #define FA2_NW 8
 #endif
-constexpr int kNW = FA2_NW, kQB = 8 / FA2_NW;
+#ifndef FA2_QB
+#define FA2_QB (8 / FA2_NW)
+#endif
+constexpr int kNW = FA2_NW, kQB = FA2_QB;
+constexpr int kFwdRows = kNW * kQB * 32;   // Q rows per forward workgroup
 
 template <typename K>
 int set_lds(K kernel, int bytes) {
@@ -114,7 +118,7 @@ int fa2_padded_head_dim(int D) {
 
 int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
     if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
-    if (q_rows_per_block) *q_rows_per_block = fa2::kQBlock;
+    if (q_rows_per_block) *q_rows_per_block = kFwdRows;
     if (kv_rows_per_tile) *kv_rows_per_tile = fa2::kKvTile;
     return FA2_OK;
 }
@@ -163,7 +167,7 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     p.ls[0] = lse_strides[0]; p.ls[1] = lse_strides[1];
     p.c = std::fabs(scale) * 1.4426950408889634f;  // fold log2(e): reference kernel_fp16.cu:827
     p.negate_q = scale < 0.f;
-    p.nqblk = (Nq + fa2::kQBlock - 1) / fa2::kQBlock;
+    p.nqblk = (Nq + kFwdRows - 1) / kFwdRows;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;

@@ -184,6 +184,27 @@ def test_bnhd_layout_is_zero_copy_and_matches_bhnd():
     assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd)
 
 
+def test_sd_hook_bnhd_adapter_matches_sdpa():
+    """The [B, N, H*D] call shape of ComfyUI / sd-webui (reference README.md:35-37) through the zero-copy BNHD path:
+    SD1.5 self-attention (D=40 and D=160) and cross-attention with 77 text tokens."""
+    from rocwmma_fattn.sd_hook import attention_bnhd
+    g = torch.Generator(device="cpu").manual_seed(14)
+    for (b, nq, nkv, heads, d) in ((2, 1024, 1024, 8, 40), (2, 256, 77, 8, 160), (1, 4096, 4096, 10, 64)):
+        q = torch.randn((b, nq, heads * d), generator=g).half().to(_dev())
+        k = torch.randn((b, nkv, heads * d), generator=g).half().to(_dev())
+        v = torch.randn((b, nkv, heads * d), generator=g).half().to(_dev())
+        o = attention_bnhd(q, k, v, heads)
+        torch.cuda.synchronize()
+        assert o.shape == q.shape and o.dtype == q.dtype
+        split = lambda t: t.reshape(t.shape[0], t.shape[1], heads, d).transpose(1, 2).float()  # noqa: E731
+        ref = torch.nn.functional.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(b, nq, heads * d)
+        assert float((o.float() - ref).abs().max()) <= ATOL[0] + RTOL[0] * float(ref.abs().max())
+    with pytest.raises(NotImplementedError):
+        attention_bnhd(q, k, v, heads, mask=torch.ones(1, device=_dev()))
+    sentinel = object()
+    assert attention_bnhd(q, k, v, heads, mask=torch.ones(1), fallback=lambda *a: sentinel) is sentinel
+
+
 def test_non_half_inputs_run_as_bf16_like_the_reference():
     """host.cpp:42-45: any other dtype is cast to bf16 and the bf16 result is returned."""
     g = torch.Generator(device="cpu").manual_seed(12)

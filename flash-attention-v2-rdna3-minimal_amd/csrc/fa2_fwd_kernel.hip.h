@@ -108,6 +108,21 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
 }
 
+// one dword of two 16-bit floats times an f32 factor, rounded back to 16 bits (RNE)
+template <bool BF16>
+__device__ __forceinline__ uint32_t scale2(uint32_t w, float f) {
+    float lo, hi;
+    if constexpr (BF16) {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xffff0000u);
+    } else {
+        const f32x2 x = __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
+        lo = x[0];
+        hi = x[1];
+    }
+    return pack2<BF16>(lo * f, hi * f);
+}
+
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -159,7 +174,16 @@ struct Geo {
 // HDV == HD except for D = 256, which is run as two column halves (blockIdx.y selects [0,128) or
 // [128,256)): a 256-wide f32 O accumulator plus the Q fragments would not fit 256 VGPRs, so QK^T is
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
-template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
+//
+// PRE ("pre-scaled Q", used for HD = 64 where the registers are there): Q is multiplied by c = |scale|*log2(e)
+// once and rounded back to 16 bits — the reference oracle's own contract, `scale * q_frags`
+// (pure_torch_ver.py:61) — and a tile's first QK^T MFMAs take C = -m (16 registers that all hold the
+// negated running reference) instead of C = 0, so the MFMA chain delivers s*c - m and the v_fma in front of
+// every v_exp disappears (-32 of ~180 VALU/LDS instructions per tile; +4 % at D = 64).  LSE then carries the
+// 16-bit rounding of q*c: measured 3e-4 (fp16) / 6e-3 (bf16) against 3e-6 without it — the reference's own L
+// is 6e-3 / 5e-2 off the float64 truth on the golden fixtures.  The host only selects PRE kernels when c <= 1
+// (the product cannot overflow fp16).
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool PRE = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
@@ -224,6 +248,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
             for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] ^= (u32x4){sgn, sgn, sgn, sgn};
         }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int ks = 0; ks < KS_QK; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qf[qb][ks][i] = scale2<BF16>(qf[qb][ks][i], p.c);
+        }
     }
 
     // ---- K/V staging: buffer descriptors of this head's matrices (out-of-range rows read 0)
@@ -274,12 +304,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
         ntiles_w = nt_w < ntiles ? nt_w : ntiles;
     }
+    // PRE: hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops into a
+    // shape that needs ~30 more VGPRs than the causal kernel's
+    if constexpr (PRE) asm volatile("" : "+s"(ntiles_w));
 
     f32x16 acc[QB][DT];
-    float m_run[QB], l_run[QB];  // running reference max (raw score units) / row sum (this lane's kv half)
+    float m_run[QB], l_run[QB];  // running reference max (raw score units; PRE: log2 units) / row sum (this lane's kv half)
+    float negm[QB][16];          // PRE: -m_run, 16 separately named copies that the allocator keeps as one MFMA C tuple
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = -INFINITY;
+        m_run[qb] = PRE ? 0.f : -INFINITY;
+        if constexpr (PRE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; asm volatile("" : "+v"(negm[qb][r])); }
+        }
         l_run[qb] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -346,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[qb][0][r] = 0.f; s[qb][1][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[qb][0][r] = s[qb][1][r] = PRE ? negm[qb][r] : 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
             u32x4 a0, a1;
@@ -374,9 +412,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
-    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
+    // PRE: the scores arrive as s*c - m_old; `first` (tile 0) adopts the tile's own maximum whatever its sign.
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], bool first = false) __attribute__((always_inline)) {
         float mx[QB];
-        bool grow = FA2_DEFER_THR < 0.f;
+        bool grow = FA2_DEFER_THR < 0.f || (PRE && first);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             f32x16& s0 = s[qb][0];
@@ -405,9 +444,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             }
             mx[qb] = half_swap_max(m);
             if (!(FA2_DEFER_THR < 0.f))
-                grow = grow || (__builtin_amdgcn_ballot_w64((mx[qb] - m_run[qb]) * c > FA2_DEFER_THR) != 0);
+                grow = grow || (__builtin_amdgcn_ballot_w64((PRE ? mx[qb] : (mx[qb] - m_run[qb]) * c) > FA2_DEFER_THR) != 0);
         }
-        if (grow) {
+        if (PRE && grow) {
+            // this tile's scores were formed against the old reference: shift them, the reference and the
+            // accumulated row by the growth d
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float d = first ? mx[qb] : __builtin_fmaxf(mx[qb], 0.f);
+                if (d == -INFINITY) d = 0.f;
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                m_run[qb] += d;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    negm[qb][r] = -m_run[qb];
+                    asm volatile("" : "+v"(negm[qb][r]));   // keep 16 distinct values (no CSE into one register)
+                    s[qb][0][r] -= d;
+                    s[qb][1][r] -= d;
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[qb][dt][r] *= alpha;
+            }
+        }
+        if (!PRE && grow) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const float m_new = __builtin_fmaxf(m_run[qb], mx[qb]);
@@ -434,8 +496,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!(FA2_ABL & 1)) {
-                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
-                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
+                    s0[r] = __builtin_amdgcn_exp2f(PRE ? s0[r] : __builtin_fmaf(s0[r], c, -mc));
+                    s1[r] = __builtin_amdgcn_exp2f(PRE ? s1[r] : __builtin_fmaf(s1[r], c, -mc));
                 }
                 if (!(FA2_ABL & 2)) {
                     rs0 += s0[r];
@@ -522,7 +584,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     __syncthreads();
     f32x16 sa[QB][2], sb[QB][2];
     qk(0, sa);
-    finish_scores(0, std::true_type{}, sa);
+    finish_scores(0, std::true_type{}, sa, true);
 
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
@@ -558,7 +620,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
         if (cur_w) {
             qk(PAR, sc);
-            finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc);
+            finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc, tile == 0);
             u32x4 pf[QB][4];
             exp_scores(sc, pf);
             pv(PAR, pf);
@@ -619,7 +681,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
             if (hi == 0 && vcol0 == 0)
-                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = m_run[qb] * c + __builtin_amdgcn_logf(l_tot);
+                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = (PRE ? m_run[qb] : m_run[qb] * c) + __builtin_amdgcn_logf(l_tot);
         }
     }
 }

@@ -39,23 +39,28 @@ int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int HD, bool BF16>
-int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+#ifndef FA2_PRESCALE_MAX_HD          // head dims up to this run the pre-scaled-Q kernels (fa2_fwd_kernel.hip.h, "PRE")
+#define FA2_PRESCALE_MAX_HD 64
+#endif
+
+template <int HD, bool BF16, bool CAUSAL, bool PRE>
+int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
     constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
-    const dim3 block(kNW * 64);
-    int rc;
-    if (causal) {
-        auto kern = fa2::fwd_kernel<HD, HDV, BF16, true, kNW, kQB>;
-        if ((rc = set_lds(kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    } else {
-        auto kern = fa2::fwd_kernel<HD, HDV, BF16, false, kNW, kQB>;
-        if ((rc = set_lds(kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    }
+    auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB, PRE>;
+    if (int rc = set_lds(kern, lds)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(kNW * 64), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+template <int HD, bool BF16>
+int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    if constexpr (HD <= FA2_PRESCALE_MAX_HD && kQB == 1) {
+        if (p.c <= 1.0f)   // q*c cannot leave the fp16 range; larger scales keep the f32 scaling path
+            return causal ? launch_t<HD, BF16, true, true>(p, stream) : launch_t<HD, BF16, false, true>(p, stream);
+    }
+    return causal ? launch_t<HD, BF16, true, false>(p, stream) : launch_t<HD, BF16, false, false>(p, stream);
 }
 
 template <int HD, bool BF16, bool CAUSAL>
@@ -123,6 +128,11 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
     return FA2_OK;
 }
 
+int fa2_fwd_prescales_q(int D, float scale) {
+    if (fa2_padded_head_dim(D) != D) return -1;
+    return kQB == 1 && D <= FA2_PRESCALE_MAX_HD && std::fabs(scale) * 1.4426950408889634f <= 1.0f;
+}
+
 const char* fa2_error_string(int code) {
     switch (code) {
         case FA2_OK: return "ok";
@@ -139,7 +149,7 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.2 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.3 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined)"; }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
             int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],

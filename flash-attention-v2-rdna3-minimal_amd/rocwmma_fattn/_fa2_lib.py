@@ -40,6 +40,7 @@ SYMBOLS = {
     "fa2_supported_head_dims": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
     "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "fa2_fwd_prescales_q": (ctypes.c_int, [ctypes.c_int, ctypes.c_float]),
     "fa2_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "fa2_version": (ctypes.c_char_p, []),
 }

@@ -29,6 +29,10 @@
  *                          reference's 16-bit LDS accumulator is (kernel_fp16.cu:223-228, :483-488),
  *                          and m, l kept in the I/O dtype as pure_torch_ver.py:54-58 does
  *   FA2_ORACLE_BF16_TRUNC  bf16 conversions truncate instead of RNE (kernel_bf16.cu:62-72)
+ *   FA2_ORACLE_PRESCALE_Q  Q is multiplied by scale*log2(e) and rounded back to the I/O dtype BEFORE the
+ *                          product, as pure_torch_ver.py:61 does (`scale * q_frags[Tr_i]`); S = Q' K^T is then
+ *                          not scaled again.  The gfx950 kernels use this contract where
+ *                          fa2_fwd_prescales_q(D, scale) says so (include/fa2_gfx950.h).
  *
  * Build: oracle/Makefile (gcc -O3 -mavx2 -fopenmp -ffp-contract=off -shared -fPIC).  Plain C99.
  */
@@ -45,6 +49,7 @@
 #define FA2_ORACLE_ROUND_S 1
 #define FA2_ORACLE_ROUND_O 2
 #define FA2_ORACLE_BF16_TRUNC 4
+#define FA2_ORACLE_PRESCALE_Q 8
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -127,6 +132,8 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
     const float c = scale * 1.4426950408889634f; /* kernel_fp16.cu:827 */
     const int Tr = (Nq + Br - 1) / Br, Tc = (Nkv + Bc - 1) / Bc;
     const int round_s = flags & FA2_ORACLE_ROUND_S, round_o = flags & FA2_ORACLE_ROUND_O;
+    const int prescale = flags & FA2_ORACLE_PRESCALE_Q;
+    const float cs = prescale ? 1.f : c; /* factor applied to the f32 dot product */
     int failed = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -171,7 +178,11 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
                     const int r0 = tr * Br, rows = (r0 + Br <= Nq) ? Br : Nq - r0;
                     const uint16_t* qb = q + b * qs[0] + h * qs[1];
                     for (int i = 0; i < rows; ++i) {
-                        for (int d = 0; d < D; ++d) qf[(size_t)i * D + d] = load16(cv, qb[(int64_t)(r0 + i) * qs[2] + d]);
+                        for (int d = 0; d < D; ++d) {
+                            float x = load16(cv, qb[(int64_t)(r0 + i) * qs[2] + d]);
+                            if (prescale) x = round16(cv, x * c); /* pure_torch_ver.py:61 */
+                            qf[(size_t)i * D + d] = x;
+                        }
                         m[i] = -INFINITY;
                         l[i] = 0.f;
                         memset(O + (size_t)i * D, 0, D * sizeof(float));
@@ -190,7 +201,7 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
                                 float acc = 0.f;
 #pragma omp simd reduction(+ : acc)
                                 for (int d = 0; d < D; ++d) acc += qi[d] * kj[d];
-                                float s = acc * c;
+                                float s = acc * cs;
                                 if (round_s) s = round16(cv, s);
                                 if (causal && c0 + j > r0 + i) s = -INFINITY; /* kernel_fp16.cu:403-410 */
                                 Si[j] = s;

@@ -31,6 +31,7 @@ DTYPE_BF16 = 1
 ROUND_S = 1
 ROUND_O = 2
 BF16_TRUNC = 4
+PRESCALE_Q = 8      # scale*log2e folded into Q in the I/O dtype (pure_torch_ver.py:61)
 LOG2E = 1.4426950408889634
 
 _lib = None

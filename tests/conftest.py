@@ -35,7 +35,10 @@ GOLDEN_CASES = ["c1_f16", "c1_bf16", "mt_f16", "mt_bf16", "ragged_f16", "cross_f
 FLOOR = {0: 1e-3, 1: 8e-3}          # vs truth, by dtype code (0 = fp16, 1 = bf16)
 ATOL = {0: 1e-3, 1: 8e-3}           # vs same-contract oracle
 RTOL = {0: 2e-3, 1: 1.6e-2}
-LSE_TOL = 1e-3
+LSE_TOL = 1e-3                      # vs the oracle run under the SAME scaling contract (fa2_fwd_prescales_q)
+# vs float64 truth: where Q is pre-scaled in the I/O dtype (the reference oracle's `scale * q_frags`,
+# pure_torch_ver.py:61) LSE carries that 16-bit rounding; the reference's own L is 6e-3 / 5e-2 off truth on the fixtures
+LSE_TRUTH_TOL = {0: 2e-3, 1: 1.6e-2}
 GRAD_TOL = {0: 2e-3, 1: 1.6e-2}
 
 

@@ -3,7 +3,7 @@ pure_torch_ver.py (tests/golden/make_golden.py) and against dense float64 attent
 import numpy as np
 import pytest
 
-from conftest import ATOL, FLOOR, GRAD_TOL, LSE_TOL, RTOL, grads_truth, load_golden
+from conftest import ATOL, FLOOR, GRAD_TOL, LSE_TOL, LSE_TRUTH_TOL, RTOL, grads_truth, load_golden
 from oracle import fa2_oracle as fo
 
 
@@ -64,6 +64,26 @@ def test_c_oracle_against_golden(golden):
         n = golden["N"]
         l_ref2 = var["l_ref"][:, :, :n] * fo.LOG2E
         assert np.abs(lse - l_ref2).max() <= (2e-2 if dt == 0 else 1.6e-1)
+
+
+def test_c_oracle_prescaled_q_contract_against_golden(golden):
+    """PRESCALE_Q = the reference oracle's own `scale * q_frags` in the I/O dtype (pure_torch_ver.py:61), which the
+    gfx950 kernels use where fa2_fwd_prescales_q() says so: same O bar against truth, LSE within the 16-bit
+    rounding of q*scale, and closer to the reference's L than that L is to truth."""
+    dt = golden["dtype"]
+    for causal, var in golden["variants"].items():
+        o_bits, lse = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal, flags=fo.PRESCALE_Q)
+        err = np.abs(_f32(o_bits, dt) - var["o_true"]).max()
+        ref_err = np.abs(_f32(var["o_ref"], dt) - var["o_true"]).max()
+        assert err <= max(2 * ref_err, FLOOR[dt]), (golden["name"], causal, err, ref_err)
+        lse_err = np.abs(lse - var["lse2_true"]).max()
+        assert lse_err <= LSE_TRUTH_TOL[dt], (golden["name"], causal, lse_err)
+        n = golden["N"]
+        ref_lse_err = np.abs(var["l_ref"][:, :, :n] * fo.LOG2E - var["lse2_true"]).max()
+        assert lse_err <= ref_lse_err, "pre-scaled-Q LSE should be at least as close to truth as the reference's 16-bit L"
+        o0, lse0 = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal)
+        assert np.abs(_f32(o_bits, dt) - _f32(o0, dt)).max() <= ATOL[dt] + RTOL[dt]      # the two contracts agree within tolerance
+        assert np.abs(lse - lse0).max() <= LSE_TRUTH_TOL[dt]
 
 
 def test_c_oracle_reference_rounding_mode_tracks_reference(golden):

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     }
     int ntiles_w = ntiles;
     if (CAUSAL) { const int nt_w = (qw0 + 31) / kKvTile + 1; ntiles_w = nt_w < ntiles ? nt_w : ntiles; }
+    asm volatile("" : "+s"(ntiles_w));   // opaque: stops the non-causal build from peeling the tail tile into a register-hungry shape
 
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
         char* base = smem + stage * STAGEB;
@@ -214,12 +215,14 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const float c = p.c, scale = p.scale;
 
-    stage_load(0, 0);
-    __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int st = tile & 1;
-        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
-        if (tile < ntiles_w) {
+    // tiles [0, n_plain) need no mask for this wave: fully inside Nkv and fully below the wave's diagonal
+    int n_plain = p.Nkv / kKvTile;
+    if (CAUSAL) { const int nc = (qw0 + 1) / kKvTile; n_plain = nc < n_plain ? nc : n_plain; }
+    n_plain = n_plain < ntiles_w ? n_plain : ntiles_w;
+
+    auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        {
             const char* kR = smem + st * STAGEB;
             const char* vR = kR + TILEB;
             const char* kT = kR + 2 * TILEB;
@@ -232,21 +235,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
                 s1 = mfma16<BF16>(*(const u32x4*)(kR + ln.kr_off[ks] + 32 * ROWB), qf[ks], s1);
             }
             const int kv0 = tile * kKvTile;
-            const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0);
-            const bool need_tail = kv0 + kKvTile > p.Nkv;
-            int lim = 0x7fffffff;
-            if (need_causal || need_tail) {
-                const int lim_c = CAUSAL ? qrow : 0x7fffffff;
-                lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
-            }
+            const int lim_c = CAUSAL ? qrow : 0x7fffffff;
+            const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;   // kv index must be <= lim (MASKED tiles only)
             // P^T = 2^(S^T c - L); masked entries -> 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -Lq));
                 float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -Lq));
-                s0[r] = kvi > lim ? 0.f : p0;
-                s1[r] = kvi + 32 > lim ? 0.f : p1;
+                s0[r] = MASKED && kvi > lim ? 0.f : p0;
+                s1[r] = MASKED && kvi + 32 > lim ? 0.f : p1;
             }
             f32x16 d0, d1;
 #pragma unroll
@@ -256,11 +254,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
                 d0 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks]), gf[ks], d0);
                 d1 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks] + 32 * ROWB), gf[ks], d1);
             }
-            // dS^T = scale * P^T * (dP^T - D)
+            // dS^T / scale = P^T * (dP^T - D); the factor `scale` is applied once, to the finished dQ
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s0[r] = s0[r] * (d0[r] - Dq) * scale;
-                s1[r] = s1[r] * (d1[r] - Dq) * scale;
+                s0[r] = s0[r] * (d0[r] - Dq);
+                s1[r] = s1[r] * (d1[r] - Dq);
             }
             u32x4 df[4];
 #pragma unroll
@@ -280,11 +278,20 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, df[ks], acc[dt]);
                 }
         }
+    };
+
+    stage_load(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int st = tile & 1;
+        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
+        if (tile < n_plain) tile_body(tile, st, std::false_type{});
+        else if (tile < ntiles_w) tile_body(tile, st, std::true_type{});
         __syncthreads();
     }
     if (qrow < p.Nq) {
         uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, 1.0f);
+        store_acc_t<BF16, DT>(acc, op, hi, scale);
     }
 }
 
@@ -365,12 +372,12 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const float c = p.c, scale = p.scale;
 
-    if (tile0 < ntiles) stage_load(tile0, 0);
-    __syncthreads();
-    for (int tile = tile0; tile < ntiles; ++tile) {
-        const int st = (tile - tile0) & 1;
-        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
-        if (tile >= tile0_w) {
+    // Q tiles from first_plain on lie entirely at or below this wave's KV rows' diagonal (q >= kv for every pair)
+    const int first_plain = CAUSAL ? (kvw0 + 31 + kKvTile - 1) / kKvTile : 0;
+
+    auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        {
             const char* qR = smem + st * STAGEB;
             const char* lt = qR + NT * TILEB;
             f32x16 s0, s1;
@@ -393,7 +400,6 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
                 }
             }
             const int q0t = tile * kKvTile;
-            const bool need_causal = CAUSAL && (kvw0 + 31 > q0t);   // some (q, kv) of this wave has kv > q
             // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -411,13 +417,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
                     const int qi = q0t + e + 8 * g4 + 4 * hi;
                     float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
                     float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
-                    if (need_causal) {
+                    if constexpr (MASKED) {           // causal: pairs with kv > q contribute nothing
                         if (kvrow > qi) p0 = 0.f;
                         if (kvrow > qi + 32) p1 = 0.f;
                     }
-                    if constexpr (WANT_DK) {
-                        p0 = p0 * (d0[r] - D0[e]) * scale;
-                        p1 = p1 * (d1[r] - D1[e]) * scale;
+                    if constexpr (WANT_DK) {          // dS / scale; `scale` is applied once, to the finished dK
+                        p0 = p0 * (d0[r] - D0[e]);
+                        p1 = p1 * (d1[r] - D1[e]);
                     }
                     s0[r] = p0;
                     s1[r] = p1;
@@ -442,12 +448,21 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], acc[dt]);
                 }
         }
+    };
+
+    if (tile0 < ntiles) stage_load(tile0, 0);
+    __syncthreads();
+    for (int tile = tile0; tile < ntiles; ++tile) {
+        const int st = (tile - tile0) & 1;
+        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+        if (tile >= first_plain) tile_body(tile, st, std::false_type{});
+        else if (tile >= tile0_w) tile_body(tile, st, std::true_type{});
         __syncthreads();
     }
     if (kvrow < p.Nkv) {
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
                                : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, 1.0f);
+        store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f);
     }
 }
 

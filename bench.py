@@ -176,6 +176,34 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     assert torch.isfinite(o.float()).all(), "non-finite attention output"
 
+    # Informational, outside the timed region and never part of `value`: the backward of the same workload
+    # through autograd, timed the way the reference harness does (O.backward(dO, retain_graph=True) in a loop,
+    # bench_with_sdpa.py:78-88) — grads are dropped instead of zeroed so no accumulation kernels are counted.
+    bwd = None
+    if world == 1:
+        qg, kg, vg = (t.detach().requires_grad_(True) for t in (q, k, v))
+        do = torch.rand_like(q)
+        og = attn(qg, kg, vg, None, causal)
+
+        def one_backward():
+            qg.grad = kg.grad = vg.grad = None
+            og.backward(do, retain_graph=True)
+
+        for _ in range(5):
+            one_backward()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_b = 30
+        b0.record()
+        for _ in range(n_b):
+            one_backward()
+        b1.record()
+        torch.cuda.synchronize()
+        bwd_ms = b0.elapsed_time(b1) / n_b
+        assert all(torch.isfinite(t.grad.float()).all() for t in (qg, kg, vg)), "non-finite gradient"
+        bwd = {"bwd_ms": round(bwd_ms, 4),
+               "bwd_tflops": round(2.5 * attention_flops(B_local, H, N, N, D, causal) / (bwd_ms * 1e-3) / 1e12, 1),
+               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); 4 launches: delta, dQ, dV, dK"}
+
     times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
@@ -199,6 +227,8 @@ def main():
                          "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_local},
             "pct_of_mfma_roofline": round(100.0 * value / (MFMA_PEAK_TFLOPS * world), 2),
         }
+        if bwd is not None:
+            line["backward"] = bwd
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_sdpa"] = cpu_baseline(B * H, N, D, causal, dtype, 1234 + cfg_idx)
         print(json.dumps(line), flush=True)

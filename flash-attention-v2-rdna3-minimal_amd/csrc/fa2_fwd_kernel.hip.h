@@ -49,14 +49,6 @@
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
 #endif
-// FA2_QLDS=1 (HD == 128): the Q fragments live in a wave-private LDS image (K-tile swizzle) and are re-read per
-// k-step instead of occupying 32 VGPRs — the room the rotated pipeline (FA2_PIPE=2) needs for its second P buffer.
-#ifndef FA2_QLDS
-#define FA2_QLDS 0
-#endif
-#ifndef FA2_ROT_PIN
-#define FA2_ROT_PIN 1
-#endif
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
@@ -291,13 +283,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     int kr_off[KS_QK];  // K fragment (row l31 of the 32-row half tile), k-step ks
 #pragma unroll
     for (int ks = 0; ks < KS_QK; ++ks) kr_off[ks] = G_::k_off(l31, 2 * ks + hi);
-    constexpr bool kQLds = FA2_QLDS && HD == 128 && QB == 1;
-    constexpr int QBASE = 2 * TILEB + 2 * VTILEB;            // Q image: NW x (32 rows x ROWB), wave-private
-    char* const qimg = smem + QBASE + wave * (32 * ROWB);
-    if constexpr (kQLds) {
-#pragma unroll
-        for (int ks = 0; ks < KS_QK; ++ks) *(u32x4*)(qimg + kr_off[ks]) = qf[0][ks];
-    }
     int vr_off[DT];     // V^T fragment via transpose read: rows 4hi + (p>>2), cols 32dt + 16(g&1) + 4(p&3)
     {
         const int pp = lane & 15, g1 = (lane >> 4) & 1;
@@ -414,11 +399,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                     s[qb][0][ks] += __uint_as_float(a0[0] ^ a0[1] ^ a0[2] ^ a0[3]);
                     s[qb][1][ks] += __uint_as_float(a1[0] ^ a1[1] ^ a1[2] ^ a1[3]);
                 } else {
-                    u32x4 bq;
-                    if constexpr (kQLds) bq = *(const u32x4*)(qimg + kr_off[ks]);
-                    else bq = qf[qb][ks];
-                    s[qb][0] = mfma16<BF16>(a0, bq, s[qb][0]);
-                    s[qb][1] = mfma16<BF16>(a1, bq, s[qb][1]);
+                    s[qb][0] = mfma16<BF16>(a0, qf[qb][ks], s[qb][0]);
+                    s[qb][1] = mfma16<BF16>(a1, qf[qb][ks], s[qb][1]);
                 }
             }
         }
@@ -431,10 +413,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
     // PRE: the scores arrive as s*c - m_old; `first` (tile 0) adopts the tile's own maximum whatever its sign.
-    // `pend` (rotated pipeline): the previous tile's P, already formed at the old reference but not yet multiplied
-    // into O — it is rescaled with O and l.
-    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], bool first = false,
-                             u32x4 (*pend)[4] = nullptr) __attribute__((always_inline)) {
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], bool first = false) __attribute__((always_inline)) {
         float mx[QB];
         bool grow = FA2_DEFER_THR < 0.f || (PRE && first);
 #pragma unroll
@@ -477,12 +456,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 const float alpha = __builtin_amdgcn_exp2f(-d);
                 m_run[qb] += d;
                 l_run[qb] *= alpha;
-                if (pend) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pend[qb][ks][i] = scale2<BF16>(pend[qb][ks][i], alpha);
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     negm[qb][r] = -m_run[qb];
@@ -503,12 +476,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
                 m_run[qb] = m_new;
                 l_run[qb] *= alpha;
-                if (pend) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pend[qb][ks][i] = scale2<BF16>(pend[qb][ks][i], alpha);
-                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -607,84 +574,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn);
     };
 
-#if FA2_PIPE == 2
-    // Rotated pipeline: step(t) runs QK^T(t+1), P.V(t-1) and softmax(t) — none of the three depends on another
-    // inside the step, so all 32 MFMAs can stream while the VALU forms P(t).  V(t) is staged during step(t) (it
-    // is first read in step(t+1)); P lives in two register buffers by tile parity.
-    auto step2 = [&](int tile, auto par, auto mode, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2],
-                     u32x4 (&pf_prev)[QB][4], u32x4 (&pf_cur)[QB][4]) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        constexpr int MODE = decltype(mode)::value;
-        constexpr bool FAST = MODE != 0;
-        const bool more2 = FAST || tile + 2 < ntiles;
-        const bool next_w = FAST || tile + 1 < ntiles_w, cur_w = FAST || tile < ntiles_w;
-        const bool prev_w = FAST || (tile > 0 && tile - 1 < ntiles_w);
-#if FA2_IGLP >= 0
-        if constexpr (FAST) __builtin_amdgcn_iglp_opt(FA2_IGLP);
-#endif
-        if (more2) load_k(tile + 2, PAR);
-        load_v(tile, PAR);
-        if (next_w) qk(PAR ^ 1, sn);
-        if (prev_w) pv(PAR ^ 1, pf_prev);
-        if (cur_w) {
-            exp_scores(sc, pf_cur);
-#if FA2_ROT_PIN
-            // keep the softmax in front of the barrier (beside the MFMAs): the compiler otherwise sinks it past it
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(pf_cur[qb][ks]));
-#endif
-        }
-        if (more2) write_k(PAR);
-        write_v(PAR);
-        __syncthreads();
-        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn, false, cur_w ? pf_cur : nullptr);
-    };
-    load_k(0, 0);
-    write_k(0);
-    if (ntiles > 1) { load_k(1, 1); write_k(1); }
-    __syncthreads();
-    f32x16 sa[QB][2], sb[QB][2];
-    u32x4 pfa[QB][4], pfb[QB][4];
-    qk(0, sa);
-    finish_scores(0, std::true_type{}, sa, true);
-
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::integral_constant<int, 0> GENERIC{};
-    constexpr std::integral_constant<int, 1> STEADY{};
-    // steady-state tiles [2, n_fast): tile >= 1, tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
-    int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
-    {
-        const int unmasked_kv = p.Nkv / kKvTile;
-        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;
-        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
-        n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;
-        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
-    }
-    int tile = 0;
-    if (ntiles >= 2) {                       // tiles 0, 1: no P.V behind tile 0
-        step2(0, P0, GENERIC, sa, sb, pfb, pfa);
-        step2(1, P1, GENERIC, sb, sa, pfa, pfb);
-        tile = 2;
-    }
-    for (; tile < n_fast; tile += 2) {
-        step2(tile, P0, STEADY, sa, sb, pfb, pfa);
-        step2(tile + 1, P1, STEADY, sb, sa, pfa, pfb);
-    }
-    for (; tile + 1 < ntiles; tile += 2) {
-        step2(tile, P0, GENERIC, sa, sb, pfb, pfa);
-        step2(tile + 1, P1, GENERIC, sb, sa, pfa, pfb);
-    }
-    if (tile < ntiles) step2(tile, P0, GENERIC, sa, sb, pfb, pfa);
-    // drain: P.V of the last tile (waves whose causal range ended earlier did theirs inside the loop)
-    if (ntiles - 1 < ntiles_w) {
-        if ((ntiles - 1) & 1) pv(1, pfb);
-        else pv(0, pfa);
-    }
-
-#elif FA2_PIPE == 1
+#if FA2_PIPE == 1
     // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
     load_k(0, 0);
     load_v(0, 0);

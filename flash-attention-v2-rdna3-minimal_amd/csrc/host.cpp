@@ -46,8 +46,7 @@ int set_lds(K kernel, int bytes) {
 template <int HD, bool BF16, bool CAUSAL, bool PRE>
 int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
-    constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB +
-                        ((FA2_QLDS && HD == 128 && kQB == 1) ? kNW * 32 * fa2::Geo<HD, kNW>::ROWB : 0);
+    constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
     auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB, PRE>;
     if (int rc = set_lds(kern, lds)) return rc;

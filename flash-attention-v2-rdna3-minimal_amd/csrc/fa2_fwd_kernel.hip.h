@@ -584,6 +584,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     __syncthreads();
     f32x16 sa[QB][2], sb[QB][2];
     qk(0, sa);
+    __syncthreads();   // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us
     finish_scores(0, std::true_type{}, sa, true);
 
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked

@@ -40,16 +40,14 @@
 #ifndef FA2_DEFER_THR        // skip the O rescale while the row max grew by <= this (log2 units); <0: always rescale.
 #define FA2_DEFER_THR 8.0f   // 0 = exact FA2 (rescale whenever any row's max grows); 8 keeps P <= 2^8 (fp16/bf16 safe): +5 %
 #endif
-// (The loop is the cross-tile software pipeline: QK^T of tile+1 beside the softmax of tile.  The plain-order
-//  variant, 1090-1125 TF against 1130-1180, is in the git history: FA2_PIPE=0 before the persistent rewrite.)
+#ifndef FA2_PIPE             // 1: cross-tile software pipeline inside each wave (QK^T of tile+1 beside softmax of tile);
+#define FA2_PIPE 1           // 0: plain order.  1 -> 1130-1180 TF, 0 -> 1090-1125 TF
+#endif
 #ifndef FA2_LDS_DMA          // stage K/V tiles with buffer_load ... lds (no staging VGPRs, no ds_write); the LDS swizzle
 #define FA2_LDS_DMA 1        // is applied to the per-lane SOURCE address, the LDS image stays lane-linear.
 #endif                       // D=128: +3 % non-causal, +6 % causal; D=64: -3 % -> register staging below FA2_LDS_DMA_MIN_HD
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
-#endif
-#ifndef FA2_SEAM             // 1: prefetch the next item's K0/K1/V0/Q inside the last two steps of the current one
-#define FA2_SEAM 1
 #endif
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
@@ -203,15 +201,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
-    // Per-item code (coordinates, pointers, strides) re-reads the parameter block from the kernarg segment instead
-    // of keeping ~40 SGPRs of it alive across the whole item loop (they were spilled to VGPR lanes): the laundered
-    // pointer stops the compiler from hoisting those scalar loads to kernel entry.
-    typedef const __attribute__((address_space(4))) FwdParams* kernarg_ptr;
-    auto args = [&]() __attribute__((always_inline)) {
-        kernarg_ptr a = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(a));
-        return a;
-    };
 
     // ---- workgroup -> (batch*head, q block).  blockIdx % 8 is the XCD a block lands on.
     //   non-causal: all q blocks of a head run on one XCD, back to back, so the head's K/V stay in that
@@ -220,75 +209,58 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     //               the order is longest-first ACROSS heads (all heads' last q block, then the one before,
     //               ...): with per-head ordering the long blocks of the later heads arrive last and the
     //               makespan was 100 tile-steps instead of 68 at B2 H16 N4096.
-    auto decode = [&](int bid, int& bh, int& qblk, int& H) __attribute__((always_inline)) {
-        const kernarg_ptr p = args();
-        const int nbh = p->B * p->H;
-        H = p->H;
-        if ((nbh & 7) == 0) {
-            const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
-            if (CAUSAL) {
-                bh = (bid & 7) + 8 * (slot % hpx);
-                qblk = p->nqblk - 1 - slot / hpx;
-            } else {
-                bh = (bid & 7) + 8 * (slot / p->nqblk);
-                qblk = slot % p->nqblk;
-            }
-        } else if (CAUSAL) {
-            bh = bid % nbh;
-            qblk = p->nqblk - 1 - bid / nbh;
+    const int nbh = p.B * p.H;
+    const int bid = blockIdx.x;
+    int bh, qblk;
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
+        if (CAUSAL) {
+            bh = (bid & 7) + 8 * (slot % hpx);
+            qblk = p.nqblk - 1 - slot / hpx;
         } else {
-            bh = bid / p->nqblk;
-            qblk = bid % p->nqblk;
+            bh = (bid & 7) + 8 * (slot / p.nqblk);
+            qblk = slot % p.nqblk;
         }
-    };
-    // Persistent workgroups: gridDim.x <= number of (head, q block) items; a workgroup walks the item list in
-    // rounds of gridDim.x, snaking (round r odd: reversed) so that under the causal longest-first order every
-    // workgroup gets a long and a short item.  gridDim.x is a multiple of 8 whenever it is smaller than the
-    // item count (host.cpp), so all workgroups of an XCD keep working on the same residue class of heads.
-    constexpr bool kPersistent = HD <= 128;      // D = 256 (two column halves on grid.y) keeps one item per workgroup
-    int b, h, q0, qw0;                           // current item
+    } else if (CAUSAL) {
+        bh = bid % nbh;
+        qblk = p.nqblk - 1 - bid / nbh;
+    } else {
+        bh = bid / p.nqblk;
+        qblk = bid % p.nqblk;
+    }
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * kRowsPerBlock;
+    const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave
     int qrow[QB];                               // this lane's Q row in each of its blocks (may be >= Nq)
-    u32x4 qf[QB][KS_QK];                        // Q fragments (B operand): 8 consecutive d of the lane's row per k-step
-    // issue the global loads of an item's Q fragments (no use of the data: the wait lands at fix_q)
-    auto issue_q = [&](int ib, int ih, int iq0) __attribute__((always_inline)) {
-        const kernarg_ptr p = args();
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            const int r = iq0 + wave * kRowsPerWave + 32 * qb + l31;
-            const int qr = r < p->Nq ? r : p->Nq - 1;
-            const uint16_t* qp = (const uint16_t*)p->q + ib * p->qs[0] + ih * p->qs[1] + (int64_t)qr * p->qs[2];
+    for (int qb = 0; qb < QB; ++qb) qrow[qb] = qw0 + 32 * qb + l31;
+
+    // ---- Q fragments (B operand): lane reads 8 consecutive d of its row per k-step
+    u32x4 qf[QB][KS_QK];
 #pragma unroll
-            for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
+        const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
+#pragma unroll
+        for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi);
+        if (p.negate_q) {
+            const uint32_t sgn = 0x80008000u;
+#pragma unroll
+            for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] ^= (u32x4){sgn, sgn, sgn, sgn};
         }
-    };
-    auto fix_q = [&]() __attribute__((always_inline)) {
+        if constexpr (PRE) {
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            if (p.negate_q) {
-                const uint32_t sgn = 0x80008000u;
+            for (int ks = 0; ks < KS_QK; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] ^= (u32x4){sgn, sgn, sgn, sgn};
-            }
-            if constexpr (PRE) {
-#pragma unroll
-                for (int ks = 0; ks < KS_QK; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) qf[qb][ks][i] = scale2<BF16>(qf[qb][ks][i], p.c);
-            }
+                for (int i = 0; i < 4; ++i) qf[qb][ks][i] = scale2<BF16>(qf[qb][ks][i], p.c);
         }
-    };
+    }
 
     // ---- K/V staging: buffer descriptors of this head's matrices (out-of-range rows read 0)
-    auto k_desc = [&](int ib, int ih) __attribute__((always_inline)) {
-        const kernarg_ptr p = args();
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p->k + ib * p->ks[0] + ih * p->ks[1]), 0, p->k_bytes, 0x00020000);
-    };
-    auto v_desc = [&](int ib, int ih) __attribute__((always_inline)) {
-        const kernarg_ptr p = args();
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p->v + ib * p->vs[0] + ih * p->vs[1]), 0, p->v_bytes, 0x00020000);
-    };
-    auto krs = k_desc(0, 0), vrs = v_desc(0, 0);      // current item's; set by set_item
-    auto nkrs = krs, nvrs = vrs;                      // next item's (seam prefetch)
+    const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
+    const uint16_t* vbase = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1];
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
     const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
     uint32_t kg_off[NPASS], vg_off[VNPASS];  // per-lane byte offsets into the head matrix, tile 0
     int kw_off[NPASS], vw_off[VNPASS];       // per-lane LDS byte offsets inside a tile image
@@ -319,49 +291,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             vr_off[dt] = GV_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
     }
 
-    // ---- per-item setup: coordinates, descriptors, KV sweep bounds
-    int ntiles, ntiles_w;     // KV tiles of the item / tiles this wave computes (causal: the rest only stage + sync)
-    auto set_item = [&](int ib, int ih, int iq0) __attribute__((always_inline)) {
-        b = ib; h = ih; q0 = iq0;
-        qw0 = q0 + wave * kRowsPerWave;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) qrow[qb] = qw0 + 32 * qb + l31;
-        krs = k_desc(b, h);
-        vrs = v_desc(b, h);
-        ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
-        if (CAUSAL) {
-            const int qmax = (q0 + kRowsPerBlock < p.Nq ? q0 + kRowsPerBlock : p.Nq) - 1;
-            const int nt_c = qmax / kKvTile + 1;
-            ntiles = nt_c < ntiles ? nt_c : ntiles;
-        }
-        ntiles_w = ntiles;
-        if (CAUSAL) {
-            const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
-            ntiles_w = nt_w < ntiles ? nt_w : ntiles;
-        }
-        // hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops into a
-        // shape that needs ~30 more VGPRs than the causal kernel's
-        asm volatile("" : "+s"(ntiles_w));
-    };
+    // ---- KV sweep bounds
+    int ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
+    if (CAUSAL) {
+        const int qmax = (q0 + kRowsPerBlock < p.Nq ? q0 + kRowsPerBlock : p.Nq) - 1;
+        const int nt_c = qmax / kKvTile + 1;
+        ntiles = nt_c < ntiles ? nt_c : ntiles;
+    }
+    // causal: tiles this wave actually computes (the rest only stage + sync)
+    int ntiles_w = ntiles;
+    if (CAUSAL) {
+        const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
+        ntiles_w = nt_w < ntiles ? nt_w : ntiles;
+    }
+    // PRE: hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops into a
+    // shape that needs ~30 more VGPRs than the causal kernel's
+    if constexpr (PRE) asm volatile("" : "+s"(ntiles_w));
 
     f32x16 acc[QB][DT];
     float m_run[QB], l_run[QB];  // running reference max (raw score units; PRE: log2 units) / row sum (this lane's kv half)
     float negm[QB][16];          // PRE: -m_run, 16 separately named copies that the allocator keeps as one MFMA C tuple
-    auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            m_run[qb] = PRE ? 0.f : -INFINITY;
-            if constexpr (PRE) {
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = PRE ? 0.f : -INFINITY;
+        if constexpr (PRE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; asm volatile("" : "+v"(negm[qb][r])); }
-            }
-            l_run[qb] = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; asm volatile("" : "+v"(negm[qb][r])); }
         }
-    };
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
+    }
     const float c = p.c;
 
     // Staging.  DMA form (head dims >= FA2_LDS_DMA_MIN_HD): buffer_load ... lds writes the tile image
@@ -386,20 +348,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         vd_off[i] = row * v_rowb + gv * 16 + vcol0 * 2;
     }
     u32x4 kreg[NPASS], vreg[VNPASS];
-    auto load_k = [&](decltype(krs) rs, int tile, int buf) __attribute__((always_inline)) {
+    auto load_k = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            if constexpr (kDma) dma16_to_lds(rs, smem + buf * TILEB + (wave * 64 + kThreads * i) * 16, kd_off[i], soff);
-            else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, kg_off[i], soff, 0);
+            if constexpr (kDma) dma16_to_lds(krs, smem + buf * TILEB + (wave * 64 + kThreads * i) * 16, kd_off[i], soff);
+            else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
         }
     };
-    auto load_v = [&](decltype(vrs) rs, int tile, int buf) __attribute__((always_inline)) {
+    auto load_v = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
         for (int i = 0; i < VNPASS; ++i) {
-            if constexpr (kDma) dma16_to_lds(rs, smem + VBASE + buf * VTILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
-            else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vg_off[i], soff, 0);
+            if constexpr (kDma) dma16_to_lds(vrs, smem + VBASE + buf * VTILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
+            else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
         }
     };
     auto write_k = [&](int buf) __attribute__((always_inline)) {
@@ -464,17 +426,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 const bool need_tail = kv0 + kKvTile > p.Nkv;
                 if (need_causal || need_tail) {
                     const int lim_c = CAUSAL ? qrow[qb] : 0x7fffffff;  // kv index must be <= lim_c
-                    int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
-                    // opaque: without this the non-causal build hoists all 32 lane masks of the (tile-independent)
-                    // tail comparison to kernel entry and spills the 64 SGPRs that hold them
-                    asm volatile("" : "+v"(lim));
-                    // (opaque too: the per-register kv indices are lane constants that LICM would otherwise hoist out
-                    //  of the item loop and keep in 32 VGPRs through the steady-state loop)
-                    int kvb = kv0 + 4 * hi;
-                    asm volatile("" : "+v"(kvb));
+                    const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kvi = kvb + (r & 3) + 8 * (r >> 2);
+                        const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         if (kvi > lim) s0[r] = -INFINITY;
                         if (kvi + 32 > lim) s1[r] = -INFINITY;
                     }
@@ -596,12 +551,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // block the scheduler can interleave; the only branch is the rare rescale at the end.  MODE 0 = generic
     // (masked tiles, pipeline tail, waves above the causal diagonal that only stage and sync).  A masked
     // steady-state variant for the diagonal tiles measured +0 % (and cost 23 VGPRs), so it is not kept.
-    // Seam prefetch: when the item has an even number (>= 2) of KV tiles, its last two steps have free staging slots
-    // of exactly the parity the NEXT item's prologue needs (K0 -> K buffer 0, K1 -> K buffer 1, V0 -> V buffer 0),
-    // and the Q fragment registers are dead after the last QK^T: the next item's tiles and Q are fetched there,
-    // under this item's last MFMAs, instead of in an exposed prologue.
-    bool seam = false;
-    int nb = 0, nh = 0, nq0 = 0;      // next item (valid when seam)
     auto step = [&](int tile, auto par, auto mode, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
         constexpr int MODE = decltype(mode)::value;
@@ -611,120 +560,130 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #if FA2_IGLP >= 0
         if constexpr (FAST) __builtin_amdgcn_iglp_opt(FA2_IGLP);   // scheduler hint for the steady-state block
 #endif
-        if (more2) load_k(krs, tile + 2, PAR);            // global loads fly under the MFMA work below
-        else if (seam) load_k(nkrs, tile + 2 - ntiles, PAR);
-        if (more1) load_v(vrs, tile + 1, PAR ^ 1);
-        else if (seam) { load_v(nvrs, 0, PAR ^ 1); issue_q(nb, nh, nq0); }
+        if (more2 && !(FA2_ABL & 16)) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
+        if (more1 && !(FA2_ABL & 16)) load_v(tile + 1, PAR ^ 1);
         if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
             u32x4 pf[QB][4];
             exp_scores(sc, pf);
             pv(PAR, pf);
         }
-        if (more2 || seam) write_k(PAR);
-        if (more1 || seam) write_v(PAR ^ 1);
-        __syncthreads();
+        if (more2 && !(FA2_ABL & 16)) write_k(PAR);
+        if (more1 && !(FA2_ABL & 16)) write_v(PAR ^ 1);
+        if (!(FA2_ABL & 256)) __syncthreads();
         if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn);
     };
 
+#if FA2_PIPE == 1
+    // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
+    load_k(0, 0);
+    load_v(0, 0);
+    write_k(0);
+    write_v(0);
+    if (ntiles > 1) { load_k(1, 1); write_k(1); }
+    __syncthreads();
+    f32x16 sa[QB][2], sb[QB][2];
+    qk(0, sa);
+    __syncthreads();   // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us
+    finish_scores(0, std::true_type{}, sa, true);
+
+    // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
+    int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
+    {
+        const int unmasked_kv = p.Nkv / kKvTile;                           // tiles fully inside Nkv
+        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;  // tiles fully below the diagonal
+        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
+        n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
+        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
+    }
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
     constexpr std::integral_constant<int, 0> GENERIC{};
     constexpr std::integral_constant<int, 1> STEADY{};
-    {
-        int bh, qblk, H;
-        decode(blockIdx.x, bh, qblk, H);
-        set_item(bh / H, bh % H, qblk * kRowsPerBlock);
-        issue_q(b, h, q0);
+    int tile = 0;
+    for (; tile < n_fast; tile += 2) {
+        step(tile, P0, STEADY, sa, sb);
+        step(tile + 1, P1, STEADY, sb, sa);
     }
-    bool staged = false;     // the current item's K0, V0, K1 are already in LDS (fetched across the seam)
-    for (int round = 1;; ++round) {
-        fix_q();
-        reset_state();
-        if (!staged) {
-            // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1
-            load_k(krs, 0, 0);
-            load_v(vrs, 0, 0);
-            write_k(0);
-            write_v(0);
-            if (ntiles > 1) { load_k(krs, 1, 1); write_k(1); }
-            __syncthreads();
-        }
-        f32x16 sa[QB][2], sb[QB][2];
-        qk(0, sa);
-        // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us.  A bare
-        // s_barrier: the reads were consumed by the MFMAs above, and nothing needs to become visible — a
-        // __syncthreads() here would also wait for the previous item's O stores.
-        __builtin_amdgcn_s_barrier();
-        finish_scores(0, std::true_type{}, sa, true);
+    for (; tile + 1 < ntiles; tile += 2) {
+        step(tile, P0, GENERIC, sa, sb);
+        step(tile + 1, P1, GENERIC, sb, sa);
+    }
+    if (tile < ntiles) step(tile, P0, GENERIC, sa, sb);
 
-        // next item of this workgroup (snake order), decided before the tail so the seam can prefetch it
-        const int nidx = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
-        bool have_next = false;
-        if constexpr (kPersistent) { const kernarg_ptr a = args(); have_next = nidx < a->B * a->H * a->nqblk; }
-        seam = false;
-        if (have_next) {
-            int bh, qblk, H;
-            decode(nidx, bh, qblk, H);
-            nb = bh / H; nh = bh % H; nq0 = qblk * kRowsPerBlock;
-            seam = FA2_SEAM && ntiles >= 2 && !(ntiles & 1);
-            if (seam) { nkrs = k_desc(nb, nh); nvrs = v_desc(nb, nh); }
+#else
+    // Plain order: tile's K and V both live in buffer PAR; next tile is staged into PAR^1.
+    auto step_plain = [&](int tile, auto par, auto fast, f32x16 (&sc)[QB][2]) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FAST = decltype(fast)::value;
+        const bool more1 = FAST || tile + 1 < ntiles;
+        const bool cur_w = FAST || tile < ntiles_w;
+        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
+        if (cur_w) {
+            qk(PAR, sc);
+            finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc, tile == 0);
+            u32x4 pf[QB][4];
+            exp_scores(sc, pf);
+            pv(PAR, pf);
         }
+        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
+        if (!(FA2_ABL & 256)) __syncthreads();
+    };
+    load_k(0, 0);
+    load_v(0, 0);
+    write_k(0);
+    write_v(0);
+    __syncthreads();
+    f32x16 sa[QB][2];
+    int n_fast = ntiles - 1 < ntiles_w ? ntiles - 1 : ntiles_w;
+    {
+        const int unmasked_kv = p.Nkv / kKvTile;
+        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;
+        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
+        n_fast = n_fast < unmasked ? n_fast : unmasked;
+        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
+    }
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int tile = 0;
+    for (; tile < n_fast; tile += 2) {
+        step_plain(tile, P0, std::true_type{}, sa);
+        step_plain(tile + 1, P1, std::true_type{}, sa);
+    }
+    for (; tile + 1 < ntiles; tile += 2) {
+        step_plain(tile, P0, std::false_type{}, sa);
+        step_plain(tile + 1, P1, std::false_type{}, sa);
+    }
+    if (tile < ntiles) step_plain(tile, P0, std::false_type{}, sa);
+#endif
 
-        // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
-        int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
-        {
-            const int unmasked_kv = p.Nkv / kKvTile;                           // tiles fully inside Nkv
-            const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;  // tiles fully below the diagonal
-            const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
-            n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
-            n_fast = n_fast < 0 ? 0 : n_fast & ~1;
-        }
-        int tile = 0;
-        for (; tile < n_fast; tile += 2) {
-            step(tile, P0, STEADY, sa, sb);
-            step(tile + 1, P1, STEADY, sb, sa);
-        }
-        for (; tile + 1 < ntiles; tile += 2) {
-            step(tile, P0, GENERIC, sa, sb);
-            step(tile + 1, P1, GENERIC, sb, sa);
-        }
-        if (tile < ntiles) step(tile, P0, GENERIC, sa, sb);
-
-        // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
-        const kernarg_ptr pe = args();
+    // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            const float l_tot = half_swap_sum(l_run[qb]);
-            const float inv_l = 1.0f / l_tot;
-            if (qrow[qb] < pe->Nq) {
-                uint16_t* op = (uint16_t*)pe->o + b * pe->os[0] + h * pe->os[1] + (int64_t)qrow[qb] * pe->os[2] + vcol0;
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = half_swap_sum(l_run[qb]);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow[qb] < p.Nq) {
+            uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow[qb] * p.os[2] + vcol0;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4 += 2) {
-                        const f32x16& a = acc[qb][dt];
-                        // lane holds d = 32dt + 8*r4 + 4*hi + {0..3} (group r4) and the same for r4+1
-                        uint32_t a0 = pack2<BF16>(a[4 * r4 + 0] * inv_l, a[4 * r4 + 1] * inv_l);
-                        uint32_t a1 = pack2<BF16>(a[4 * r4 + 2] * inv_l, a[4 * r4 + 3] * inv_l);
-                        uint32_t b0 = pack2<BF16>(a[4 * r4 + 4] * inv_l, a[4 * r4 + 5] * inv_l);
-                        uint32_t b1 = pack2<BF16>(a[4 * r4 + 6] * inv_l, a[4 * r4 + 7] * inv_l);
-                        // half exchange: lower lanes end with 8 consecutive d of group r4, upper of r4+1
-                        auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                        auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                        const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
-                        *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
-                    }
+                for (int r4 = 0; r4 < 4; r4 += 2) {
+                    const f32x16& a = acc[qb][dt];
+                    // lane holds d = 32dt + 8*r4 + 4*hi + {0..3} (group r4) and the same for r4+1
+                    uint32_t a0 = pack2<BF16>(a[4 * r4 + 0] * inv_l, a[4 * r4 + 1] * inv_l);
+                    uint32_t a1 = pack2<BF16>(a[4 * r4 + 2] * inv_l, a[4 * r4 + 3] * inv_l);
+                    uint32_t b0 = pack2<BF16>(a[4 * r4 + 4] * inv_l, a[4 * r4 + 5] * inv_l);
+                    uint32_t b1 = pack2<BF16>(a[4 * r4 + 6] * inv_l, a[4 * r4 + 7] * inv_l);
+                    // half exchange: lower lanes end with 8 consecutive d of group r4, upper of r4+1
+                    auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
+                    *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
                 }
-                if (hi == 0 && vcol0 == 0)
-                    pe->lse[b * pe->ls[0] + h * pe->ls[1] + qrow[qb]] = (PRE ? m_run[qb] : m_run[qb] * c) + __builtin_amdgcn_logf(l_tot);
             }
+            if (hi == 0 && vcol0 == 0)
+                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = (PRE ? m_run[qb] : m_run[qb] * c) + __builtin_amdgcn_logf(l_tot);
         }
-
-        if (!have_next) break;
-        staged = seam;
-        set_item(nb, nh, nq0);
-        if (!seam) issue_q(b, h, q0);
     }
 }
 

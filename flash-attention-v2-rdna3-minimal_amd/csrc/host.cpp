@@ -33,23 +33,6 @@ constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 constexpr int kNW = FA2_NW, kQB = FA2_QB;
 constexpr int kFwdRows = kNW * kQB * 32;   // Q rows per forward workgroup
 
-#ifndef FA2_PERSISTENT
-#define FA2_PERSISTENT 1
-#endif
-
-// workgroups of a persistent launch: the CU count of the current device rounded down to a multiple of 8
-int persistent_slots() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cached[dev]) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-        cached[dev] = cus & ~7;
-    }
-    return cached[dev];
-}
-
 template <typename K>
 int set_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -64,11 +47,7 @@ template <int HD, bool BF16, bool CAUSAL, bool PRE>
 int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
     constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
-    // Persistent workgroups: one per CU walks the (head, q block) items when there are more items than CUs
-    // (grid a multiple of 8 so a workgroup's items stay on one XCD's residue class of heads).
-    const int64_t items = (int64_t)p.B * p.H * p.nqblk;
-    const int64_t slots = persistent_slots();
-    const dim3 grid((unsigned)(FA2_PERSISTENT && HD <= 128 && items > slots ? slots : items), HD / HDV);
+    const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
     auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB, PRE>;
     if (int rc = set_lds(kern, lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(kNW * 64), lds, stream, p);

@@ -304,8 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
         ntiles_w = nt_w < ntiles ? nt_w : ntiles;
     }
-    // PRE: hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops into a
-    // shape that needs ~30 more VGPRs than the causal kernel's
+    // hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops
     if constexpr (PRE) asm volatile("" : "+s"(ntiles_w));
 
     f32x16 acc[QB][DT];
@@ -426,10 +425,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 const bool need_tail = kv0 + kKvTile > p.Nkv;
                 if (need_causal || need_tail) {
                     const int lim_c = CAUSAL ? qrow[qb] : 0x7fffffff;  // kv index must be <= lim_c
-                    const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+                    int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+                    int kvb = kv0 + 4 * hi;
+                    // opaque (D = 64, 256; measured neutral-to-negative at D = 128): the tail comparison of the non-causal
+                    // build does not depend on the tile, so LICM hoists all 32 lane masks (64 SGPRs) or the 32
+                    // per-register kv indices (32 VGPRs) to kernel entry — D = 256: 24 -> 3 spilled VGPRs, +2..+9 %
+                    if constexpr (HD != 128) asm volatile("" : "+v"(lim), "+v"(kvb));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int kvi = HD != 128 ? kvb + (r & 3) + 8 * (r >> 2) : kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         if (kvi > lim) s0[r] = -INFINITY;
                         if (kvi + 32 > lim) s1[r] = -INFINITY;
                     }

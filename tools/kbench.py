@@ -27,6 +27,9 @@ CFGS = {
     "c4": (1, 32, 8192, 128, "f16", True),
     "b8": (8, 16, 4096, 128, "f16", False),
     "d64": (2, 16, 4096, 64, "f16", False),
+    "d64c": (2, 16, 4096, 64, "bf16", True),
+    "d256": (2, 16, 2048, 256, "f16", False),
+    "d256c": (2, 16, 2048, 256, "bf16", True),
     "n2k": (4, 16, 2048, 128, "f16", False),
     "n1k": (8, 16, 1024, 128, "f16", False),
     "n512": (16, 16, 512, 128, "f16", False),

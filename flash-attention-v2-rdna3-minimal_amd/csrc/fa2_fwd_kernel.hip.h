@@ -49,36 +49,6 @@
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
 #endif
-#ifndef FA2_TRACE
-#define FA2_TRACE 0
-#endif
-#ifndef FA2_HANDSCHED
-#define FA2_HANDSCHED 0
-#endif
-#ifndef FA2_HS_DMA0
-#define FA2_HS_DMA0 1
-#endif
-#ifndef FA2_HS_DMAS
-#define FA2_HS_DMAS 4
-#endif
-#ifndef FA2_HS_FINISH_AFTER
-#define FA2_HS_FINISH_AFTER 0
-#endif
-#ifndef FA2_HS_PRIO
-#define FA2_HS_PRIO 0
-#endif
-#ifndef FA2_HS_ABL
-#define FA2_HS_ABL 0
-#endif
-#ifndef FA2_HS_DMA1
-#define FA2_HS_DMA1 1
-#endif
-#ifndef FA2_HS_KPF
-#define FA2_HS_KPF 3
-#endif
-#ifndef FA2_HS_VPF
-#define FA2_HS_VPF 3
-#endif
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
@@ -165,15 +135,6 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-#if FA2_TRACE
-// developer tracing: s_memtime stamps of one workgroup's waves around the hand-placed step (tools/trace_step.py)
-__device__ long long g_fa2_trace[8 * 64 * 16];
-#define FA2_STAMP(k) do { if (blockIdx.x == 0 && (tile >> 1) == 10 && lane == 0) \
-    g_fa2_trace[(wave * 2 + (tile & 1)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FA2_STAMP(k) do { } while (0)
-#endif
 
 // 16 bytes per lane, global (buffer descriptor, zero for out-of-range) -> LDS at wave-uniform `lds_dst` + lane*16
 template <typename RSRC>
@@ -585,295 +546,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         }
     };
 
-    // Two-role hand-placed step (FA2_HANDSCHED=2).  The two waves of a SIMD (wave w and w + NW/2) run the step's
-    // independent halves in opposite order so that one is MFMA-only while the other carries the softmax VALU work:
-    //   role 0:  QK^T(t+1) [MFMA + K reads]           ->  softmax(t) || P.V(t) || row-max(t+1) -> rescale check -> barrier
-    //   role 1:  row-max(t) -> rescale check -> softmax(t) || P.V(t)   ->  QK^T(t+1) [MFMA + K reads]       -> barrier
-    // Role 1 therefore enters a step with UN-finished scores and leaves un-finished scores behind; the rescale
-    // check is idempotent (a tile that already moved the reference passes it), so entering the loop needs nothing
-    // and leaving it takes one finish_scores call.
-    auto step_role = [&](int tile, auto par, auto role_t, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        constexpr int ROLE = decltype(role_t)::value;
-        constexpr int NQK = 2 * KS_QK, NPV = 4 * DT;
-        constexpr int KPF = FA2_HS_KPF, VPF = FA2_HS_VPF;
-        const char* kt = smem + (PAR ^ 1) * TILEB;                 // K(tile+1)
-        const char* vt = smem + VBASE + PAR * VTILEB;              // V(tile)
-        const uint32_t k_soff = (uint32_t)(tile + 2) * kKvTile * k_rowb, v_soff = (uint32_t)(tile + 1) * kKvTile * v_rowb;
-        auto dma_piece = [&](int n) __attribute__((always_inline)) {
-            if (FA2_HS_ABL & 1) return;
-            if (n < NPASS) dma16_to_lds(krs, smem + PAR * TILEB + (wave * 64 + kThreads * n) * 16, kd_off[n], k_soff);
-            else dma16_to_lds(vrs, smem + VBASE + (PAR ^ 1) * VTILEB + (wave * 64 + kThreads * (n - NPASS)) * 16, vd_off[n - NPASS], v_soff);
-        };
-        constexpr int NDMA = NPASS + VNPASS;
-        u32x4 kfr[NQK], vfr[NPV], pf[4];
-        f32x16& c0 = sc[0][0];
-        f32x16& c1 = sc[0][1];
-        f32x16& n0 = sn[0][0];
-        f32x16& n1 = sn[0][1];
-        float rs0 = 0.f, rs1 = 0.f;
-        auto k_read = [&](int i) __attribute__((always_inline)) {
-            kfr[i] = *(const u32x4*)(kt + kr_off[i >> 1] + (i & 1) * 32 * ROWB);
-        };
-        auto v_read = [&](int j) __attribute__((always_inline)) {
-            const char* va = vt + vr_off[j % DT] + 16 * (j / DT) * VROWB;
-            const u32x2 lo2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
-            const u32x2 hi2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB)));
-            vfr[j] = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
-        };
-        auto rescale_check = [&](float mx) __attribute__((always_inline)) {
-            const float mxw = half_swap_max(mx);
-            if (__builtin_amdgcn_ballot_w64((mxw - m_run[0]) * c > FA2_DEFER_THR) != 0) {
-                const float m_new = __builtin_fmaxf(m_run[0], mxw);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[0] - m_new) * c);
-                m_run[0] = m_new;
-                l_run[0] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][dt][r] *= alpha;
-            }
-        };
-        float mc = m_run[0] * c;
-        auto sm_elem = [&](int e) __attribute__((always_inline)) {     // one element of P(t) = 2^(S c - m c), row sum, packing
-            f32x16& sh = (e >> 4) ? c1 : c0;
-            const int r = e & 15;
-            if (!(FA2_HS_ABL & 2)) sh[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sh[r], c, -mc));
-            if (e & 1) {
-                if (!(FA2_HS_ABL & 2)) rs1 += sh[r];
-                pf[e >> 3][(e & 7) >> 1] = (FA2_HS_ABL & 2) ? __float_as_uint(sh[r]) : pack2<BF16>(sh[r - 1], sh[r]);
-            } else if (!(FA2_HS_ABL & 2)) rs0 += sh[r];
-        };
-        auto qk_slot = [&](int i) __attribute__((always_inline)) {
-            if (i + KPF < NQK) k_read(i + KPF);
-            if (i & 1) n1 = mfma16<BF16>(kfr[i], qf[0][i >> 1], n1);
-            else n0 = mfma16<BF16>(kfr[i], qf[0][i >> 1], n0);
-        };
-        auto pv_slot = [&](int j) __attribute__((always_inline)) {
-            if (j + VPF < NPV && !((FA2_HS_ABL & 4) && j + VPF >= VPF + 1)) v_read(j + VPF);
-            if ((FA2_HS_ABL & 4) && j > VPF) vfr[j] = vfr[j % (VPF + 1)];
-            acc[0][j % DT] = mfma16<BF16>(vfr[j], pf[j / DT], acc[0][j % DT]);
-        };
-        // softmax elements that must be done before P.V slot j: pf[ks] feeds slots [ks*DT, (ks+1)*DT)
-        constexpr int SM_SLOTS = 3 * DT;          // elements 8..31 are spread over P.V slots [0, 3*DT)
-
-        FA2_STAMP(0);
-        if constexpr (ROLE == 0) {
-#if FA2_HS_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-            for (int i = 0; i < KPF; ++i) k_read(i);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
-#pragma unroll
-            for (int i = 0; i < NQK; ++i) {
-#pragma unroll
-                for (int n = 0; n < NDMA; ++n)
-                    if (i == FA2_HS_DMA0 + n * FA2_HS_DMAS) dma_piece(n);
-                if (i + VPF >= NQK) v_read(i + VPF - NQK);            // first V fragments
-                qk_slot(i);
-                if (i >= NQK - 8) sm_elem(i - (NQK - 8));              // pf[0]'s eight elements ride the last QK^T slots
-                __builtin_amdgcn_sched_barrier(0);
-                if ((i & 3) == 3) { FA2_STAMP(1 + (i >> 2)); __builtin_amdgcn_sched_barrier(0); }
-            }
-            float mx = -INFINITY;
-#if FA2_HS_PRIO
-            __builtin_amdgcn_s_setprio(FA2_HS_PRIO);      // the softmax-carrying half outranks the partner's bare MFMAs
-#endif
-#pragma unroll
-            for (int j = 0; j < NPV; ++j) {
-                pv_slot(j);
-#pragma unroll
-                for (int e = 8; e < 32; ++e)
-                    if ((e - 8) * SM_SLOTS / 24 == j) sm_elem(e);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r * NPV / 16 == j) mx = max3(mx, n0[r], n1[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((j & 3) == 3) { FA2_STAMP(5 + (j >> 2)); __builtin_amdgcn_sched_barrier(0); }
-            }
-            l_run[0] += rs0 + rs1;
-            rescale_check(mx);
-            FA2_STAMP(12);
-        } else {
-            // V fragments first (their latency hides under the row-max chain), then the max of the tile's raw scores
-#if FA2_HS_PRIO
-            __builtin_amdgcn_s_setprio(FA2_HS_PRIO);
-#endif
-#pragma unroll
-            for (int j = 0; j < VPF; ++j) v_read(j);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                mx = max3(mx, c0[r], c1[r]);
-#if FA2_HS_DMA1 == 1
-                // staging pieces ride the VALU-only row-max chain (LDS-DMA issue is cheapest away from MFMAs and ds_reads)
-#pragma unroll
-                for (int n = 0; n < NDMA; ++n)
-                    if (r == 1 + 4 * n) { __builtin_amdgcn_sched_barrier(0); dma_piece(n); __builtin_amdgcn_sched_barrier(0); }
-#endif
-            }
-            rescale_check(mx);
-            mc = m_run[0] * c;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sm_elem(e);
-            __builtin_amdgcn_sched_barrier(0);
-            FA2_STAMP(12);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NPV; ++j) {
-#if FA2_HS_DMA1 == 0
-#pragma unroll
-                for (int n = 0; n < NDMA; ++n)
-                    if (j == FA2_HS_DMA0 + n * FA2_HS_DMAS) dma_piece(n);
-#endif
-                if (j + KPF >= NPV) k_read(j + KPF - NPV);            // first K fragments
-                pv_slot(j);
-#pragma unroll
-                for (int e = 8; e < 32; ++e)
-                    if ((e - 8) * SM_SLOTS / 24 == j) sm_elem(e);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((j & 3) == 3) { FA2_STAMP(1 + (j >> 2)); __builtin_amdgcn_sched_barrier(0); }
-            }
-            l_run[0] += rs0 + rs1;
-#if FA2_HS_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
-#pragma unroll
-            for (int i = 0; i < NQK; ++i) {
-                qk_slot(i);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((i & 3) == 3) { FA2_STAMP(5 + (i >> 2)); __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
-        FA2_STAMP(13);
-        __syncthreads();
-        FA2_STAMP(14);
-    };
-
-    // Hand-placed steady-state step (FA2_HANDSCHED=1, QB == 1): the same work as step(..., STEADY), written slot by
-    // slot — one MFMA, the LDS fragment reads of the MFMA a few slots ahead, and a fixed share of the softmax
-    // VALU work of the CURRENT tile (QK^T slots) or of the row-max of the NEXT tile (P.V slots) — with a
-    // sched_barrier between slots so hipcc keeps this order and only adds its wait counts and hazard nops.
-    auto step_hs = [&](int tile, auto par, f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2]) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        constexpr int NQK = 2 * KS_QK, NPV = 4 * DT, NS = NQK + NPV;
-        constexpr int KPF = FA2_HS_KPF, VPF = FA2_HS_VPF;          // fragment prefetch distance in slots
-        constexpr int SPREAD = NQK + 3 * DT;                       // softmax elements are spread over slots [0, SPREAD)
-        constexpr int MAX0 = NQK + 2;                              // row-max chain of the next tile starts here
-        const char* kt = smem + (PAR ^ 1) * TILEB;                 // K(tile+1)
-        const char* vt = smem + VBASE + PAR * VTILEB;              // V(tile)
-        FA2_STAMP(0);
-        // staging: one 1-KiB LDS-DMA piece per wave at a time, spread over the QK^T slots (all eight waves issuing
-        // their four pieces at the top of the step stalled the second wave of every SIMD for ~800 cycles)
-        const uint32_t k_soff = (uint32_t)(tile + 2) * kKvTile * k_rowb, v_soff = (uint32_t)(tile + 1) * kKvTile * v_rowb;
-        auto dma_piece = [&](int n) __attribute__((always_inline)) {
-            if (n < NPASS) dma16_to_lds(krs, smem + PAR * TILEB + (wave * 64 + kThreads * n) * 16, kd_off[n], k_soff);
-            else dma16_to_lds(vrs, smem + VBASE + (PAR ^ 1) * VTILEB + (wave * 64 + kThreads * (n - NPASS)) * 16, vd_off[n - NPASS], v_soff);
-        };
-        constexpr int NDMA = NPASS + VNPASS;
-        u32x4 kfr[NQK], vfr[NPV], pf[4];
-        f32x16& c0 = sc[0][0];
-        f32x16& c1 = sc[0][1];
-        f32x16& n0 = sn[0][0];
-        f32x16& n1 = sn[0][1];
-        const float mc = m_run[0] * c;
-        float rs0 = 0.f, rs1 = 0.f, mx = -INFINITY;
-        auto k_read = [&](int i) __attribute__((always_inline)) {
-            kfr[i] = *(const u32x4*)(kt + kr_off[i >> 1] + (i & 1) * 32 * ROWB);
-        };
-        auto v_read = [&](int j) __attribute__((always_inline)) {
-            const char* va = vt + vr_off[j % DT] + 16 * (j / DT) * VROWB;
-            const u32x2 lo2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
-            const u32x2 hi2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB)));
-            vfr[j] = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
-        };
-#pragma unroll
-        for (int i = 0; i < KPF; ++i) k_read(i);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            // staging piece n goes out at slot FA2_HS_DMA0 + n * FA2_HS_DMAS
-#pragma unroll
-            for (int n = 0; n < NDMA; ++n)
-                if (i == FA2_HS_DMA0 + n * FA2_HS_DMAS) dma_piece(n);
-            // fragment reads for a later slot
-            if (i + KPF < NQK) k_read(i + KPF);
-            if (i + VPF >= NQK && i + VPF < NS) v_read(i + VPF - NQK);
-            if (i < VPF && i + NQK < NQK + VPF && NQK < VPF) { }   // (VPF <= NQK always: nothing to pre-issue before slot 0)
-            // the slot's MFMA
-            if (i < NQK) {
-                if (i & 1) n1 = mfma16<BF16>(kfr[i], qf[0][i >> 1], n1);
-                else n0 = mfma16<BF16>(kfr[i], qf[0][i >> 1], n0);
-            } else {
-                const int j = i - NQK;
-                acc[0][j % DT] = mfma16<BF16>(vfr[j], pf[j / DT], acc[0][j % DT]);
-            }
-            // softmax of the current tile: elements e with e * SPREAD / 32 == i
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                if (e * SPREAD / 32 != i) continue;
-                f32x16& sh = (e >> 4) ? c1 : c0;
-                const int r = e & 15;
-                sh[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sh[r], c, -mc));
-                if (e & 1) {
-                    rs1 += sh[r];
-                    pf[e >> 3][(e & 7) >> 1] = pack2<BF16>(sh[r - 1], sh[r]);
-                } else rs0 += sh[r];
-            }
-            // row max of the next tile: 16 steps over slots [MAX0, NS)
-            if (i >= MAX0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (MAX0 + r * (NS - MAX0) / 16 == i) mx = max3(mx, n0[r], n1[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if ((i & 3) == 3) { FA2_STAMP(1 + (i >> 2)); __builtin_amdgcn_sched_barrier(0); }
-        }
-        l_run[0] += rs0 + rs1;
-        FA2_STAMP(12);
-#if !FA2_HS_FINISH_AFTER
-        // rare: the reference max moves (same rule as finish_scores).  Done in front of the barrier: the waves of a
-        // workgroup reach it at different times, so this tail overlaps other waves' MFMAs instead of idling all of them.
-        {
-            const float mxw = half_swap_max(mx);
-            if (__builtin_amdgcn_ballot_w64((mxw - m_run[0]) * c > FA2_DEFER_THR) != 0) {
-                const float m_new = __builtin_fmaxf(m_run[0], mxw);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[0] - m_new) * c);
-                m_run[0] = m_new;
-                l_run[0] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][dt][r] *= alpha;
-            }
-        }
-        FA2_STAMP(13);
-        __syncthreads();
-#else
-        __syncthreads();
-        FA2_STAMP(13);
-        {
-            const float mxw = half_swap_max(mx);
-            if (__builtin_amdgcn_ballot_w64((mxw - m_run[0]) * c > FA2_DEFER_THR) != 0) {
-                const float m_new = __builtin_fmaxf(m_run[0], mxw);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[0] - m_new) * c);
-                m_run[0] = m_new;
-                l_run[0] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][dt][r] *= alpha;
-            }
-        }
-#endif
-        FA2_STAMP(14);
-    };
-
     // One pipeline step.  PAR = tile & 1 selects the LDS buffers statically:
     //   reads  K(tile+1) from K buf PAR^1, V(tile) from V buf PAR
     //   writes K(tile+2) to   K buf PAR,   V(tile+1) to V buf PAR^1
@@ -933,40 +605,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     constexpr std::integral_constant<int, 0> GENERIC{};
     constexpr std::integral_constant<int, 1> STEADY{};
     int tile = 0;
-#if FA2_HANDSCHED == 2
-    if constexpr (QB == 1 && !PRE && kDma) {
-        // one loop per role: the two instruction streams never merge inside the steady state
-        if (wave < NW / 2) {
-            for (; tile < n_fast; tile += 2) {
-                step_role(tile, P0, std::integral_constant<int, 0>{}, sa, sb);
-                step_role(tile + 1, P1, std::integral_constant<int, 0>{}, sb, sa);
-            }
-        } else {
-            for (; tile < n_fast; tile += 2) {
-                step_role(tile, P0, std::integral_constant<int, 1>{}, sa, sb);
-                step_role(tile + 1, P1, std::integral_constant<int, 1>{}, sb, sa);
-            }
-        }
-    } else
-#endif
     for (; tile < n_fast; tile += 2) {
-#if FA2_HANDSCHED == 1
-        if constexpr (QB == 1 && !PRE && kDma) {
-            step_hs(tile, P0, sa, sb);
-            step_hs(tile + 1, P1, sb, sa);
-        } else
-#endif
-        {
-            step(tile, P0, STEADY, sa, sb);
-            step(tile + 1, P1, STEADY, sb, sa);
-        }
+        step(tile, P0, STEADY, sa, sb);
+        step(tile + 1, P1, STEADY, sb, sa);
     }
-#if FA2_HANDSCHED == 2
-    if constexpr (QB == 1 && !PRE && kDma) {
-        // role-1 waves leave the loop with the next tile's scores un-finished (idempotent for role 0)
-        if (n_fast > 0) finish_scores(tile, std::false_type{}, sa);
-    }
-#endif
     for (; tile + 1 < ntiles; tile += 2) {
         step(tile, P0, GENERIC, sa, sb);
         step(tile + 1, P1, GENERIC, sb, sa);

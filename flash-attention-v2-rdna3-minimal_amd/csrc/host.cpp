@@ -149,12 +149,6 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-#if FA2_TRACE
-int fa2_debug_read_trace(long long* out, int n) {   // developer builds only (not in the public header)
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fa2::g_fa2_trace), sizeof(long long) * n);
-}
-#endif
-
 const char* fa2_version(void) { return "fa2_gfx950 0.3 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined)"; }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,

@@ -38,6 +38,7 @@ struct BwdParams {
     void* dk;
     void* dv;
     int B, H, Nq, Nkv;
+    int D;            // actual head dim (multiple of 8, <= the kernel's HD): columns >= D read as 0, are not stored
     int64_t qs[3], ks[3], vs[3], os[3], dos[3], dqs[3], dks[3], dvs[3];  // element strides: batch, head, row
     int64_t ls[2];                                                       // lse / delta strides: batch, head
     float scale, c;                                                      // scale, scale * log2(e)
@@ -103,7 +104,7 @@ struct BwdLane {
     uint32_t r_src[NPASS];       // DMA source byte offset (minus row pitch term) for a row-form image
     uint32_t t_src[NPASS];       // ... for a tr-form image
     int rowi[NPASS];             // tile row this lane's DMA piece belongs to
-    __device__ __forceinline__ void init(int tid, int lane) {
+    __device__ __forceinline__ void init(int tid, int lane, int D) {
         const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kr_off[ks] = G_::k_off(l31, 2 * ks + hi);
@@ -116,15 +117,17 @@ struct BwdLane {
             const int idx = tid + 512 * i;
             const int row = idx / G_::G, slot = idx % G_::G;
             rowi[i] = row;
-            r_src[i] = (slot ^ ((row / G_::RPB) & G_::KMASK)) * 16;
-            t_src[i] = (((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3)) * 16;
+            const int gr = slot ^ ((row / G_::RPB) & G_::KMASK);                                  // source granules
+            const int gt = ((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3);
+            r_src[i] = gr * 8 < D ? gr * 16 : kOobOffset;       // columns >= D: out of range for the descriptor -> zeros
+            t_src[i] = gt * 8 < D ? gt * 16 : kOobOffset;
         }
     }
 };
 
 // 16-bit store of an O^T-layout accumulator (lane = column n = lane & 31, rows d) to row-major [n][d] memory
 template <bool BF16, int DT>
-__device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* rowp, int hi, float mul) {
+__device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* rowp, int hi, float mul, int D) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -137,7 +140,7 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
             auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
             auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
-            *(u32x4*)(rowp + 32 * dt + 8 * (r4 + hi)) = w;
+            if (32 * dt + 8 * (r4 + hi) < D) *(u32x4*)(rowp + 32 * dt + 8 * (r4 + hi)) = w;
         }
     }
 }
@@ -168,13 +171,17 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     const int qr = qrow < p.Nq ? qrow : p.Nq - 1;
 
     L_ ln;
-    ln.init(tid, lane);
+    ln.init(tid, lane, p.D);
     u32x4 qf[KS], gf[KS];
     {
         const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
         const uint16_t* gp = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1] + (int64_t)qr * p.dos[2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi); gf[ks] = *(const u32x4*)(gp + 16 * ks + 8 * hi); }
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool in = 16 * ks + 8 * hi < p.D;
+            qf[ks] = in ? *(const u32x4*)(qp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
+            gf[ks] = in ? *(const u32x4*)(gp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
+        }
     }
     const float Lq = p.lse[b * p.ls[0] + h * p.ls[1] + qr];
     const float Dq = p.delta[b * p.ls[0] + h * p.ls[1] + qr];
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     }
     if (qrow < p.Nq) {
         uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, scale);
+        store_acc_t<BF16, DT>(acc, op, hi, scale, p.D);
     }
 }
 
@@ -322,15 +329,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     const int kr = kvrow < p.Nkv ? kvrow : p.Nkv - 1;
 
     L_ ln;
-    ln.init(tid, lane);
+    ln.init(tid, lane, p.D);
     u32x4 kf[KS], vf[WANT_DK ? KS : 1];
     {
         const uint16_t* kp = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1] + (int64_t)kr * p.ks[2];
         const uint16_t* vp = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1] + (int64_t)kr * p.vs[2];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *(const u32x4*)(kp + 16 * ks + 8 * hi);
-            if constexpr (WANT_DK) vf[ks] = *(const u32x4*)(vp + 16 * ks + 8 * hi);
+            const bool in = 16 * ks + 8 * hi < p.D;
+            kf[ks] = in ? *(const u32x4*)(kp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
+            if constexpr (WANT_DK) vf[ks] = in ? *(const u32x4*)(vp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
         }
     }
     const uint16_t* qbase = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1];
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     if (kvrow < p.Nkv) {
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
                                : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f);
+        store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f, p.D);
     }
 }
 

@@ -72,6 +72,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kQBlock = 256;      // rows per workgroup of the default kernel shapes (8 waves x 32 rows)
 constexpr int kKvTile = 64;       // KV rows per tile
+// Buffer-load byte offset that is out of range for every head matrix (host.cpp keeps them below 2 GiB, and the
+// per-tile scalar offset added to it stays below 2 GiB too): lanes that stage columns >= D use it and receive 0.
+constexpr uint32_t kOobOffset = 0x80000000u;
 
 struct FwdParams {
     const void* q;
@@ -80,6 +83,7 @@ struct FwdParams {
     void* o;
     float* lse;
     int B, H, Nq, Nkv;
+    int D;                               // actual head dim (multiple of 8, <= the kernel's HD): columns >= D read as 0, are not stored
     int64_t qs[3], ks[3], vs[3], os[3];  // element strides: batch, head, row
     int64_t ls[2];                       // lse strides: batch, head
     float c;                             // |scale| * log2(e)
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
         const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
 #pragma unroll
-        for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] = *(const u32x4*)(qp + 16 * ks + 8 * hi);
+        for (int ks = 0; ks < KS_QK; ++ks)     // head dims below HD: the missing columns are zeros (reference: host-side pad, kernel_fp16.cu:763-779)
+            qf[qb][ks] = (16 * ks + 8 * hi < p.D) ? *(const u32x4*)(qp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
         if (p.negate_q) {
             const uint32_t sgn = 0x80008000u;
 #pragma unroll
@@ -268,14 +273,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     for (int i = 0; i < NPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / G_::G, gi = idx % G_::G;
-        kg_off[i] = row * k_rowb + gi * 16;
+        kg_off[i] = gi * 8 < p.D ? row * k_rowb + gi * 16 : kOobOffset;
         kw_off[i] = G_::k_off(row, gi);
     }
 #pragma unroll
     for (int i = 0; i < VNPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / GV_::G, gi = idx % GV_::G;
-        vg_off[i] = row * v_rowb + gi * 16 + vcol0 * 2;
+        vg_off[i] = gi * 8 + vcol0 < p.D ? row * v_rowb + gi * 16 + vcol0 * 2 : kOobOffset;
         vw_off[i] = GV_::v_off(row, gi * 16);
     }
 
@@ -337,14 +342,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     for (int i = 0; i < NPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / G_::G, slot = idx % G_::G;
-        kd_off[i] = row * k_rowb + (slot ^ ((row / G_::RPB) & G_::KMASK)) * 16;
+        const int gk = slot ^ ((row / G_::RPB) & G_::KMASK);   // source granule of this image slot
+        kd_off[i] = gk * 8 < p.D ? row * k_rowb + gk * 16 : kOobOffset;
     }
 #pragma unroll
     for (int i = 0; i < VNPASS; ++i) {
         const int idx = tid + kThreads * i;
         const int row = idx / GV_::G, slot = idx % GV_::G;
         const int gv = ((((slot >> 2) ^ ((row / GV_::RPB) & GV_::VMASK))) << 2) | (slot & 3);
-        vd_off[i] = row * v_rowb + gv * 16 + vcol0 * 2;
+        vd_off[i] = gv * 8 + vcol0 < p.D ? row * v_rowb + gv * 16 + vcol0 * 2 : kOobOffset;
     }
     u32x4 kreg[NPASS], vreg[VNPASS];
     auto load_k = [&](int tile, int buf) __attribute__((always_inline)) {
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                     auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
-                    *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
+                    if (vcol0 + 32 * dt + 8 * (r4 + hi) < p.D) *(u32x4*)(op + 32 * dt + 8 * (r4 + hi)) = w;
                 }
             }
             if (hi == 0 && vcol0 == 0)

@@ -67,7 +67,7 @@ template <int HD, bool BF16, bool CAUSAL>
 int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     constexpr int TILEB = fa2::Geo<HD, 8>::TILEB;
     const int64_t rows = (int64_t)p.B * p.H * p.Nq;
-    hipLaunchKernelGGL((fa2::bwd_delta_kernel<BF16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p, HD);
+    hipLaunchKernelGGL((fa2::bwd_delta_kernel<BF16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p, p.D);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     {   // dQ: one workgroup per 256 Q rows
@@ -129,8 +129,9 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 }
 
 int fa2_fwd_prescales_q(int D, float scale) {
-    if (fa2_padded_head_dim(D) != D) return -1;
-    return kQB == 1 && D <= FA2_PRESCALE_MAX_HD && std::fabs(scale) * 1.4426950408889634f <= 1.0f;
+    const int HD = fa2_padded_head_dim(D);
+    if (HD < 0) return -1;
+    return kQB == 1 && HD <= FA2_PRESCALE_MAX_HD && std::fabs(scale) * 1.4426950408889634f <= 1.0f;
 }
 
 const char* fa2_error_string(int code) {
@@ -159,18 +160,19 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
         return FA2_ERR_NULL_POINTER;
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
-    if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
+    const int HD = fa2_padded_head_dim(D);       // kernel head dim; columns [D, HD) are masked in-kernel
+    if (HD < 0 || (D & 7)) return FA2_ERR_HEAD_DIM;
     if (!std::isfinite(scale)) return FA2_ERR_SCALE;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !strides_ok(q_strides) ||
         !strides_ok(k_strides) || !strides_ok(v_strides) || !strides_ok(o_strides))
         return FA2_ERR_ALIGNMENT;
     const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2;
     const int64_t v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
-    if (k_bytes > 0xffffffffLL || v_bytes > 0xffffffffLL) return FA2_ERR_BAD_SHAPE;
+    if (k_bytes > 0x7fffffffLL || v_bytes > 0x7fffffffLL) return FA2_ERR_BAD_SHAPE;   // (fa2::kOobOffset relies on < 2 GiB)
 
     fa2::FwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
-    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv; p.D = D;
     for (int i = 0; i < 3; ++i) {
         p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; p.os[i] = o_strides[i];
     }
@@ -184,7 +186,7 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
 
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool bf16 = dtype == FA2_DTYPE_BF16;
-    switch (D) {
+    switch (HD) {
         case 64: return bf16 ? launch<64, true>(p, causal != 0, stream) : launch<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch<128, true>(p, causal != 0, stream) : launch<128, false>(p, causal != 0, stream);
         case 256: return bf16 ? launch<256, true>(p, causal != 0, stream) : launch<256, false>(p, causal != 0, stream);
@@ -203,7 +205,8 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
         return FA2_ERR_NULL_POINTER;
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
-    if (D != 64 && D != 128) return FA2_ERR_HEAD_DIM;   // backward kernels: D <= 128
+    const int HD = fa2_padded_head_dim(D);              // columns [D, HD) are masked in-kernel
+    if (HD < 0 || HD > 128 || (D & 7)) return FA2_ERR_HEAD_DIM;   // backward kernels: D <= 128
     if (!std::isfinite(scale)) return FA2_ERR_SCALE;
     const void* ptrs[] = {q, k, v, o, dout, dq, dk, dv};
     const int64_t* strides[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
@@ -211,14 +214,14 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
         if (!aligned16(ptrs[i]) || !strides_ok(strides[i])) return FA2_ERR_ALIGNMENT;
     const int64_t q_bytes = ((int64_t)(Nq - 1) * q_strides[2] + D) * 2, do_bytes = ((int64_t)(Nq - 1) * do_strides[2] + D) * 2;
     const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2, v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
-    if (q_bytes > 0xffffffffLL || do_bytes > 0xffffffffLL || k_bytes > 0xffffffffLL || v_bytes > 0xffffffffLL)
+    if (q_bytes > 0x7fffffffLL || do_bytes > 0x7fffffffLL || k_bytes > 0x7fffffffLL || v_bytes > 0x7fffffffLL)
         return FA2_ERR_BAD_SHAPE;
     const int64_t blocks = (int64_t)B * H * (((Nq > Nkv ? Nq : Nkv) + fa2::kQBlock - 1) / fa2::kQBlock);
     if (blocks > 0x7fffffffLL || (int64_t)B * H * Nq / 16 > 0x7fffffffLL) return FA2_ERR_GRID;
 
     fa2::BwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = o; p.dout = dout; p.lse = lse; p.delta = delta_ws; p.dq = dq; p.dk = dk; p.dv = dv;
-    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nkv = Nkv; p.D = D;
     for (int i = 0; i < 3; ++i) {
         p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; p.os[i] = o_strides[i];
         p.dos[i] = do_strides[i]; p.dqs[i] = dq_strides[i]; p.dks[i] = dk_strides[i]; p.dvs[i] = dv_strides[i];
@@ -231,7 +234,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
     p.do_bytes = (uint32_t)do_bytes; p.l_bytes = (uint32_t)Nq * 4u;
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool bf16 = dtype == FA2_DTYPE_BF16;
-    switch (D) {
+    switch (HD) {
         case 64: return bf16 ? launch_bwd<64, true>(p, causal != 0, stream) : launch_bwd<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch_bwd<128, true>(p, causal != 0, stream) : launch_bwd<128, false>(p, causal != 0, stream);
         default: return FA2_ERR_HEAD_DIM;

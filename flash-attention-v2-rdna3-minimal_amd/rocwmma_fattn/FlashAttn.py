@@ -29,9 +29,12 @@ class _FlashAttnWmma:
 
     @staticmethod
     def forward(q, k, v, Br, Bc, causal, scale, permute_NH):
-        """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16
-        (kernel_fp16.cu:744-876).  Br/Bc only size the N padding of O and L exactly as the
-        reference does (kernel_fp16.cu:761, :793-796); the gfx950 kernel picks its own tiles."""
+        """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16 (kernel_fp16.cu:744-876).
+        Where the reference pads on the host — Q/O/L rows to a multiple of Br, D to a multiple of 32
+        (kernel_fp16.cu:761-779, :793-796) — the gfx950 kernels mask in-kernel (ragged Nq / Nkv, any D that is
+        a multiple of 8), so q_pad, k_pad, v_pad are the inputs themselves (made contiguous if their strides
+        require it) and O, L have the actual sizes; only a D that is not a multiple of 8 is zero-padded up to
+        one.  Br/Bc are accepted for signature compatibility; the kernels pick their own tiles."""
         lib = _fa2_lib.load()
         if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
             raise RuntimeError("fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)")
@@ -55,31 +58,21 @@ class _FlashAttnWmma:
         if k.size(0) != b or v.size(0) != b or k.size(h_ax) != h or v.size(h_ax) != h or \
                 k.size(3) != d or v.size(3) != d or v.size(n_ax) != n_kv:
             raise RuntimeError("fa2: inconsistent q/k/v shapes %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(v.shape)))
-        Br, Bc = int(Br), int(Bc)
-        d_kernel = lib.fa2_padded_head_dim(d)
-        if d_kernel < 0:
+        if lib.fa2_padded_head_dim(d) < 0:
             raise RuntimeError("fa2: head dim %d is larger than the largest gfx950 kernel" % d)
-        nq_pad = (Br - n % Br) % Br
-        d_pad = d_kernel - d
+        d_pad = -d % 8
+        d_kernel = d + d_pad                     # the head dim handed to the C-ABI (columns up to the kernel's are masked there)
 
-        # padding (kernel_fp16.cu:767-779): Q in N and D, K/V in D only
         q_pad, k_pad, v_pad = q, k, v
-        if nq_pad or d_pad:
-            pad = (0, d_pad, 0, 0, 0, nq_pad) if permute_NH else (0, d_pad, 0, nq_pad)
-            q_pad = torch.nn.functional.pad(q_pad, pad)
         if d_pad:
-            k_pad = torch.nn.functional.pad(k_pad, (0, d_pad))
-            v_pad = torch.nn.functional.pad(v_pad, (0, d_pad))
+            q_pad, k_pad, v_pad = (torch.nn.functional.pad(t, (0, d_pad)) for t in (q, k, v))
         q_pad, k_pad, v_pad = (_kernel_ready(t) for t in (q_pad, k_pad, v_pad))
 
-        # outputs (kernel_fp16.cu:793-796) — on q's device; only the N-padding tail is zero-filled
+        # outputs on q's device, laid out like q (kernel_fp16.cu:793-796)
         O = torch.empty_like(q_pad)
         if not _strides_ok(O):
             O = torch.empty(q_pad.shape, dtype=q_pad.dtype, device=q_pad.device)
-        L = torch.empty((b, h, n + nq_pad), dtype=torch.float32, device=q.device)
-        if nq_pad:
-            O.narrow(n_ax, n, nq_pad).zero_()
-            L[:, :, n:].zero_()
+        L = torch.empty((b, h, n), dtype=torch.float32, device=q.device)
 
         def s3(t):
             return _fa2_lib.strides3(t.stride(0), t.stride(h_ax), t.stride(n_ax))
@@ -95,19 +88,15 @@ class _FlashAttnWmma:
             rc = lib.fa2_fwd(*args)
         _fa2_lib.check(rc)
 
-        # O_fwd is a view into the padded O (kernel_fp16.cu:865-875)
-        if nq_pad or d_pad:
-            O_fwd = O[:, :n, :, :d] if permute_NH else O[:, :, :n, :d]
-        else:
-            O_fwd = O
+        O_fwd = O[..., :d] if d_pad else O       # a view into O (kernel_fp16.cu:865-875)
         return [O_fwd, q_pad, k_pad, v_pad, O, L]
 
     @staticmethod
     def backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH):
         """Returns [dQ, dK, dV] sliced to the actual sizes, like backward_fp16/backward_bf16
         (host.cpp:47-58, kernel_fp16.cu:878-1028).  Q, K, V, O, L are the tensors the forward returned
-        (D already padded to a kernel head dim, Q/O/L possibly padded in N); the gfx950 kernels take the
-        actual Nq / Nkv and mask in-kernel, so nothing is padded in N here."""
+        (D a multiple of 8); the gfx950 kernels take the actual Nq / Nkv / D and mask in-kernel, so nothing is
+        padded here except a dO whose D differs from Q's."""
         lib = _fa2_lib.load()
         if not (Q.is_cuda and dO.is_cuda):
             raise RuntimeError("fa2: tensors must be on a ROCm device (no CPU path in this operator)")

@@ -30,6 +30,9 @@
  *   ("permute_NH", kernel_fp16.cu:328-333) layout is the same call with the head and row strides
  *   of the [B,N,H,D] tensor: strides = {N*H*D, D, H*D}.
  *   All base pointers must be 16-byte aligned and every stride a multiple of 8 elements.
+ *   D is any multiple of 8 up to the largest kernel head dim (forward 256, backward 128): the call runs on the
+ *   kernel of fa2_padded_head_dim(D) and columns >= D are masked in-kernel — read as zero, never stored — where
+ *   the reference zero-pads D on the host (kernel_fp16.cu:763, :767-779).  One head's matrix must stay below 2 GiB.
  *
  * Numerics contract (reference: kernel_fp16.cu:434-490, :510-543)
  *   S = (Q K^T) * scale * log2(e)   (f32 accumulate on MFMA)
@@ -56,7 +59,7 @@ extern "C" {
 #define FA2_OK                 0
 #define FA2_ERR_NULL_POINTER  -1
 #define FA2_ERR_BAD_SHAPE     -2   /* B,H,Nq,Nkv,D < 1 */
-#define FA2_ERR_HEAD_DIM      -3   /* D not one of fa2_supported_head_dims() */
+#define FA2_ERR_HEAD_DIM      -3   /* D not a multiple of 8, or larger than the largest kernel head dim */
 #define FA2_ERR_ALIGNMENT     -4   /* pointer not 16-B aligned or stride not a multiple of 8 */
 #define FA2_ERR_DTYPE         -5
 #define FA2_ERR_SCALE         -6   /* scale is NaN/inf */
@@ -98,7 +101,7 @@ int fa2_fwd(int dtype,
  * Four launches on `hip_stream` (D, dQ, dV, dK); deterministic: every output element has one owner — the
  * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
  * Gradients are those of O = softmax(scale * Q K^T [+ causal mask]) V, i.e. what torch autograd returns.
- * Head dims: 64 and 128 (the forward additionally has a 256 kernel); other D return FA2_ERR_HEAD_DIM.
+ * Head dims: multiples of 8 up to 128 (the forward goes up to 256); other D return FA2_ERR_HEAD_DIM.
  */
 int fa2_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, float* delta_ws,
@@ -125,12 +128,12 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
             float scale, int causal, void* hip_stream);
 
-/* Head dims the kernels are instantiated for (ascending).  Writes up to `cap` entries into
- * `dims`, returns the total count.  A caller with another D zero-pads the last dimension up to the
- * next supported value — the reference pads D the same way (kernel_fp16.cu:763, :767-779). */
+/* Head dims the forward kernels are instantiated for (ascending).  Writes up to `cap` entries into `dims`, returns
+ * the total count.  Any D that is a multiple of 8 runs on the next of these with its tail columns masked; only a D
+ * that is not a multiple of 8 has to be zero-padded by the caller (to the next multiple of 8). */
 int fa2_supported_head_dims(int* dims, int cap);
 
-/* Smallest supported head dim >= D, or -1 if D is larger than the largest kernel. */
+/* Head dim of the kernel that serves D (the smallest instantiated one >= D), or -1 if D is larger than the largest. */
 int fa2_padded_head_dim(int D);
 
 /* Q rows per workgroup / KV rows per tile of the kernel chosen for head dim D (informational:

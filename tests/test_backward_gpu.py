@@ -96,6 +96,18 @@ def test_seeded_shapes_against_oracle(shape, dt, causal):
     _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
 
 
+@pytest.mark.parametrize("D", [8, 40, 80, 104, 120])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_backward_head_dims_masked_in_kernel(D, dt):
+    """Multiples of 8 up to 128 run on the 64 / 128 kernels with columns >= D masked (SD1.5: 40, 80), unpadded buffers."""
+    g = torch.Generator(device="cpu").manual_seed(200 + D)
+    mk = lambda n: torch.randn((2, 2, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(130), mk(203), mk(203), mk(130)
+    for causal in (False, True):
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+
+
 def test_autograd_through_the_operator_matches_torch():
     """FlashAttentionFunction.apply(...).backward(dO) — the reference's training call shape (bench_with_sdpa.py:89-96)."""
     g = torch.Generator(device="cpu").manual_seed(21)

@@ -69,8 +69,8 @@ def test_validation_codes_without_a_gpu():
     assert call(q=None) == c["FA2_ERR_NULL_POINTER"]
     assert call(dtype=7) == c["FA2_ERR_DTYPE"]
     assert call(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
-    assert call(D=40) == c["FA2_ERR_HEAD_DIM"]
-    assert call(D=4096) == c["FA2_ERR_HEAD_DIM"]
+    assert call(D=44) == c["FA2_ERR_HEAD_DIM"]          # head dims are masked in-kernel in steps of 8 columns
+    assert call(D=4096) == c["FA2_ERR_HEAD_DIM"] and call(D=264) == c["FA2_ERR_HEAD_DIM"]
     assert call(q=p + 2) == c["FA2_ERR_ALIGNMENT"]
     assert call(qs=_fa2_lib.strides3(2048, 1024, 68)) == c["FA2_ERR_ALIGNMENT"]
     assert call(scale=float("nan")) == c["FA2_ERR_SCALE"]
@@ -79,14 +79,14 @@ def test_validation_codes_without_a_gpu():
     with pytest.raises(RuntimeError, match="fa2 call failed"):
         _fa2_lib.check(c["FA2_ERR_HEAD_DIM"])
     assert lib.fa2_fwd_f16(None, p, p, p, p, 1, 1, 1, 1, 64, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_NULL_POINTER"]
-    assert lib.fa2_fwd_bf16(p, p, p, p, p, 1, 1, 1, 1, 48, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_HEAD_DIM"]
+    assert lib.fa2_fwd_bf16(p, p, p, p, p, 1, 1, 1, 1, 52, s3, s3, s3, s3, s2, 1.0, 0, None) == c["FA2_ERR_HEAD_DIM"]
     # backward: same validation, ten pointers and eight stride triples
     bwd = lambda **kw: lib.fa2_bwd(kw.get("dtype", 0), kw.get("q", p), p, p, p, p, p, p, p, p, kw.get("ws", p), 1, 2, 16,  # noqa: E731
                                    kw.get("Nkv", 16), kw.get("D", 64), s3, s3, s3, s3, kw.get("dos", s3), s3, s3, s3, s2,
                                    kw.get("scale", 0.125), 0, None)
     assert bwd(q=None) == c["FA2_ERR_NULL_POINTER"] and bwd(ws=None) == c["FA2_ERR_NULL_POINTER"]
     assert bwd(dtype=3) == c["FA2_ERR_DTYPE"] and bwd(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
-    assert bwd(D=96) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
+    assert bwd(D=136) == c["FA2_ERR_HEAD_DIM"] and bwd(D=100) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
     assert bwd(dos=_fa2_lib.strides3(2048, 1024, 66)) == c["FA2_ERR_ALIGNMENT"]
     assert lib.fa2_bwd_f16(p, p, p, p, p, p, p, p, p, None, 1, 1, 1, 1, 64, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
         == c["FA2_ERR_NULL_POINTER"]

@@ -33,10 +33,17 @@ constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 constexpr int kNW = FA2_NW, kQB = FA2_QB;
 constexpr int kFwdRows = kNW * kQB * 32;   // Q rows per forward workgroup
 
+// Kernels that need more than 64 KiB of dynamic LDS must be opted in once per (kernel, device).
 template <typename K>
 int set_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return 0;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    static bool done[64] = {false};          // one flag set per template instantiation (= per kernel)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && done[dev]) return 0;
+    const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == 0 && dev >= 0) done[dev] = true;
+    return rc;
 }
 
 #ifndef FA2_PRESCALE_MAX_HD          // head dims up to this run the pre-scaled-Q kernels (fa2_fwd_kernel.hip.h, "PRE")

@@ -53,12 +53,12 @@ class _FlashAttnWmma:
                 q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
 
         n_ax, h_ax = (1, 2) if permute_NH else (2, 1)
-        b, h, n, d = q.size(0), q.size(h_ax), q.size(n_ax), q.size(3)
-        n_kv = k.size(n_ax)
-        if k.size(0) != b or v.size(0) != b or k.size(h_ax) != h or v.size(h_ax) != h or \
-                k.size(3) != d or v.size(3) != d or v.size(n_ax) != n_kv:
+        qsh, ksh = q.shape, k.shape
+        b, h, n, d = qsh[0], qsh[h_ax], qsh[n_ax], qsh[3]
+        n_kv = ksh[n_ax]
+        if ksh[0] != b or ksh[h_ax] != h or ksh[3] != d or v.shape != ksh:
             raise RuntimeError("fa2: inconsistent q/k/v shapes %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(v.shape)))
-        if lib.fa2_padded_head_dim(d) < 0:
+        if d > _MAX_HEAD_DIM:
             raise RuntimeError("fa2: head dim %d is larger than the largest gfx950 kernel" % d)
         d_pad = -d % 8
         d_kernel = d + d_pad                     # the head dim handed to the C-ABI (columns up to the kernel's are masked there)
@@ -75,18 +75,20 @@ class _FlashAttnWmma:
         L = torch.empty((b, h, n), dtype=torch.float32, device=q.device)
 
         def s3(t):
-            return _fa2_lib.strides3(t.stride(0), t.stride(h_ax), t.stride(n_ax))
+            st = t.stride()
+            return _fa2_lib.strides3(st[0], st[h_ax], st[n_ax])
 
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        dev = q.device.index
         args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
                 b, h, n, n_kv, d_kernel, s3(q_pad), s3(k_pad), s3(v_pad), s3(O),
-                _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0, stream)
-        if q.device.index != torch.cuda.current_device():
-            with torch.cuda.device(q.device):
+                _fa2_lib.strides2(h * n, n), float(scale), 1 if causal else 0, _raw_stream(dev))
+        if dev != _current_device():
+            with torch.cuda.device(dev):
                 rc = lib.fa2_fwd(*args)
         else:
             rc = lib.fa2_fwd(*args)
-        _fa2_lib.check(rc)
+        if rc:
+            _fa2_lib.check(rc)
 
         O_fwd = O[..., :d] if d_pad else O       # a view into O (kernel_fp16.cu:865-875)
         return [O_fwd, q_pad, k_pad, v_pad, O, L]
@@ -117,27 +119,42 @@ class _FlashAttnWmma:
             L = L.contiguous()
 
         def s3(t):
-            return _fa2_lib.strides3(t.stride(0), t.stride(h_ax), t.stride(n_ax))
+            st = t.stride()
+            return _fa2_lib.strides3(st[0], st[h_ax], st[n_ax])
 
-        stream = torch.cuda.current_stream(Q.device).cuda_stream
+        stream = _raw_stream(Q.device.index)
         args = (dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr(),
                 dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), delta.data_ptr(), b, h, act_n, act_nkv, dk,
                 s3(Q), s3(K), s3(V), s3(O), s3(dO), s3(dQ), s3(dK), s3(dV),
                 _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0, stream)
-        if Q.device.index != torch.cuda.current_device():
+        if Q.device.index != _current_device():
             with torch.cuda.device(Q.device):
                 rc = lib.fa2_bwd(*args)
         else:
             rc = lib.fa2_bwd(*args)
-        _fa2_lib.check(rc)
+        if rc:
+            _fa2_lib.check(rc)
         if permute_NH:
             return [dQ[:, :act_n, :, :act_d], dK[:, :act_nkv, :, :act_d], dV[:, :act_nkv, :, :act_d]]
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
 
 
+_MAX_HEAD_DIM = 256      # largest forward kernel head dim (fa2_supported_head_dims)
+
+
+def _raw_stream(device_index):
+    """hipStream_t of torch's current stream on that device, as an integer (the cheap form of
+    torch.cuda.current_stream(dev).cuda_stream: this is on the path of every call)."""
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
+def _current_device():
+    return torch._C._cuda_getDevice()
+
+
 def _strides_ok(t):
-    return t.stride(3) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.stride(2) % 8 == 0 \
-        and t.data_ptr() % 16 == 0
+    s0, s1, s2, s3 = t.stride()
+    return s3 == 1 and not ((s0 | s1 | s2) & 7) and not (t.data_ptr() & 15)
 
 
 def _kernel_ready(t):

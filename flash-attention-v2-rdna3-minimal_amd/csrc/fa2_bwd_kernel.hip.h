@@ -46,9 +46,22 @@ struct BwdParams {
     uint32_t q_bytes, k_bytes, v_bytes, do_bytes, l_bytes;               // addressable bytes of one head's matrices
 };
 
+// The backward kernels address LDS through address-space-3 pointers only (no generic pointers into LDS): besides
+// sparing the aperture checks, this avoids a hipcc 7.2 miscompile of the generic<->LDS casts in the 4-wave kernels
+// ("Illegal instruction detected: Operand has incorrect register class", a V_CMP against src_shared_base).
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+typedef __attribute__((address_space(3))) const u32x4* lds_u32x4_cptr;
+__device__ __forceinline__ u32x4 lds_load128(lds_char_ptr p) { return *(lds_u32x4_cptr)p; }
+template <typename RSRC>
+__device__ __forceinline__ void dma16_to_lds3(RSRC rsrc, lds_char_ptr lds_dst, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
+
 // 4 bytes per lane, global -> LDS at wave-uniform `lds_dst` + lane*4 (zero for out-of-range)
 template <typename RSRC>
-__device__ __forceinline__ void dma4_to_lds(RSRC rsrc, char* lds_dst, uint32_t voff, uint32_t soff) {
+__device__ __forceinline__ void dma4_to_lds(RSRC rsrc, lds_char_ptr lds_dst, uint32_t voff, uint32_t soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, voff, soff, 0, 0);
 #endif
@@ -95,9 +108,9 @@ __global__ __launch_bounds__(256) void bwd_delta_kernel(const BwdParams p, int D
 
 // ---------------------------------------------------------------------------------------------------------
 // Shared per-lane LDS offsets and DMA source permutations (see the forward kernel for the image layouts).
-template <int HD>
+template <int HD, int NW = 8>
 struct BwdLane {
-    using G_ = Geo<HD, 8>;
+    using G_ = Geo<HD, NW>;
     static constexpr int NPASS = G_::NPASS, KS = G_::KS_QK, DT = G_::DT, ROWB = G_::ROWB, TILEB = G_::TILEB;
     int kr_off[KS];              // row-form A fragment: row lane&31 of a 32-row half tile, k-step ks
     int vr_off[DT];              // tr-form A fragment base for d block dt
@@ -114,7 +127,7 @@ struct BwdLane {
             vr_off[dt] = G_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + NW * 64 * i;
             const int row = idx / G_::G, slot = idx % G_::G;
             rowi[i] = row;
             const int gr = slot ^ ((row / G_::RPB) & G_::KMASK);                                  // source granules
@@ -148,12 +161,18 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // ---------------------------------------------------------------------------------------------------------
 // dQ: workgroup = 256 Q rows (8 waves x 32), sweep over KV tiles of 64.
 // LDS per stage: K row-form | V row-form | K tr-form; two stages.
-template <int HD, bool BF16, bool CAUSAL>
-__global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
-    using L_ = BwdLane<HD>;
+// NW = 8: two waves per SIMD, 256 VGPRs, two LDS stages (D <= 128).  NW = 4 (D = 256): one wave per SIMD with the
+// 512-register budget, 128 rows per workgroup, ONE LDS stage (three 32-KiB images do not fit twice) — a correct, simple
+// path for the rare large head dim (SD1.5's D = 160), not a tuned one.
+template <int HD, bool BF16, bool CAUSAL, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams p) {
+    using L_ = BwdLane<HD, NW>;
+    constexpr int kRows = NW * 32;            // rows per workgroup (p.nblk = ceil(N / kRows))
+    constexpr bool DBUF = NW == 8;
     constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
     constexpr int STAGEB = 3 * TILEB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    const lds_char_ptr smem = (lds_char_ptr)smem_generic;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     } else if (CAUSAL) { bh = bid % nbh; qblk = p.nblk - 1 - bid / nbh; }
     else { bh = bid / p.nblk; qblk = bid % p.nblk; }
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = qblk * kQBlock, qw0 = q0 + 32 * wave, qrow = qw0 + l31;
+    const int q0 = qblk * kRows, qw0 = q0 + 32 * wave, qrow = qw0 + l31;
     const int qr = qrow < p.Nq ? qrow : p.Nq - 1;
 
     L_ ln;
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
 
     int ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
     if (CAUSAL) {
-        const int qmax = (q0 + kQBlock < p.Nq ? q0 + kQBlock : p.Nq) - 1;
+        const int qmax = (q0 + kRows < p.Nq ? q0 + kRows : p.Nq) - 1;
         const int nt_c = qmax / kKvTile + 1;
         ntiles = nt_c < ntiles ? nt_c : ntiles;
     }
@@ -203,15 +222,15 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     asm volatile("" : "+s"(ntiles_w));   // opaque: stops the non-causal build from peeling the tail tile into a register-hungry shape
 
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
-        char* base = smem + stage * STAGEB;
+        const lds_char_ptr base = smem + stage * STAGEB;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            char* dst = base + (wave * 64 + 512 * i) * 16;
+            const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
             const uint32_t krow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * k_rowb;
             const uint32_t vrow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * v_rowb;
-            dma16_to_lds(krs, dst, krow + ln.r_src[i], 0);
-            dma16_to_lds(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
-            dma16_to_lds(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+            dma16_to_lds3(krs, dst, krow + ln.r_src[i], 0);
+            dma16_to_lds3(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
+            dma16_to_lds3(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
         }
     };
 
@@ -230,16 +249,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_t)::value;
         {
-            const char* kR = smem + st * STAGEB;
-            const char* vR = kR + TILEB;
-            const char* kT = kR + 2 * TILEB;
+            const lds_char_ptr kR = smem + st * STAGEB;
+            const lds_char_ptr vR = kR + TILEB;
+            const lds_char_ptr kT3 = kR + 2 * TILEB;
             f32x16 s0, s1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {                     // S^T = K Q^T
-                s0 = mfma16<BF16>(*(const u32x4*)(kR + ln.kr_off[ks]), qf[ks], s0);
-                s1 = mfma16<BF16>(*(const u32x4*)(kR + ln.kr_off[ks] + 32 * ROWB), qf[ks], s1);
+                s0 = mfma16<BF16>(lds_load128(kR + ln.kr_off[ks]), qf[ks], s0);
+                s1 = mfma16<BF16>(lds_load128(kR + ln.kr_off[ks] + 32 * ROWB), qf[ks], s1);
             }
             const int kv0 = tile * kKvTile;
             const int lim_c = CAUSAL ? qrow : 0x7fffffff;
@@ -258,8 +277,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {                     // dP^T = V dO^T
-                d0 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks]), gf[ks], d0);
-                d1 = mfma16<BF16>(*(const u32x4*)(vR + ln.kr_off[ks] + 32 * ROWB), gf[ks], d1);
+                d0 = mfma16<BF16>(lds_load128(vR + ln.kr_off[ks]), gf[ks], d0);
+                d1 = mfma16<BF16>(lds_load128(vR + ln.kr_off[ks] + 32 * ROWB), gf[ks], d1);
             }
             // dS^T / scale = P^T * (dP^T - D); the factor `scale` is applied once, to the finished dQ
 #pragma unroll
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
             for (int ks = 0; ks < 4; ++ks)                         // dQ^T += K^T dS^T
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const char* va = kT + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const lds_char_ptr va = kT3 + ln.vr_off[dt] + 16 * ks * ROWB;
                     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
                     const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, df[ks], acc[dt]);
@@ -290,11 +309,12 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
     stage_load(0, 0);
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int st = tile & 1;
-        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
-        if (tile < n_plain) tile_body(tile, st, std::false_type{});
-        else if (tile < ntiles_w) tile_body(tile, st, std::true_type{});
+        const int st = DBUF ? tile & 1 : 0;
+        if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
+        if (DBUF && tile < n_plain) tile_body(tile, st, std::false_type{});
+        else if (tile < ntiles_w) tile_body(tile, st, std::true_type{});       // (NW = 4: one body keeps the code and the registers down)
         __syncthreads();
+        if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
     if (qrow < p.Nq) {
         uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
@@ -305,13 +325,16 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_kernel(const BwdParams p) {
 // ---------------------------------------------------------------------------------------------------------
 // dV (WANT_DK = false) or dK (WANT_DK = true): workgroup = 256 KV rows (8 waves x 32), sweep over Q tiles of 64.
 // LDS per stage: Q row-form | (dK: dO row-form | Q tr-form)  (dV: dO tr-form) | L[64] | D[64]; two stages.
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK>
-__global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
-    using L_ = BwdLane<HD>;
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
+    using L_ = BwdLane<HD, NW>;
+    constexpr int kRows = NW * 32;
+    constexpr bool DBUF = NW == 8;
     constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
     constexpr int NT = WANT_DK ? 3 : 2;
     constexpr int STAGEB = NT * TILEB + 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    const lds_char_ptr smem = (lds_char_ptr)smem_generic;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     } else if (CAUSAL) { bh = bid % nbh; kblk = bid / nbh; }
     else { bh = bid / p.nblk; kblk = bid % p.nblk; }
     const int b = bh / p.H, h = bh % p.H;
-    const int kv0 = kblk * kQBlock, kvw0 = kv0 + 32 * wave, kvrow = kvw0 + l31;   // this lane's KV row
+    const int kv0 = kblk * kRows, kvw0 = kv0 + 32 * wave, kvrow = kvw0 + l31;   // this lane's KV row
     const int kr = kvrow < p.Nkv ? kvrow : p.Nkv - 1;
 
     L_ ln;
@@ -355,18 +378,18 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     const int tile0_w = CAUSAL ? kvw0 / kKvTile : 0;     // this wave's first useful tile
 
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
-        char* base = smem + stage * STAGEB;
+        const lds_char_ptr base = smem + stage * STAGEB;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            char* dst = base + (wave * 64 + 512 * i) * 16;
+            const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
             const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
             const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
-            dma16_to_lds(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
+            dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
             if constexpr (WANT_DK) {
-                dma16_to_lds(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                   // dO row-form
-                dma16_to_lds(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);               // Q tr-form
+                dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                   // dO row-form
+                dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);               // Q tr-form
             } else {
-                dma16_to_lds(grs, dst + TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
+                dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
             }
         }
         if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
@@ -386,25 +409,25 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_t)::value;
         {
-            const char* qR = smem + st * STAGEB;
-            const char* lt = qR + NT * TILEB;
+            const lds_char_ptr qR = smem + st * STAGEB;
+            const lds_char_ptr lt = qR + NT * TILEB;
             f32x16 s0, s1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {                     // S[q, kv] = Q K^T  (lane = kv)
-                s0 = mfma16<BF16>(*(const u32x4*)(qR + ln.kr_off[ks]), kf[ks], s0);
-                s1 = mfma16<BF16>(*(const u32x4*)(qR + ln.kr_off[ks] + 32 * ROWB), kf[ks], s1);
+                s0 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks]), kf[ks], s0);
+                s1 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks] + 32 * ROWB), kf[ks], s1);
             }
             f32x16 d0, d1;
             if constexpr (WANT_DK) {
-                const char* gR = qR + TILEB;
+                const lds_char_ptr gR = qR + TILEB;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {                 // dP[q, kv] = dO V^T
-                    d0 = mfma16<BF16>(*(const u32x4*)(gR + ln.kr_off[ks]), vf[ks], d0);
-                    d1 = mfma16<BF16>(*(const u32x4*)(gR + ln.kr_off[ks] + 32 * ROWB), vf[ks], d1);
+                    d0 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks]), vf[ks], d0);
+                    d1 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks] + 32 * ROWB), vf[ks], d1);
                 }
             }
             const int q0t = tile * kKvTile;
@@ -412,12 +435,12 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
-                const f32x4 L0 = *(const f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
-                const f32x4 L1 = *(const f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
+                const f32x4 L0 = *(const __attribute__((address_space(3))) f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
+                const f32x4 L1 = *(const __attribute__((address_space(3))) f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
                 f32x4 D0, D1;
                 if constexpr (WANT_DK) {
-                    D0 = *(const f32x4*)(lt + 256 + (8 * g4 + 4 * hi) * 4);
-                    D1 = *(const f32x4*)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+                    D0 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (8 * g4 + 4 * hi) * 4);
+                    D1 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -445,12 +468,12 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
                 xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
                 xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
             }
-            const char* tT = qR + (WANT_DK ? 2 : 1) * TILEB;       // Q tr-form (dK) or dO tr-form (dV)
+            const lds_char_ptr tT = qR + (WANT_DK ? 2 : 1) * TILEB;       // Q tr-form (dK) or dO tr-form (dV)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)                         // dK^T += Q^T dS   /   dV^T += dO^T P
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const char* va = tT + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const lds_char_ptr va = tT + ln.vr_off[dt] + 16 * ks * ROWB;
                     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
                     const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], acc[dt]);
@@ -461,11 +484,12 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_kernel(const BwdParams p) {
     if (tile0 < ntiles) stage_load(tile0, 0);
     __syncthreads();
     for (int tile = tile0; tile < ntiles; ++tile) {
-        const int st = (tile - tile0) & 1;
-        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
-        if (tile >= first_plain) tile_body(tile, st, std::false_type{});
-        else if (tile >= tile0_w) tile_body(tile, st, std::true_type{});
+        const int st = DBUF ? (tile - tile0) & 1 : 0;
+        if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+        if (DBUF && tile >= first_plain) tile_body(tile, st, std::false_type{});
+        else if (tile >= tile0_w) tile_body(tile, st, std::integral_constant<bool, CAUSAL>{});
         __syncthreads();
+        if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
     if (kvrow < p.Nkv) {
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]

@@ -72,32 +72,34 @@ int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
 
 template <int HD, bool BF16, bool CAUSAL>
 int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
-    constexpr int TILEB = fa2::Geo<HD, 8>::TILEB;
+    constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
+    constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
     const int64_t rows = (int64_t)p.B * p.H * p.Nq;
     hipLaunchKernelGGL((fa2::bwd_delta_kernel<BF16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p, p.D);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    {   // dQ: one workgroup per 256 Q rows
-        constexpr int lds = 2 * 3 * TILEB;
-        auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL>;
+    {   // dQ: one workgroup per kRows Q rows
+        constexpr int lds = kStages * 3 * TILEB;
+        auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, NW>;
         if ((rc = set_lds(kern, lds))) return rc;
-        p.nblk = (p.Nq + fa2::kQBlock - 1) / fa2::kQBlock;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        p.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
     }
-    p.nblk = (p.Nkv + fa2::kQBlock - 1) / fa2::kQBlock;   // dV, dK: one workgroup per 256 KV rows
+    p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows
     {
-        constexpr int lds = 2 * (2 * TILEB + 512);
-        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false>;
+        constexpr int lds = kStages * (2 * TILEB + 512);
+        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false, NW>;
         if ((rc = set_lds(kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
     }
     {
-        constexpr int lds = 2 * (3 * TILEB + 512);
-        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true>;
+        constexpr int lds = kStages * (3 * TILEB + 512);
+        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW>;
         if ((rc = set_lds(kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
     }
     return 0;
@@ -213,7 +215,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
     const int HD = fa2_padded_head_dim(D);              // columns [D, HD) are masked in-kernel
-    if (HD < 0 || HD > 128 || (D & 7)) return FA2_ERR_HEAD_DIM;   // backward kernels: D <= 128
+    if (HD < 0 || (D & 7)) return FA2_ERR_HEAD_DIM;
     if (!std::isfinite(scale)) return FA2_ERR_SCALE;
     const void* ptrs[] = {q, k, v, o, dout, dq, dk, dv};
     const int64_t* strides[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
@@ -244,6 +246,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
     switch (HD) {
         case 64: return bf16 ? launch_bwd<64, true>(p, causal != 0, stream) : launch_bwd<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch_bwd<128, true>(p, causal != 0, stream) : launch_bwd<128, false>(p, causal != 0, stream);
+        case 256: return bf16 ? launch_bwd<256, true>(p, causal != 0, stream) : launch_bwd<256, false>(p, causal != 0, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
 }

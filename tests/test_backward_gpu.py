@@ -80,7 +80,7 @@ def test_golden_backward_fixtures(golden):
         _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
 
 
-SHAPES = [(1, 1, 1, 1, 64), (1, 2, 1, 300, 128), (2, 3, 65, 1, 64), (1, 2, 31, 33, 64), (1, 3, 255, 257, 128),
+SHAPES = [(1, 1, 1, 1, 64), (1, 2, 1, 300, 128), (1, 2, 300, 129, 256), (2, 1, 128, 384, 160), (2, 3, 65, 1, 64), (1, 2, 31, 33, 64), (1, 3, 255, 257, 128),
           (2, 2, 256, 256, 128), (1, 2, 257, 511, 64), (1, 1, 700, 700, 128), (3, 5, 130, 77, 64), (1, 4, 512, 512, 128)]
 
 
@@ -96,10 +96,11 @@ def test_seeded_shapes_against_oracle(shape, dt, causal):
     _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
 
 
-@pytest.mark.parametrize("D", [8, 40, 80, 104, 120])
+@pytest.mark.parametrize("D", [8, 40, 80, 104, 120, 136, 160, 200, 256])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_backward_head_dims_masked_in_kernel(D, dt):
-    """Multiples of 8 up to 128 run on the 64 / 128 kernels with columns >= D masked (SD1.5: 40, 80), unpadded buffers."""
+    """Multiples of 8 up to 256 run on the 64 / 128 / 256 kernels with columns >= D masked (SD1.5: 40, 80, 160), unpadded
+    buffers; D > 128 takes the 4-wave single-stage kernels."""
     g = torch.Generator(device="cpu").manual_seed(200 + D)
     mk = lambda n: torch.randn((2, 2, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
     q, k, v, do = mk(130), mk(203), mk(203), mk(130)

@@ -86,7 +86,7 @@ def test_validation_codes_without_a_gpu():
                                    kw.get("scale", 0.125), 0, None)
     assert bwd(q=None) == c["FA2_ERR_NULL_POINTER"] and bwd(ws=None) == c["FA2_ERR_NULL_POINTER"]
     assert bwd(dtype=3) == c["FA2_ERR_DTYPE"] and bwd(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
-    assert bwd(D=136) == c["FA2_ERR_HEAD_DIM"] and bwd(D=100) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
+    assert bwd(D=264) == c["FA2_ERR_HEAD_DIM"] and bwd(D=100) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
     assert bwd(dos=_fa2_lib.strides3(2048, 1024, 66)) == c["FA2_ERR_ALIGNMENT"]
     assert lib.fa2_bwd_f16(p, p, p, p, p, p, p, p, p, None, 1, 1, 1, 1, 64, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
         == c["FA2_ERR_NULL_POINTER"]

@@ -33,7 +33,7 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-shared",
     "-fno-honor-nans",          # no canonicalising v_max before fmaxf on MFMA outputs; +-inf still honoured
-]
+] + os.environ.get("FA2_EXTRA_HIPCC_FLAGS", "").split()    # e.g. "-DFA2_PRESCALE_MAX_HD=64" (kernel knobs, see the headers)
 
 
 def _hipcc():

@@ -179,7 +179,7 @@ struct Geo {
 // [128,256)): a 256-wide f32 O accumulator plus the Q fragments would not fit 256 VGPRs, so QK^T is
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 //
-// PRE ("pre-scaled Q", used for HD = 64 where the registers are there): Q is multiplied by c = |scale|*log2(e)
+// PRE ("pre-scaled Q", opt-in: host.cpp FA2_PRESCALE_MAX_HD; fits HD = 64 where the registers are there): Q is multiplied by c = |scale|*log2(e)
 // once and rounded back to 16 bits — the reference oracle's own contract, `scale * q_frags`
 // (pure_torch_ver.py:61) — and a tile's first QK^T MFMAs take C = -m (16 registers that all hold the
 // negated running reference) instead of C = 0, so the MFMA chain delivers s*c - m and the v_fma in front of

@@ -6,7 +6,7 @@
 // exactly one workgroup, so the result is deterministic and needs no atomics, at the price of recomputing
 // S in each of the three passes:
 //
-//   bwd_delta_kernel                D_i = rowsum(dO_i * O_i)                  (kernel_fp16.cu:605-631)
+//   (D_i = rowsum(dO_i * O_i), kernel_fp16.cu:605-631, is computed by bwd_dq for its own rows and stored for bwd_dkv)
 //   bwd_dq_kernel                   workgroup = 256 Q rows, sweeps KV tiles:   dQ  = sum_j dS_ij K_j
 //   bwd_dkv_kernel<WANT_DK=false>   workgroup = 256 KV rows, sweeps Q tiles:   dV  = sum_i P_ij^T dO_i
 //   bwd_dkv_kernel<WANT_DK=true>    same sweep:                               dK  = sum_i dS_ij^T Q_i
@@ -68,42 +68,23 @@ __device__ __forceinline__ void dma4_to_lds(RSRC rsrc, lds_char_ptr lds_dst, uin
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// D_i = sum_d dO[i,d] * O[i,d]   (f32).  16 lanes per row (8 elements each), 4 rows per wave.
+// f32 dot product of two fragments of eight 16-bit values.
 template <bool BF16>
-__global__ __launch_bounds__(256) void bwd_delta_kernel(const BwdParams p, int D) {
-    const int lane16 = threadIdx.x & 15;
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // flattened (b, h, i)
-    const int64_t total = (int64_t)p.B * p.H * p.Nq;
+__device__ __forceinline__ float dot8(u32x4 a, u32x4 g) {
     float acc = 0.f;
-    if (row < total) {
-        const int i = (int)(row % p.Nq);
-        const int bh = (int)(row / p.Nq);
-        const int b = bh / p.H, h = bh % p.H;
-        const uint16_t* op = (const uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)i * p.os[2];
-        const uint16_t* gp = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1] + (int64_t)i * p.dos[2];
-        for (int d = lane16 * 8; d < D; d += 128) {
-            const u32x4 a = *(const u32x4*)(op + d), g = *(const u32x4*)(gp + d);
-            if constexpr (BF16) {
+    if constexpr (BF16) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    acc += __uint_as_float(a[w] << 16) * __uint_as_float(g[w] << 16) +
-                           __uint_as_float(a[w] & 0xffff0000u) * __uint_as_float(g[w] & 0xffff0000u);
-            } else {
-                // (whole-vector bit_cast: a per-element __builtin_bit_cast(f16x2, a[w]) in an unrolled loop was
-                // folded to element 0 by hipcc 7.2)
-                const f16x8 ah = __builtin_bit_cast(f16x8, a), gh = __builtin_bit_cast(f16x8, g);
+        for (int w = 0; w < 4; ++w)
+            acc += __uint_as_float(a[w] << 16) * __uint_as_float(g[w] << 16) +
+                   __uint_as_float(a[w] & 0xffff0000u) * __uint_as_float(g[w] & 0xffff0000u);
+    } else {
+        // (whole-vector bit_cast: a per-element __builtin_bit_cast(f16x2, a[w]) in an unrolled loop was folded to
+        // element 0 by hipcc 7.2)
+        const f16x8 ah = __builtin_bit_cast(f16x8, a), gh = __builtin_bit_cast(f16x8, g);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += (float)ah[e] * (float)gh[e];
-            }
-        }
+        for (int e = 0; e < 8; ++e) acc += (float)ah[e] * (float)gh[e];
     }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
-    if (row < total && lane16 == 0) {
-        const int i = (int)(row % p.Nq);
-        const int bh = (int)(row / p.Nq);
-        p.delta[(bh / p.H) * p.ls[0] + (bh % p.H) * p.ls[1] + i] = acc;
-    }
+    return acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -203,7 +184,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
         }
     }
     const float Lq = p.lse[b * p.ls[0] + h * p.ls[1] + qr];
-    const float Dq = p.delta[b * p.ls[0] + h * p.ls[1] + qr];
+    // D_i = sum_d dO[i,d] * O[i,d] (the reference's `Di`, kernel_fp16.cu:605-631) for the lane's own row, from the dO
+    // fragments already in registers; stored to the delta workspace for the dK pass that follows on the stream.
+    float Dq;
+    {
+        const uint16_t* orow = (const uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qr * p.os[2];
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (16 * ks + 8 * hi < p.D) part += dot8<BF16>(*(const u32x4*)(orow + 16 * ks + 8 * hi), gf[ks]);
+        }
+        Dq = half_swap_sum(part);
+        if (hi == 0 && qrow < p.Nq) p.delta[b * p.ls[0] + h * p.ls[1] + qrow] = Dq;
+    }
 
     const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
     const uint16_t* vbase = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1];

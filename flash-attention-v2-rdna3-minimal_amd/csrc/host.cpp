@@ -78,11 +78,8 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
     constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
-    const int64_t rows = (int64_t)p.B * p.H * p.Nq;
-    hipLaunchKernelGGL((fa2::bwd_delta_kernel<BF16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p, p.D);
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
-    {   // dQ: one workgroup per kRows Q rows
+    int rc;
+    {   // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass
         constexpr int lds = kStages * 3 * TILEB;
         auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, NW>;
         if ((rc = set_lds(kern, lds))) return rc;

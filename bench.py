@@ -202,7 +202,7 @@ def main():
         assert all(torch.isfinite(t.grad.float()).all() for t in (qg, kg, vg)), "non-finite gradient"
         bwd = {"bwd_ms": round(bwd_ms, 4),
                "bwd_tflops": round(2.5 * attention_flops(B_local, H, N, N, D, causal) / (bwd_ms * 1e-3) / 1e12, 1),
-               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); 3 launches: dQ (+ delta), dV, dK"}
+               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); launches: dQ (+ delta), dV, dK (dK+dV fused at D <= 64)"}
 
     times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:

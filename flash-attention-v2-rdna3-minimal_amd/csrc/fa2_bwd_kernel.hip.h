@@ -318,13 +318,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
 // ---------------------------------------------------------------------------------------------------------
 // dV (WANT_DK = false) or dK (WANT_DK = true): workgroup = 256 KV rows (8 waves x 32), sweep over Q tiles of 64.
 // LDS per stage: Q row-form | (dK: dO row-form | Q tr-form)  (dV: dO tr-form) | L[64] | D[64]; two stages.
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8>
+// BOTH (WANT_DK and D = 64, where two accumulators fit): dK and dV in one sweep — S and P are formed once, the stage
+// additionally carries dO in tr-form (Q row | dO row | Q tr | dO tr).
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
+    static_assert(!BOTH || WANT_DK, "the fused pass is the dK pass plus a dV accumulator");
     using L_ = BwdLane<HD, NW>;
     constexpr int kRows = NW * 32;
     constexpr bool DBUF = NW == 8;
     constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
-    constexpr int NT = WANT_DK ? 3 : 2;
+    constexpr int NT = BOTH ? 4 : WANT_DK ? 3 : 2;
     constexpr int STAGEB = NT * TILEB + 512;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const lds_char_ptr smem = (lds_char_ptr)smem_generic;
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
             if constexpr (WANT_DK) {
                 dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                   // dO row-form
                 dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);               // Q tr-form
+                if constexpr (BOTH) dma16_to_lds3(grs, dst + 3 * TILEB, grow_b + ln.t_src[i], 0);   // dO tr-form
             } else {
                 dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
             }
@@ -389,11 +393,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
         if (WANT_DK && wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
     };
 
-    f32x16 acc[DT];
+    f32x16 acc[DT], accv[BOTH ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[dt][r] = 0.f; if constexpr (BOTH) accv[dt][r] = 0.f; }
     const float c = p.c, scale = p.scale;
 
     // Q tiles from first_plain on lie entirely at or below this wave's KV rows' diagonal (q >= kv for every pair)
@@ -445,7 +449,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                         if (kvrow > qi) p0 = 0.f;
                         if (kvrow > qi + 32) p1 = 0.f;
                     }
-                    if constexpr (WANT_DK) {          // dS / scale; `scale` is applied once, to the finished dK
+                    if constexpr (BOTH) { d0[r] = p0 * (d0[r] - D0[e]); d1[r] = p1 * (d1[r] - D1[e]); }   // dS / scale, P kept
+                    else if constexpr (WANT_DK) {     // dS / scale; `scale` is applied once, to the finished dK
                         p0 = p0 * (d0[r] - D0[e]);
                         p1 = p1 * (d1[r] - D1[e]);
                     }
@@ -460,6 +465,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                 xf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
                 xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
                 xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            }
+            if constexpr (BOTH) {                                  // dV^T += dO^T P with the P fragments above ...
+                const lds_char_ptr gT = qR + 3 * TILEB;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const lds_char_ptr va = gT + ln.vr_off[dt] + 16 * ks * ROWB;
+                        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
+                        const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                        accv[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], accv[dt]);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                      // ... then the fragments are re-packed from dS for dK
+                    xf[0][i] = pack2<BF16>(d0[2 * i], d0[2 * i + 1]);
+                    xf[1][i] = pack2<BF16>(d0[8 + 2 * i], d0[8 + 2 * i + 1]);
+                    xf[2][i] = pack2<BF16>(d1[2 * i], d1[2 * i + 1]);
+                    xf[3][i] = pack2<BF16>(d1[8 + 2 * i], d1[8 + 2 * i + 1]);
+                }
             }
             const lds_char_ptr tT = qR + (WANT_DK ? 2 : 1) * TILEB;       // Q tr-form (dK) or dO tr-form (dV)
 #pragma unroll
@@ -488,6 +512,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
                                : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
         store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f, p.D);
+        if constexpr (BOTH) {
+            uint16_t* ov = (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
+            store_acc_t<BF16, DT>(accv, ov, hi, 1.0f, p.D);
+        }
     }
 }
 

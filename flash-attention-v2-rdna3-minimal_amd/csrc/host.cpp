@@ -73,6 +73,10 @@ int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     return causal ? launch_t<HD, BF16, true, false>(p, stream) : launch_t<HD, BF16, false, false>(p, stream);
 }
 
+#ifndef FA2_BWD_FUSE_MAX_HD          // head dims up to this run dK and dV as one fused pass
+#define FA2_BWD_FUSE_MAX_HD 64
+#endif
+
 template <int HD, bool BF16, bool CAUSAL>
 int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
@@ -88,19 +92,28 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
         if ((rc = (int)hipGetLastError())) return rc;
     }
     p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows
-    {
-        constexpr int lds = kStages * (2 * TILEB + 512);
-        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false, NW>;
+    if constexpr (HD <= FA2_BWD_FUSE_MAX_HD && NW == 8) {
+        // D = 64: both accumulators fit, one sweep forms S and P once for dK and dV
+        constexpr int lds = kStages * (4 * TILEB + 512);
+        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW, true>;
         if ((rc = set_lds(kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
-        if ((rc = (int)hipGetLastError())) return rc;
-    }
-    {
-        constexpr int lds = kStages * (3 * TILEB + 512);
-        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW>;
-        if ((rc = set_lds(kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
-        if ((rc = (int)hipGetLastError())) return rc;
+        return (int)hipGetLastError();
+    } else {
+        {
+            constexpr int lds = kStages * (2 * TILEB + 512);
+            auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false, NW>;
+            if ((rc = set_lds(kern, lds))) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        {
+            constexpr int lds = kStages * (3 * TILEB + 512);
+            auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW>;
+            if ((rc = set_lds(kern, lds))) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
     }
     return 0;
 }

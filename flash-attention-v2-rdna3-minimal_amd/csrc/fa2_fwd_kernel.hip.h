@@ -40,9 +40,9 @@
 #ifndef FA2_DEFER_THR        // skip the O rescale while the row max grew by <= this (log2 units); <0: always rescale.
 #define FA2_DEFER_THR 8.0f   // 0 = exact FA2 (rescale whenever any row's max grows); 8 keeps P <= 2^8 (fp16/bf16 safe): +5 %
 #endif
-#ifndef FA2_PIPE             // 1: cross-tile software pipeline inside each wave (QK^T of tile+1 beside softmax of tile);
-#define FA2_PIPE 1           // 0: plain order.  1 -> 1130-1180 TF, 0 -> 1090-1125 TF
-#endif
+// (The loop is the cross-tile software pipeline: QK^T of tile+1 beside the softmax of tile.  The plain-order variant,
+//  1090-1125 TF against 1130-1180, and the FA2_ABL ablation switches that priced the parts of the step are in the git
+//  history, up to commit f31c723.)
 #ifndef FA2_LDS_DMA          // stage K/V tiles with buffer_load ... lds (no staging VGPRs, no ds_write); the LDS swizzle
 #define FA2_LDS_DMA 1        // is applied to the per-lane SOURCE address, the LDS image stays lane-linear.
 #endif                       // D=128: +3 % non-causal, +6 % causal; D=64: -3 % -> register staging below FA2_LDS_DMA_MIN_HD
@@ -52,9 +52,6 @@
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
-#ifndef FA2_ABL              // developer-only ablation bitmask (results are WRONG when non-zero):
-#define FA2_ABL 0            // 1 no exp/fma, 2 no row sum, 4 no PV mfma, 8 no QK mfma, 16 no global->LDS staging,
-#endif                       // 32 no V transpose reads, 64 no K reads, 128 no max, 256 no barrier
 // Tried and dropped (git history has the code; DESIGN.md §3 the measurements): s_setprio variants, 2- and 3-phase
 // ping-pong of the two waves of a SIMD, issuing all LDS fragment reads of a phase up front, packed-f32 softmax math.
 
@@ -392,21 +389,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             for (int r = 0; r < 16; ++r) { s[qb][0][r] = s[qb][1][r] = PRE ? negm[qb][r] : 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
-            u32x4 a0, a1;
-            if (FA2_ABL & 64) { a0 = qf[0][ks]; a1 = qf[0][(ks + 1) % KS_QK]; }
-            else {
-                a0 = *(const u32x4*)(kt + kr_off[ks]);
-                a1 = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
-            }
+            const u32x4 a0 = *(const u32x4*)(kt + kr_off[ks]);
+            const u32x4 a1 = *(const u32x4*)(kt + kr_off[ks] + 32 * ROWB);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                if (FA2_ABL & 8) {
-                    s[qb][0][ks] += __uint_as_float(a0[0] ^ a0[1] ^ a0[2] ^ a0[3]);
-                    s[qb][1][ks] += __uint_as_float(a1[0] ^ a1[1] ^ a1[2] ^ a1[3]);
-                } else {
-                    s[qb][0] = mfma16<BF16>(a0, qf[qb][ks], s[qb][0]);
-                    s[qb][1] = mfma16<BF16>(a1, qf[qb][ks], s[qb][1]);
-                }
+                s[qb][0] = mfma16<BF16>(a0, qf[qb][ks], s[qb][0]);
+                s[qb][1] = mfma16<BF16>(a1, qf[qb][ks], s[qb][1]);
             }
         }
     };
@@ -446,12 +434,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
             float m = max3(s0[0], s1[0], s0[1]);
-            if (!(FA2_ABL & 128)) {
-                m = max3(m, s1[1], s0[2]);
+            m = max3(m, s1[1], s0[2]);
 #pragma unroll
-                for (int r = 2; r < 15; ++r) m = max3(m, s1[r], s0[r + 1]);
-                m = __builtin_fmaxf(m, s1[15]);
-            }
+            for (int r = 2; r < 15; ++r) m = max3(m, s1[r], s0[r + 1]);
+            m = __builtin_fmaxf(m, s1[15]);
             mx[qb] = half_swap_max(m);
             if (!(FA2_DEFER_THR < 0.f))
                 grow = grow || (__builtin_amdgcn_ballot_w64((PRE ? mx[qb] : (mx[qb] - m_run[qb]) * c) > FA2_DEFER_THR) != 0);
@@ -505,14 +491,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (!(FA2_ABL & 1)) {
-                    s0[r] = __builtin_amdgcn_exp2f(PRE ? s0[r] : __builtin_fmaf(s0[r], c, -mc));
-                    s1[r] = __builtin_amdgcn_exp2f(PRE ? s1[r] : __builtin_fmaf(s1[r], c, -mc));
-                }
-                if (!(FA2_ABL & 2)) {
-                    rs0 += s0[r];
-                    rs1 += s1[r];
-                }
+                s0[r] = __builtin_amdgcn_exp2f(PRE ? s0[r] : __builtin_fmaf(s0[r], c, -mc));
+                s1[r] = __builtin_amdgcn_exp2f(PRE ? s1[r] : __builtin_fmaf(s1[r], c, -mc));
+                rs0 += s0[r];
+                rs1 += s1[r];
             }
             l_run[qb] += rs0 + rs1;
 #pragma unroll
@@ -533,21 +515,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const char* va = vt + vr_off[dt] + 16 * ks * VROWB;
-                u32x4 a;
-                if (FA2_ABL & 32) a = qf[0][(ks * DT + dt) % KS_QK];
-                else {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB));
-                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
-                    a = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
-                }
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB));
+                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
+                const u32x4 a = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    if (FA2_ABL & 4)
-                        acc[qb][dt][ks] += __uint_as_float((a[0] ^ a[1] ^ a[2] ^ a[3]) &
-                                                           (pf[qb][ks][0] ^ pf[qb][ks][1] ^ pf[qb][ks][2] ^ pf[qb][ks][3]));
-                    else acc[qb][dt] = mfma16<BF16>(a, pf[qb][ks], acc[qb][dt]);
-                }
+                for (int qb = 0; qb < QB; ++qb) acc[qb][dt] = mfma16<BF16>(a, pf[qb][ks], acc[qb][dt]);
             }
         }
     };
@@ -570,21 +543,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #if FA2_IGLP >= 0
         if constexpr (FAST) __builtin_amdgcn_iglp_opt(FA2_IGLP);   // scheduler hint for the steady-state block
 #endif
-        if (more2 && !(FA2_ABL & 16)) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
-        if (more1 && !(FA2_ABL & 16)) load_v(tile + 1, PAR ^ 1);
+        if (more2) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
+        if (more1) load_v(tile + 1, PAR ^ 1);
         if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
             u32x4 pf[QB][4];
             exp_scores(sc, pf);
             pv(PAR, pf);
         }
-        if (more2 && !(FA2_ABL & 16)) write_k(PAR);
-        if (more1 && !(FA2_ABL & 16)) write_v(PAR ^ 1);
-        if (!(FA2_ABL & 256)) __syncthreads();
+        if (more2) write_k(PAR);
+        if (more1) write_v(PAR ^ 1);
+        __syncthreads();
         if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn);
     };
 
-#if FA2_PIPE == 1
     // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
     load_k(0, 0);
     load_v(0, 0);
@@ -621,51 +593,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     }
     if (tile < ntiles) step(tile, P0, GENERIC, sa, sb);
 
-#else
-    // Plain order: tile's K and V both live in buffer PAR; next tile is staged into PAR^1.
-    auto step_plain = [&](int tile, auto par, auto fast, f32x16 (&sc)[QB][2]) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-        constexpr bool FAST = decltype(fast)::value;
-        const bool more1 = FAST || tile + 1 < ntiles;
-        const bool cur_w = FAST || tile < ntiles_w;
-        if (more1 && !(FA2_ABL & 16)) { load_k(tile + 1, PAR ^ 1); load_v(tile + 1, PAR ^ 1); }
-        if (cur_w) {
-            qk(PAR, sc);
-            finish_scores(tile, std::integral_constant<bool, !FAST>{}, sc, tile == 0);
-            u32x4 pf[QB][4];
-            exp_scores(sc, pf);
-            pv(PAR, pf);
-        }
-        if (more1 && !(FA2_ABL & 16)) { write_k(PAR ^ 1); write_v(PAR ^ 1); }
-        if (!(FA2_ABL & 256)) __syncthreads();
-    };
-    load_k(0, 0);
-    load_v(0, 0);
-    write_k(0);
-    write_v(0);
-    __syncthreads();
-    f32x16 sa[QB][2];
-    int n_fast = ntiles - 1 < ntiles_w ? ntiles - 1 : ntiles_w;
-    {
-        const int unmasked_kv = p.Nkv / kKvTile;
-        const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;
-        const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
-        n_fast = n_fast < unmasked ? n_fast : unmasked;
-        n_fast = n_fast < 0 ? 0 : n_fast & ~1;
-    }
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    int tile = 0;
-    for (; tile < n_fast; tile += 2) {
-        step_plain(tile, P0, std::true_type{}, sa);
-        step_plain(tile + 1, P1, std::true_type{}, sa);
-    }
-    for (; tile + 1 < ntiles; tile += 2) {
-        step_plain(tile, P0, std::false_type{}, sa);
-        step_plain(tile + 1, P1, std::false_type{}, sa);
-    }
-    if (tile < ntiles) step_plain(tile, P0, std::false_type{}, sa);
-#endif
 
     // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
 #pragma unroll

@@ -275,6 +275,37 @@ def test_launch_is_on_the_callers_stream_and_device():
     assert torch.equal(o, ref)
 
 
+def test_operator_is_graph_capturable():
+    """Small (cross-attention-sized) calls are host-bound; the C-ABI launch only enqueues on the caller's stream, so a
+    sequence of operator calls can be captured into a HIP graph and replayed without any host work."""
+    g = torch.Generator(device="cpu").manual_seed(12)
+    q = torch.randn((2, 4, 512, 64), generator=g).half().to(_dev())
+    k = torch.randn((2, 4, 77, 64), generator=g).half().to(_dev())
+    v = torch.randn((2, 4, 77, 64), generator=g).half().to(_dev())
+    ref = FlashAttentionFunction.apply(q, k, v, None, False)          # warm-up outside the capture (library load, LDS opt-in)
+    ref256 = FlashAttentionFunction.apply(q.repeat(1, 1, 1, 4), k.repeat(1, 1, 1, 4), v.repeat(1, 1, 1, 4), None, False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            o1 = FlashAttentionFunction.apply(q, k, v, None, False)
+            o2 = FlashAttentionFunction.apply(o1, k, v, None, False)   # a dependent second call inside the same graph
+    torch.cuda.current_stream().wait_stream(side)
+    o1.zero_()
+    o2.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, ref)
+    assert torch.equal(o2, FlashAttentionFunction.apply(ref, k, v, None, False))
+    q.copy_(q * 0.5)                                                   # new inputs in the captured buffers, replay again
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, FlashAttentionFunction.apply(q, k, v, None, False))
+    del ref256
+
+
 # ---------------------------------------------------------------- BASELINE.json configurations (full size)
 
 CONFIGS = {

@@ -172,7 +172,7 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.3 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.4 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined; head dims masked in-kernel; fwd+bwd)"; }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
             int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],

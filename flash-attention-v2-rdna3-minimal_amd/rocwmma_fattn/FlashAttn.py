@@ -30,11 +30,12 @@ class _FlashAttnWmma:
     @staticmethod
     def forward(q, k, v, Br, Bc, causal, scale, permute_NH):
         """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16 (kernel_fp16.cu:744-876).
-        Where the reference pads on the host — Q/O/L rows to a multiple of Br, D to a multiple of 32
-        (kernel_fp16.cu:761-779, :793-796) — the gfx950 kernels mask in-kernel (ragged Nq / Nkv, any D that is
-        a multiple of 8), so q_pad, k_pad, v_pad are the inputs themselves (made contiguous if their strides
-        require it) and O, L have the actual sizes; only a D that is not a multiple of 8 is zero-padded up to
-        one.  Br/Bc are accepted for signature compatibility; the kernels pick their own tiles."""
+        O and L keep the reference's shapes — rows padded to a multiple of Br with a zero tail, O_fwd a view into
+        O (kernel_fp16.cu:761, :793-796, :865-875) — but nothing is COPIED to get there: the gfx950 kernels mask
+        ragged Nq / Nkv and any D that is a multiple of 8 in-kernel, so q_pad, k_pad, v_pad are the inputs
+        themselves (made contiguous if their strides require it; the reference returns padded copies,
+        kernel_fp16.cu:767-779).  Only a D that is not a multiple of 8 is zero-padded, to the next multiple of 8.
+        Br sizes the N padding of O and L; Bc is accepted for signature compatibility."""
         lib = _fa2_lib.load()
         if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
             raise RuntimeError("fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)")
@@ -68,11 +69,20 @@ class _FlashAttnWmma:
             q_pad, k_pad, v_pad = (torch.nn.functional.pad(t, (0, d_pad)) for t in (q, k, v))
         q_pad, k_pad, v_pad = (_kernel_ready(t) for t in (q_pad, k_pad, v_pad))
 
-        # outputs on q's device, laid out like q (kernel_fp16.cu:793-796)
-        O = torch.empty_like(q_pad)
-        if not _strides_ok(O):
-            O = torch.empty(q_pad.shape, dtype=q_pad.dtype, device=q_pad.device)
-        L = torch.empty((b, h, n), dtype=torch.float32, device=q.device)
+        # outputs on q's device (kernel_fp16.cu:793-796): rows padded to a multiple of Br like the reference's, only
+        # the padding tail is zero-filled (the kernel writes every real row)
+        nq_pad = -n % int(Br)
+        if nq_pad:
+            oshape = (b, n + nq_pad, h, d_kernel) if permute_NH else (b, h, n + nq_pad, d_kernel)
+            O = torch.empty(oshape, dtype=q_pad.dtype, device=q_pad.device)
+            O.narrow(n_ax, n, nq_pad).zero_()
+            L = torch.empty((b, h, n + nq_pad), dtype=torch.float32, device=q.device)
+            L[:, :, n:].zero_()
+        else:
+            O = torch.empty_like(q_pad)
+            if not _strides_ok(O):
+                O = torch.empty(q_pad.shape, dtype=q_pad.dtype, device=q_pad.device)
+            L = torch.empty((b, h, n), dtype=torch.float32, device=q.device)
 
         def s3(t):
             st = t.stride()
@@ -81,7 +91,7 @@ class _FlashAttnWmma:
         dev = q.device.index
         args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
                 b, h, n, n_kv, d_kernel, s3(q_pad), s3(k_pad), s3(v_pad), s3(O),
-                _fa2_lib.strides2(h * n, n), float(scale), 1 if causal else 0, _raw_stream(dev))
+                _fa2_lib.strides2(h * (n + nq_pad), n + nq_pad), float(scale), 1 if causal else 0, _raw_stream(dev))
         if dev != _current_device():
             with torch.cuda.device(dev):
                 rc = lib.fa2_fwd(*args)
@@ -90,7 +100,11 @@ class _FlashAttnWmma:
         if rc:
             _fa2_lib.check(rc)
 
-        O_fwd = O[..., :d] if d_pad else O       # a view into O (kernel_fp16.cu:865-875)
+        O_fwd = O                                # a view into the padded O (kernel_fp16.cu:865-875)
+        if nq_pad:
+            O_fwd = O_fwd.narrow(n_ax, 0, n)
+        if d_pad:
+            O_fwd = O_fwd[..., :d]
         return [O_fwd, q_pad, k_pad, v_pad, O, L]
 
     @staticmethod

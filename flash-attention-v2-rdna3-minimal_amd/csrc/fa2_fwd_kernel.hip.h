@@ -49,6 +49,9 @@
 #ifndef FA2_LDS_DMA_MIN_HD
 #define FA2_LDS_DMA_MIN_HD 128
 #endif
+#ifndef FA2_EPI_LDS          // 1: O goes to global memory as whole rows through a wave-private LDS image
+#define FA2_EPI_LDS 1
+#endif
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
@@ -595,6 +598,47 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 
 
     // ---- epilogue (reference: kernel_fp16.cu:510-543): O = O / l, lse = m + log2(l) (log2 domain)
+#if FA2_EPI_LDS
+    // The normalised 16-bit O tile of a wave (32 rows x HDV columns) is written to a wave-private LDS image and read back
+    // row-major, so that every global store instruction writes whole contiguous rows (64 lanes x 16 B = 4 rows of
+    // 256 B) instead of 32 B of each of 32 rows.  The K/V buffers are free by now; rows are padded by 16 B so both the
+    // column-wise writes and the row-wise reads are bank-conflict free.
+    if constexpr (QB == 1) {
+        constexpr int EROW = HDV * 2 + 16;                       // bytes per staged row
+        constexpr int LPR = HDV * 2 / 16;                        // lanes (16-B pieces) per row
+        constexpr int RPI = 64 / LPR;                            // rows per store instruction
+        __syncthreads();                                         // every wave is done reading the K / V buffers
+        char* img = smem + wave * (32 * EROW);
+        const float l_tot = half_swap_sum(l_run[0]);
+        const float inv_l = 1.0f / l_tot;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4 += 2) {
+                const f32x16& a = acc[0][dt];
+                uint32_t a0 = pack2<BF16>(a[4 * r4 + 0] * inv_l, a[4 * r4 + 1] * inv_l);
+                uint32_t a1 = pack2<BF16>(a[4 * r4 + 2] * inv_l, a[4 * r4 + 3] * inv_l);
+                uint32_t b0 = pack2<BF16>(a[4 * r4 + 4] * inv_l, a[4 * r4 + 5] * inv_l);
+                uint32_t b1 = pack2<BF16>(a[4 * r4 + 6] * inv_l, a[4 * r4 + 7] * inv_l);
+                auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                *(u32x4*)(img + l31 * EROW + (32 * dt + 8 * (r4 + hi)) * 2) = (u32x4){x0[0], x1[0], x0[1], x1[1]};
+            }
+        }
+        if (qrow[0] < p.Nq && hi == 0 && vcol0 == 0)
+            p.lse[b * p.ls[0] + h * p.ls[1] + qrow[0]] = (PRE ? m_run[0] : m_run[0] * c) + __builtin_amdgcn_logf(l_tot);
+        // read back row-major (wave-private image: the compiler's lgkmcnt wait orders write -> read)
+        const int rl = lane / LPR, cl = lane % LPR;              // row within the group of RPI rows, 16-B piece within the row
+        uint16_t* obase = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + vcol0;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int r = i * RPI + rl;
+            const u32x4 w = *(const u32x4*)(img + r * EROW + cl * 16);
+            if (qw0 + r < p.Nq && vcol0 + cl * 8 < p.D) *(u32x4*)(obase + (int64_t)(qw0 + r) * p.os[2] + cl * 8) = w;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float l_tot = half_swap_sum(l_run[qb]);

@@ -56,7 +56,9 @@ int set_lds(K kernel, int bytes) {
 template <int HD, bool BF16, bool CAUSAL, bool PRE>
 int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
-    constexpr int lds = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
+    constexpr int lds_kv = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
+    constexpr int lds_epi = FA2_EPI_LDS && kQB == 1 ? kNW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
+    constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
     auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB, PRE>;
     if (int rc = set_lds(kern, lds)) return rc;

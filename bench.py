@@ -2,6 +2,7 @@
 """Forward-attention benchmark of the gfx950 FlashAttention-2 path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--no-cpu-baseline]
+                    [--steady-launches S] [--collectives] [--backend nccl|gloo] [--same-device]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -18,19 +19,34 @@ Workloads (BASELINE.json configs):
 With N > 1 ranks every rank runs the per-GPU workload on its own shard (c2/c3/c4: weak scaling,
 global batch = N x per-GPU batch; c5: strong).  Attention is independent per (batch, head), so no
 collective is on the data path; the only RCCL calls are the barriers and the max-over-ranks of the
-elapsed time.
+elapsed time.  `--collectives` additionally times, OUTSIDE the timed region and never folded into
+`value`, the edge transfers a caller with the full tensors on rank 0 would pay (SURVEY §8e timing
+rule): scatter_batch of q/k/v and gather_batch of o (rocwmma_fattn/shard.py).
+`--backend gloo --same-device` runs the multi-rank control flow with every rank on cuda:0 (NCCL
+refuses duplicate devices): the dry run the 1-GPU test suite uses; its numbers are not a scaling claim.
 
-Rank 0 prints ONE JSON line.  `value` = whole-job TFLOPS (all ranks' FLOPs / max-over-ranks wall
-time of the K steps, bracketed by barrier + synchronize).  `roofline` prices the kernel against the
-2.5 PFLOP/s dense fp16/bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md) using the average
-launch duration measured with HIP events on the launch stream.  `cpu_baseline` times the C port of
-the same algorithm (oracle/, test infrastructure) on a bounded sample of the workload on the host
-cores; `cpu_sdpa` times torch's CPU scaled_dot_product_attention — the comparator call of the
-reference harness (bench_with_sdpa.py:65-70) moved to device="cpu" — on the same sample.
+Rank 0 prints ONE JSON line.
+  value        whole-job TFLOPS: all ranks' FLOPs / max-over-ranks wall time of the K steps, bracketed
+               by barrier + synchronize (contract).
+  launch_ms    min / median / max / first / last of the K per-launch durations (HIP events on the
+               launch stream, one event between consecutive launches): after an idle period the chip
+               ramps its clock over the first tens of launches, which shows here as first > last.
+  steady       the same loop re-timed for --steady-launches launches AFTER the contractual region
+               (extra evidence, not the metric): the rate the kernel sustains once the clock has settled.
+  roofline     prices the kernel against the 2.5 PFLOP/s dense fp16/bf16 MFMA peak
+               (/opt/skills/guides/MI355X_MICROARCH.md) using the average launch duration of the timed
+               region; `sustained_peak` / `frac_sustained` use the MFMA-only micro-benchmark measured on
+               this chip under load (profiles/mfma_peak.json, tools/ubench/mfma_peak.hip) when present.
+  check        one head of the timed output against dense fp32 attention (after the timed region).
+  cpu_baseline torch CPU scaled_dot_product_attention — the comparator call of the reference harness
+               (bench_with_sdpa.py:65-70) on device="cpu", i.e. the reference's own CPU path — on a bounded
+               sample of the workload on all host cores; `cpu_port` = the C port of the algorithm
+               (oracle/, test infrastructure) on the same sample with the same thread count.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -56,65 +72,70 @@ def attention_flops(B, H, Nq, Nkv, D, causal):
 
 
 def cpu_baseline(H_total, N, D, causal, dtype, seed, budget_s=12.0):
-    """Time the C oracle (a port of the reference algorithm, oracle/fa2_oracle.c) and torch CPU SDPA
-    on a bounded sample: whole heads of the workload, as many as fit ~budget_s of CPU time."""
+    """torch CPU SDPA (the reference's CPU path) and the C oracle (a port of the reference algorithm,
+    oracle/fa2_oracle.c) on a bounded sample: whole heads of the workload, ~budget_s of CPU time each,
+    both on the same number of threads."""
     import numpy as np
     sys.path.insert(0, ROOT)
     from oracle import fa2_oracle as fo
     cores = os.cpu_count() or 1
-    threads = min(cores, fo.max_threads())
-    dt_code = fo.DTYPE_F16 if dtype == torch.float16 else fo.DTYPE_BF16
+    threads = max(1, min(cores, fo.max_threads()))
+    torch.set_num_threads(threads)
     g = torch.Generator(device="cpu").manual_seed(seed)
+    heads = int(min(H_total, 32))
+    q, k, v = (torch.rand((1, heads, N, D), generator=g, dtype=torch.float32).to(dtype) for _ in range(3))
+    sdpa = torch.nn.functional.scaled_dot_product_attention
+    sdpa(q, k, v, is_causal=causal)                      # warm-up (thread pool, pages)
+    t0 = time.perf_counter()
+    sdpa(q, k, v, is_causal=causal)
+    t_call = time.perf_counter() - t0
+    reps = int(max(3, min(200, budget_s / max(t_call, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sdpa(q, k, v, is_causal=causal)
+    t_sd = time.perf_counter() - t0
+    flops = attention_flops(1, heads, N, N, D, causal)
+    ref = {"value": round(flops * reps / t_sd / 1e12, 5), "unit": "TFLOPS", "cores": threads, "kind": "reference",
+           "sample": "torch.nn.functional.scaled_dot_product_attention on device=cpu (the reference harness's comparator "
+                     "call, bench_with_sdpa.py:65-70): %d of %d heads of the workload (N=%d D=%d %s causal=%s) x %d calls, %.2f s"
+                     % (heads, H_total, N, D, str(dtype)[6:], causal, reps, t_sd)}
 
-    def mk(h):
-        return [torch.rand((1, h, N, D), generator=g, dtype=torch.float32).to(dtype) for _ in range(3)]
+    dt_code = fo.DTYPE_F16 if dtype == torch.float16 else fo.DTYPE_BF16
 
     def bits(t):
         return t.view(torch.int16).numpy().view(np.uint16)
 
-    q, k, v = mk(1)
-    fo.fwd_c(bits(q), bits(k), bits(v), dt_code, causal, nthreads=threads)       # warm-up (thread pool, pages)
-    t0 = time.perf_counter()
     fo.fwd_c(bits(q), bits(k), bits(v), dt_code, causal, nthreads=threads)
-    t_head = time.perf_counter() - t0
-    heads = int(max(1, min(H_total, budget_s / max(t_head, 1e-6))))
-    q, k, v = mk(heads)
     t0 = time.perf_counter()
     fo.fwd_c(bits(q), bits(k), bits(v), dt_code, causal, nthreads=threads)
     t_pass = time.perf_counter() - t0
-    reps = int(max(1, min(40, budget_s / max(t_pass, 1e-6))))  # many-core hosts finish a pass in ~1 s: repeat it
+    reps = int(max(1, min(40, budget_s / max(t_pass, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         fo.fwd_c(bits(q), bits(k), bits(v), dt_code, causal, nthreads=threads)
     t_port = time.perf_counter() - t0
-    flops = attention_flops(1, heads, N, N, D, causal) * reps
-    out = {"value": round(flops / t_port / 1e12, 5), "unit": "TFLOPS", "cores": threads, "kind": "port",
-           "sample": "%d of %d heads of the workload (N=%d D=%d) x %d passes, %.2f s, oracle/fa2_oracle.c Br=32 Bc=64, OpenMP"
-                     % (heads, H_total, N, D, reps, t_port)}
-    # torch CPU SDPA on the same sample
-    torch.set_num_threads(cores)
-    sd_heads = min(heads, 32)
-    qs, ks, vs = q[:, :sd_heads], k[:, :sd_heads], v[:, :sd_heads]
-    torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=causal)
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=causal)
-    t_sd = (time.perf_counter() - t0) / reps
-    sdpa = {"value": round(attention_flops(1, sd_heads, N, N, D, causal) / t_sd / 1e12, 5), "unit": "TFLOPS",
-            "cores": cores, "kind": "torch.nn.functional.scaled_dot_product_attention on device=cpu",
-            "sample": "%d heads (N=%d D=%d), %.3f s per call" % (sd_heads, N, D, t_sd)}
-    return out, sdpa
+    port = {"value": round(flops * reps / t_port / 1e12, 5), "unit": "TFLOPS", "cores": threads, "kind": "port",
+            "sample": "oracle/fa2_oracle.c (Br=32 Bc=64, OpenMP) on the same %d heads x %d passes, %.2f s" % (heads, reps, t_port)}
+    return ref, port
 
 
-def read_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def read_json(name):
     try:
-        with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def dense_head_check(q, k, v, o, causal, b, h):
+    """max |o - dense fp32 attention| on one (batch, head) of the timed output."""
+    qf, kf, vf = q[b, h].float(), k[b, h].float(), v[b, h].float()
+    s = (qf @ kf.t()) * (q.shape[-1] ** -0.5)
+    if causal:
+        n, m = s.shape
+        s = s.masked_fill(torch.ones(n, m, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
+    ref = torch.softmax(s, -1) @ vf
+    return float((o[b, h].float() - ref).abs().max())
 
 
 def main():
@@ -124,6 +145,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)   # past the DVFS ramp-up after idle
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-launches", type=int, default=400, help="launches of the post-region steady re-timing (0 = skip)")
+    ap.add_argument("--collectives", action="store_true", help="also time scatter_batch / gather_batch (reported separately)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (dry run of the multi-rank path on one GPU)")
+    ap.add_argument("--no-backward", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,14 +161,32 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the attention operator has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    host_sync = args.backend == "gloo"     # gloo: barriers / reductions on CPU tensors
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            if host_sync:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev_index])
+
+    def max_over_ranks(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if host_sync else device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
 
     from rocwmma_fattn.FlashAttn import FlashAttentionFunction
-    from rocwmma_fattn.shard import shard_bounds
+    from rocwmma_fattn.shard import gather_batch, scatter_batch, shard_bounds
 
     B, H, N, D, dtype, causal, scaling = WORKLOADS[args.workload]
     if scaling == "strong":
@@ -156,31 +200,65 @@ def main():
                for _ in range(3))
     attn = FlashAttentionFunction.apply
 
+    # ---- contractual region: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize
     for _ in range(args.warmup):
         o = attn(q, k, v, None, causal)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()                      # torch's current stream == the stream the kernel is launched on
-    for _ in range(args.steps):
+    evs[0].record()                   # torch's current stream == the stream the kernel is launched on
+    for i in range(args.steps):
         o = attn(q, k, v, None, causal)
-    ev1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    per_launch = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    kernel_ms = evs[0].elapsed_time(evs[-1]) / args.steps
     assert torch.isfinite(o.float()).all(), "non-finite attention output"
+    check_err = dense_head_check(q, k, v, o, causal, B_local - 1, H - 1)
+    check_tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    assert check_err <= check_tol, "timed output differs from dense fp32 attention: %g" % check_err
 
-    # Informational, outside the timed region and never part of `value`: the backward of the same workload
-    # through autograd, timed the way the reference harness does (O.backward(dO, retain_graph=True) in a loop,
-    # bench_with_sdpa.py:78-88) — grads are dropped instead of zeroed so no accumulation kernels are counted.
+    # ---- steady re-timing (evidence, not the metric): same loop, after the region, clock settled
+    steady = None
+    if args.steady_launches > 0:
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(args.steady_launches):
+            o = attn(q, k, v, None, causal)
+        s1.record()
+        torch.cuda.synchronize()
+        steady_ms = s0.elapsed_time(s1) / args.steady_launches
+        steady = {"launches": args.steady_launches, "kernel_ms": round(steady_ms, 5),
+                  "tflops": round(attention_flops(B_local, H, N, N, D, causal) / (steady_ms * 1e-3) / 1e12, 2)}
+
+    # ---- edge transfers (SURVEY §8e timing rule): reported separately, never part of `value`
+    coll = None
+    if args.collectives and world > 1 and not host_sync:
+        shape = (B_global, H, N, D)
+        full = [torch.rand(shape, device=device, dtype=torch.float32).to(dtype) for _ in range(3)] if rank == 0 else [None] * 3
+        for _ in range(2):            # first pass = warm-up (communicator setup)
+            torch.cuda.synchronize(); barrier(); t0c = time.perf_counter()
+            slabs = [scatter_batch(t, shape, dtype, device, src=0) for t in full]
+            torch.cuda.synchronize(); barrier(); t_sc = time.perf_counter() - t0c
+            o_loc = attn(*slabs, None, causal)
+            torch.cuda.synchronize(); barrier(); t0c = time.perf_counter()
+            o_full = gather_batch(o_loc, B_global)
+            torch.cuda.synchronize(); barrier(); t_ga = time.perf_counter() - t0c
+        t_sc, t_ga = max_over_ranks([t_sc, t_ga])
+        nbytes = B_global * H * N * D * 2
+        coll = {"scatter_qkv_ms": round(t_sc * 1e3, 3), "gather_o_ms": round(t_ga * 1e3, 3),
+                "scatter_bytes": 3 * nbytes, "gather_bytes": nbytes,
+                "note": "root-held [B_global,H,N,D] tensors: dist.scatter x3, all_gather_into_tensor x1 over RCCL; not part of value"}
+        del full, slabs, o_full
+
+    # ---- informational backward (reference harness style, bench_with_sdpa.py:78-88), outside the timed region
     bwd = None
-    if world == 1:
+    if world == 1 and not args.no_backward:
         qg, kg, vg = (t.detach().requires_grad_(True) for t in (q, k, v))
         do = torch.rand_like(q)
         og = attn(qg, kg, vg, None, causal)
@@ -202,18 +280,24 @@ def main():
         assert all(torch.isfinite(t.grad.float()).all() for t in (qg, kg, vg)), "non-finite gradient"
         bwd = {"bwd_ms": round(bwd_ms, 4),
                "bwd_tflops": round(2.5 * attention_flops(B_local, H, N, N, D, causal) / (bwd_ms * 1e-3) / 1e12, 1),
-               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); launches: dQ (+ delta), dV, dK (dK+dV fused at D <= 64)"}
+               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41)"}
 
-    times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms = float(times[0]), float(times[1])
+    elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms])
 
     if rank == 0:
         flops_global = attention_flops(B_global, H, N, N, D, causal)
         flops_local = attention_flops(B_local, H, N, N, D, causal)
         value = flops_global * args.steps / elapsed / 1e12
         achieved = flops_local / (kernel_ms * 1e-3) / 1e12
+        peak_rec = read_json("mfma_peak.json")
+        sustained = peak_rec.get("sustained_tflops_f16" if dtype == torch.float16 else "sustained_tflops_bf16")
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": read_json("hbm_traffic.json").get(args.workload, {}).get("hbm_bytes_per_launch"),
+                "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_local}
+        if sustained:
+            roof["sustained_peak"] = sustained
+            roof["frac_sustained"] = round(achieved / sustained, 4)
         line = {
             "metric": "fwd attention TFLOPS (and % MFMA roofline) at B2 H16 N4096 D128 fp16",
             "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,15 +306,23 @@ def main():
             "config": {"workload": "%s: B%d H%d N%d D%d %s causal=%s per GPU, BHND, torch.rand U[0,1)"
                                    % (args.workload, B_local, H, N, D, str(dtype)[6:], causal),
                        "global_batch": B_global, "parallelism": "batch-shard x%d (no data-path collective)" % world},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": read_traffic(args.workload),
-                         "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_local},
+            "roofline": roof,
             "pct_of_mfma_roofline": round(100.0 * value / (MFMA_PEAK_TFLOPS * world), 2),
+            "launch_ms": {"min": round(min(per_launch), 5), "median": round(statistics.median(per_launch), 5),
+                          "max": round(max(per_launch), 5), "first": round(per_launch[0], 5), "last": round(per_launch[-1], 5)},
+            "check": {"max_abs_err_vs_dense_fp32": round(check_err, 6), "tol": check_tol, "head": [B_local - 1, H - 1]},
         }
+        if steady is not None:
+            line["steady"] = steady
+        if args.backend != "nccl" or args.same_device:
+            line["dry_run"] = "backend=%s same_device=%s: control-flow check of the multi-rank path, not a scaling measurement" % (
+                args.backend, args.same_device)
+        if coll is not None:
+            line["collectives"] = coll
         if bwd is not None:
             line["backward"] = bwd
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["cpu_sdpa"] = cpu_baseline(B * H, N, D, causal, dtype, 1234 + cfg_idx)
+            line["cpu_baseline"], line["cpu_port"] = cpu_baseline(B * H, N, D, causal, dtype, 1234 + cfg_idx)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -55,6 +55,14 @@
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
+#ifndef FA2_TILE_IN_SOFFSET   // 0: a tile's byte offset is added to the per-lane voffset, which the buffer bounds check
+#define FA2_TILE_IN_SOFFSET 0  // covers (rows >= Nkv of the ragged last tile read 0); 1: it rides in soffset, which LLVM
+#endif                         // documents as excluded from the bounds check (saves 4 v_add per tile)
+#if FA2_TILE_IN_SOFFSET
+#define FA2_TILE_OFF(voff, soff) (voff), (soff)
+#else
+#define FA2_TILE_OFF(voff, soff) (voff) + (soff), 0u
+#endif
 // Tried and dropped (git history has the code; DESIGN.md §3 the measurements): s_setprio variants, 2- and 3-phase
 // ping-pong of the two waves of a SIMD, issuing all LDS fragment reads of a phase up front, packed-f32 softmax math.
 
@@ -112,21 +120,6 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
 }
 
-// one dword of two 16-bit floats times an f32 factor, rounded back to 16 bits (RNE)
-template <bool BF16>
-__device__ __forceinline__ uint32_t scale2(uint32_t w, float f) {
-    float lo, hi;
-    if constexpr (BF16) {
-        lo = __uint_as_float(w << 16);
-        hi = __uint_as_float(w & 0xffff0000u);
-    } else {
-        const f32x2 x = __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
-        lo = x[0];
-        hi = x[1];
-    }
-    return pack2<BF16>(lo * f, hi * f);
-}
-
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -179,15 +172,7 @@ struct Geo {
 // [128,256)): a 256-wide f32 O accumulator plus the Q fragments would not fit 256 VGPRs, so QK^T is
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 //
-// PRE ("pre-scaled Q", opt-in: host.cpp FA2_PRESCALE_MAX_HD; fits HD = 64 where the registers are there): Q is multiplied by c = |scale|*log2(e)
-// once and rounded back to 16 bits — the reference oracle's own contract, `scale * q_frags`
-// (pure_torch_ver.py:61) — and a tile's first QK^T MFMAs take C = -m (16 registers that all hold the
-// negated running reference) instead of C = 0, so the MFMA chain delivers s*c - m and the v_fma in front of
-// every v_exp disappears (-32 of ~180 VALU/LDS instructions per tile; +4 % at D = 64).  LSE then carries the
-// 16-bit rounding of q*c: measured 3e-4 (fp16) / 6e-3 (bf16) against 3e-6 without it — the reference's own L
-// is 6e-3 / 5e-2 off the float64 truth on the golden fixtures.  The host only selects PRE kernels when c <= 1
-// (the product cannot overflow fp16).
-template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool PRE = false>
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
 __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
@@ -253,12 +238,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
             for (int ks = 0; ks < KS_QK; ++ks) qf[qb][ks] ^= (u32x4){sgn, sgn, sgn, sgn};
         }
-        if constexpr (PRE) {
-#pragma unroll
-            for (int ks = 0; ks < KS_QK; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) qf[qb][ks][i] = scale2<BF16>(qf[qb][ks][i], p.c);
-        }
     }
 
     // ---- K/V staging: buffer descriptors of this head's matrices (out-of-range rows read 0)
@@ -309,19 +288,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const int nt_w = (qw0 + kRowsPerWave - 1) / kKvTile + 1;
         ntiles_w = nt_w < ntiles ? nt_w : ntiles;
     }
-    // hide ntiles_w == ntiles from the non-causal build, which otherwise specialises its tail loops
-    if constexpr (PRE) asm volatile("" : "+s"(ntiles_w));
 
     f32x16 acc[QB][DT];
-    float m_run[QB], l_run[QB];  // running reference max (raw score units; PRE: log2 units) / row sum (this lane's kv half)
-    float negm[QB][16];          // PRE: -m_run, 16 separately named copies that the allocator keeps as one MFMA C tuple
+    float m_run[QB], l_run[QB];  // running reference max (raw score units) / row sum (this lane's kv half)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = PRE ? 0.f : -INFINITY;
-        if constexpr (PRE) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; asm volatile("" : "+v"(negm[qb][r])); }
-        }
+        m_run[qb] = -INFINITY;
         l_run[qb] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -357,16 +329,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
         const uint32_t soff = (uint32_t)tile * kKvTile * k_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            if constexpr (kDma) dma16_to_lds(krs, smem + buf * TILEB + (wave * 64 + kThreads * i) * 16, kd_off[i], soff);
-            else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kg_off[i], soff, 0);
+            if constexpr (kDma) dma16_to_lds(krs, smem + buf * TILEB + (wave * 64 + kThreads * i) * 16, FA2_TILE_OFF(kd_off[i], soff));
+            else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, FA2_TILE_OFF(kg_off[i], soff), 0);
         }
     };
     auto load_v = [&](int tile, int buf) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
         for (int i = 0; i < VNPASS; ++i) {
-            if constexpr (kDma) dma16_to_lds(vrs, smem + VBASE + buf * VTILEB + (wave * 64 + kThreads * i) * 16, vd_off[i], soff);
-            else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vg_off[i], soff, 0);
+            if constexpr (kDma) dma16_to_lds(vrs, smem + VBASE + buf * VTILEB + (wave * 64 + kThreads * i) * 16, FA2_TILE_OFF(vd_off[i], soff));
+            else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, FA2_TILE_OFF(vg_off[i], soff), 0);
         }
     };
     auto write_k = [&](int buf) __attribute__((always_inline)) {
@@ -389,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[qb][0][r] = s[qb][1][r] = PRE ? negm[qb][r] : 0.f; }
+            for (int r = 0; r < 16; ++r) { s[qb][0][r] = s[qb][1][r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS_QK; ++ks) {
             const u32x4 a0 = *(const u32x4*)(kt + kr_off[ks]);
@@ -408,10 +380,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
-    // PRE: the scores arrive as s*c - m_old; `first` (tile 0) adopts the tile's own maximum whatever its sign.
-    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], bool first = false) __attribute__((always_inline)) {
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
         float mx[QB];
-        bool grow = FA2_DEFER_THR < 0.f || (PRE && first);
+        bool grow = FA2_DEFER_THR < 0.f;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             f32x16& s0 = s[qb][0];
@@ -443,32 +414,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             m = __builtin_fmaxf(m, s1[15]);
             mx[qb] = half_swap_max(m);
             if (!(FA2_DEFER_THR < 0.f))
-                grow = grow || (__builtin_amdgcn_ballot_w64((PRE ? mx[qb] : (mx[qb] - m_run[qb]) * c) > FA2_DEFER_THR) != 0);
+                grow = grow || (__builtin_amdgcn_ballot_w64((mx[qb] - m_run[qb]) * c > FA2_DEFER_THR) != 0);
         }
-        if (PRE && grow) {
-            // this tile's scores were formed against the old reference: shift them, the reference and the
-            // accumulated row by the growth d
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float d = first ? mx[qb] : __builtin_fmaxf(mx[qb], 0.f);
-                if (d == -INFINITY) d = 0.f;
-                const float alpha = __builtin_amdgcn_exp2f(-d);
-                m_run[qb] += d;
-                l_run[qb] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    negm[qb][r] = -m_run[qb];
-                    asm volatile("" : "+v"(negm[qb][r]));   // keep 16 distinct values (no CSE into one register)
-                    s[qb][0][r] -= d;
-                    s[qb][1][r] -= d;
-                }
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[qb][dt][r] *= alpha;
-            }
-        }
-        if (!PRE && grow) {
+        if (grow) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const float m_new = __builtin_fmaxf(m_run[qb], mx[qb]);
@@ -494,8 +442,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(PRE ? s0[r] : __builtin_fmaf(s0[r], c, -mc));
-                s1[r] = __builtin_amdgcn_exp2f(PRE ? s1[r] : __builtin_fmaf(s1[r], c, -mc));
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
                 rs0 += s0[r];
                 rs1 += s1[r];
             }
@@ -570,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     f32x16 sa[QB][2], sb[QB][2];
     qk(0, sa);
     __syncthreads();   // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us
-    finish_scores(0, std::true_type{}, sa, true);
+    finish_scores(0, std::true_type{}, sa);
 
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
@@ -626,7 +574,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
             }
         }
         if (qrow[0] < p.Nq && hi == 0 && vcol0 == 0)
-            p.lse[b * p.ls[0] + h * p.ls[1] + qrow[0]] = (PRE ? m_run[0] : m_run[0] * c) + __builtin_amdgcn_logf(l_tot);
+            p.lse[b * p.ls[0] + h * p.ls[1] + qrow[0]] = m_run[0] * c + __builtin_amdgcn_logf(l_tot);
         // read back row-major (wave-private image: the compiler's lgkmcnt wait orders write -> read)
         const int rl = lane / LPR, cl = lane % LPR;              // row within the group of RPI rows, 16-B piece within the row
         uint16_t* obase = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + vcol0;
@@ -663,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
                 }
             }
             if (hi == 0 && vcol0 == 0)
-                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = (PRE ? m_run[qb] : m_run[qb] * c) + __builtin_amdgcn_logf(l_tot);
+                p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = m_run[qb] * c + __builtin_amdgcn_logf(l_tot);
         }
     }
 }

@@ -13,6 +13,7 @@
 #include "fa2_fwd_kernel.hip.h"
 #include "fa2_bwd_kernel.hip.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 
@@ -33,46 +34,36 @@ constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 constexpr int kNW = FA2_NW, kQB = FA2_QB;
 constexpr int kFwdRows = kNW * kQB * 32;   // Q rows per forward workgroup
 
-// Kernels that need more than 64 KiB of dynamic LDS must be opted in once per (kernel, device).
-template <typename K>
-int set_lds(K kernel, int bytes) {
+// Kernels that need more than 64 KiB of dynamic LDS must be opted in once per (kernel, device).  The cache is keyed on
+// the kernel itself (a non-type template parameter: one flag array per instantiation, not per function-pointer type).
+template <auto Kernel>
+int set_lds(int bytes) {
     if (bytes <= 64 * 1024) return 0;
-    static bool done[64] = {false};          // one flag set per template instantiation (= per kernel)
+    static std::atomic<bool> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (dev >= 0 && done[dev]) return 0;
-    const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (rc == 0 && dev >= 0) done[dev] = true;
+    if (dev >= 0 && done[dev].load(std::memory_order_acquire)) return 0;
+    const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == 0 && dev >= 0) done[dev].store(true, std::memory_order_release);
     return rc;
 }
 
-// Head dims up to this run the pre-scaled-Q kernels (fa2_fwd_kernel.hip.h, "PRE").  Off by default: +3 % at D = 64, but
-// the 16-bit rounding of q*scale costs accuracy in proportion to the logits (max |O - truth| 1.3e-2 instead of 1e-3 on
-// the several-hundred-logit stress input of tests/test_parity_gpu.py); build with -DFA2_PRESCALE_MAX_HD=64 to opt in.
-#ifndef FA2_PRESCALE_MAX_HD
-#define FA2_PRESCALE_MAX_HD 0
-#endif
-
-template <int HD, bool BF16, bool CAUSAL, bool PRE>
+template <int HD, bool BF16, bool CAUSAL>
 int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
     constexpr int lds_kv = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
     constexpr int lds_epi = FA2_EPI_LDS && kQB == 1 ? kNW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
     constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
-    auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB, PRE>;
-    if (int rc = set_lds(kern, lds)) return rc;
+    constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB>;
+    if (int rc = set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(kNW * 64), lds, stream, p);
     return (int)hipGetLastError();
 }
 
 template <int HD, bool BF16>
 int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
-    if constexpr (HD <= FA2_PRESCALE_MAX_HD && kQB == 1) {
-        if (p.c <= 1.0f)   // q*c cannot leave the fp16 range; larger scales keep the f32 scaling path
-            return causal ? launch_t<HD, BF16, true, true>(p, stream) : launch_t<HD, BF16, false, true>(p, stream);
-    }
-    return causal ? launch_t<HD, BF16, true, false>(p, stream) : launch_t<HD, BF16, false, false>(p, stream);
+    return causal ? launch_t<HD, BF16, true>(p, stream) : launch_t<HD, BF16, false>(p, stream);
 }
 
 #ifndef FA2_BWD_FUSE_MAX_HD          // head dims up to this run dK and dV as one fused pass
@@ -87,8 +78,8 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     int rc;
     {   // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass
         constexpr int lds = kStages * 3 * TILEB;
-        auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, NW>;
-        if ((rc = set_lds(kern, lds))) return rc;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, NW>;
+        if ((rc = set_lds<kern>(lds))) return rc;
         p.nblk = (p.Nq + kRows - 1) / kRows;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
@@ -97,22 +88,22 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     if constexpr (HD <= FA2_BWD_FUSE_MAX_HD && NW == 8) {
         // D = 64: both accumulators fit, one sweep forms S and P once for dK and dV
         constexpr int lds = kStages * (4 * TILEB + 512);
-        auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW, true>;
-        if ((rc = set_lds(kern, lds))) return rc;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW, true>;
+        if ((rc = set_lds<kern>(lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         return (int)hipGetLastError();
     } else {
         {
             constexpr int lds = kStages * (2 * TILEB + 512);
-            auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false, NW>;
-            if ((rc = set_lds(kern, lds))) return rc;
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, false, NW>;
+            if ((rc = set_lds<kern>(lds))) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
             if ((rc = (int)hipGetLastError())) return rc;
         }
         {
             constexpr int lds = kStages * (3 * TILEB + 512);
-            auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW>;
-            if ((rc = set_lds(kern, lds))) return rc;
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, BF16, CAUSAL, true, NW>;
+            if ((rc = set_lds<kern>(lds))) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
             if ((rc = (int)hipGetLastError())) return rc;
         }
@@ -153,9 +144,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 }
 
 int fa2_fwd_prescales_q(int D, float scale) {
-    const int HD = fa2_padded_head_dim(D);
-    if (HD < 0) return -1;
-    return kQB == 1 && HD <= FA2_PRESCALE_MAX_HD && std::fabs(scale) * 1.4426950408889634f <= 1.0f;
+    (void)scale;
+    return fa2_padded_head_dim(D) < 0 ? -1 : 0;   // scores are always scaled in f32 (the pre-scaled-Q build option was removed)
 }
 
 const char* fa2_error_string(int code) {
@@ -192,7 +182,8 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
         return FA2_ERR_ALIGNMENT;
     const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2;
     const int64_t v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
-    if (k_bytes > 0x7fffffffLL || v_bytes > 0x7fffffffLL) return FA2_ERR_BAD_SHAPE;   // (fa2::kOobOffset relies on < 2 GiB)
+    // fa2::kOobOffset relies on every in-range offset, plus one tile of rows past the end, staying below 2 GiB
+    if (k_bytes + 64 * k_strides[2] * 2 > 0x7fffffffLL || v_bytes + 64 * v_strides[2] * 2 > 0x7fffffffLL) return FA2_ERR_BAD_SHAPE;
 
     fa2::FwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
@@ -202,6 +193,9 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     }
     p.ls[0] = lse_strides[0]; p.ls[1] = lse_strides[1];
     p.c = std::fabs(scale) * 1.4426950408889634f;  // fold log2(e): reference kernel_fp16.cu:827
+    // scale == 0 is the uniform softmax (O = mean of V, as the reference's arithmetic gives).  With c == 0 the first
+    // tile's (max - (-inf)) * c would be NaN; a factor too small to move any f32 score off zero gives the same result.
+    if (p.c < 1e-30f) p.c = 1e-30f;
     p.negate_q = scale < 0.f;
     p.nqblk = (Nq + kFwdRows - 1) / kFwdRows;
     p.k_bytes = (uint32_t)k_bytes;
@@ -238,7 +232,9 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
         if (!aligned16(ptrs[i]) || !strides_ok(strides[i])) return FA2_ERR_ALIGNMENT;
     const int64_t q_bytes = ((int64_t)(Nq - 1) * q_strides[2] + D) * 2, do_bytes = ((int64_t)(Nq - 1) * do_strides[2] + D) * 2;
     const int64_t k_bytes = ((int64_t)(Nkv - 1) * k_strides[2] + D) * 2, v_bytes = ((int64_t)(Nkv - 1) * v_strides[2] + D) * 2;
-    if (q_bytes > 0x7fffffffLL || do_bytes > 0x7fffffffLL || k_bytes > 0x7fffffffLL || v_bytes > 0x7fffffffLL)
+    const int64_t lim = 0x7fffffffLL;   // + one tile of rows past the end: masked lanes add fa2::kOobOffset to such an offset
+    if (q_bytes + 64 * q_strides[2] * 2 > lim || do_bytes + 64 * do_strides[2] * 2 > lim || k_bytes + 64 * k_strides[2] * 2 > lim ||
+        v_bytes + 64 * v_strides[2] * 2 > lim)
         return FA2_ERR_BAD_SHAPE;
     const int64_t blocks = (int64_t)B * H * (((Nq > Nkv ? Nq : Nkv) + fa2::kQBlock - 1) / fa2::kQBlock);
     if (blocks > 0x7fffffffLL || (int64_t)B * H * Nq / 16 > 0x7fffffffLL) return FA2_ERR_GRID;

@@ -15,6 +15,7 @@ import torch  # noqa: F401
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "libfa2_gfx950.so")
+_OVERRIDE = os.environ.get("FA2_GFX950_LIB")      # developer A/B: load this build of the library instead (never built here)
 
 FA2_DTYPE_F16 = 0
 FA2_DTYPE_BF16 = 1
@@ -60,11 +61,17 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise RuntimeError("fa2: %s is missing; run `python %s`" % (LIB_PATH, os.path.join(_PKG_DIR, "build.py")))
-        _build_module().build()
-    lib = ctypes.CDLL(LIB_PATH)
+    # build() compiles only when the library is missing or older than its sources (stamp = digest of sources + flags),
+    # so a stale .so is never used silently after a kernel edit.
+    if _OVERRIDE:
+        lib_path = _OVERRIDE
+    elif build_if_missing:
+        lib_path = _build_module().build()
+    else:
+        lib_path = LIB_PATH
+    if not os.path.exists(lib_path):
+        raise RuntimeError("fa2: %s is missing; run `python %s`" % (LIB_PATH, os.path.join(_PKG_DIR, "build.py")))
+    lib = ctypes.CDLL(lib_path)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype

@@ -140,11 +140,10 @@ int fa2_padded_head_dim(int D);
  * the counterparts of the reference's Br / Bc, FlashAttn.py:56-67). */
 int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
 
-/* Where the softmax scale is applied (numerical contract, informational).  Returns 1 when the forward kernel
- * for head dim D and this scale multiplies Q by scale*log2(e) and rounds it back to the I/O dtype before
- * Q.K^T — the reference oracle's contract, `scale * q_frags` (pure_torch_ver.py:61) — and 0 when it scales the
- * f32 product afterwards, as the reference kernel does (kernel_fp16.cu:164).  Both are within the tolerances of
- * tests/conftest.py; LSE carries the 16-bit rounding of q*scale in the first case.  -1: D not supported. */
+/* Where the softmax scale is applied (numerical contract, informational).  Returns 0: every forward kernel scales the
+ * f32 Q.K^T product, as the reference kernel does (kernel_fp16.cu:164), never Q itself (the reference oracle's
+ * `scale * q_frags`, pure_torch_ver.py:61, costs LSE accuracy in proportion to the logits; a build option that did so
+ * at D = 64 was removed).  Kept so that callers written against 0.4 keep linking.  -1: D not supported. */
 int fa2_fwd_prescales_q(int D, float scale);
 
 /* Text for a return code of this library (validation codes and hipError_t values). */

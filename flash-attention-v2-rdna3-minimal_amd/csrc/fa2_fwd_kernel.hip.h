@@ -55,9 +55,9 @@
 #ifndef FA2_IGLP             // __builtin_amdgcn_iglp_opt(n) in the steady-state step; -1 = none.  0: +1-2 %; 1: -18 %;
 #define FA2_IGLP 0           // explicit uniform sched_group_barrier pipelines (1 MFMA : 4-6 VALU : 1-2 DS): -10 %
 #endif
-#ifndef FA2_TILE_IN_SOFFSET   // 0: a tile's byte offset is added to the per-lane voffset, which the buffer bounds check
-#define FA2_TILE_IN_SOFFSET 0  // covers (rows >= Nkv of the ragged last tile read 0); 1: it rides in soffset, which LLVM
-#endif                         // documents as excluded from the bounds check (saves 4 v_add per tile)
+#ifndef FA2_TILE_IN_SOFFSET   // 1: a tile's byte offset rides in the buffer instruction's soffset (no VALU, 7 fewer VGPRs); 0: it is
+#define FA2_TILE_IN_SOFFSET 1  // added to the per-lane voffset.  LLVM documents soffset as excluded from the bounds check, but on gfx950
+#endif                         // it is included: tests/test_parity_gpu.py::test_ragged_tail_ignores_memory_past_nkv passes with both
 #if FA2_TILE_IN_SOFFSET
 #define FA2_TILE_OFF(voff, soff) (voff), (soff)
 #else

@@ -102,19 +102,22 @@ int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
-    std::vector<unsigned short> h_f16(8 * 512 * 8), h_bf16(8 * 512 * 8);
+    std::vector<unsigned short> h_f16(8 * 512 * 8), h_bf16(8 * 512 * 8), h_u01(8 * 512 * 8);
     srand(1234);
     for (size_t i = 0; i < h_f16.size(); ++i) {
         const float x = 2.f * (float)rand() / (float)RAND_MAX - 1.f;
         h_f16[i] = f32_to_f16_bits(x);
         h_bf16[i] = f32_to_bf16_bits(x);
+        h_u01[i] = f32_to_f16_bits(0.5f * (x + 1.f));     // U[0,1): the distribution of bench.py's q/k/v (torch.rand)
     }
-    u32x4 *d_f16, *d_bf16, *d_zero;
+    u32x4 *d_f16, *d_bf16, *d_zero, *d_u01;
     float* d_out;
     const size_t bytes = h_f16.size() * 2;
     CHECK(hipMalloc(&d_f16, bytes));
     CHECK(hipMalloc(&d_bf16, bytes));
     CHECK(hipMalloc(&d_zero, bytes));
+    CHECK(hipMalloc(&d_u01, bytes));
+    CHECK(hipMemcpy(d_u01, h_u01.data(), bytes, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, (size_t)n_cu * 512 * 4));
     CHECK(hipMemcpy(d_f16, h_f16.data(), bytes, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_bf16, h_bf16.data(), bytes, hipMemcpyHostToDevice));
@@ -127,6 +130,8 @@ int main() {
     const double f16_w1 = run<false, 256>(d_f16, d_out, n_cu, settle, timed, &ms);   const double f16_w1_ms = ms;
     const double bf16_w2 = run<true, 512>(d_bf16, d_out, n_cu, settle, timed, &ms);  const double bf16_w2_ms = ms;
     const double bf16_w1 = run<true, 256>(d_bf16, d_out, n_cu, settle, timed, &ms);  const double bf16_w1_ms = ms;
+    const double u01_w2 = run<false, 512>(d_u01, d_out, n_cu, settle, timed, &ms);   const double u01_w2_ms = ms;
+    const double u01_w1 = run<false, 256>(d_u01, d_out, n_cu, settle, timed, &ms);   const double u01_w1_ms = ms;
     const double zero_w2 = run<false, 512>(d_zero, d_out, n_cu, settle, timed, &ms); const double zero_w2_ms = ms;
     // cold: 20 launches straight after >= 1 s of idle (what a short driver-run benchmark sees)
     CHECK(hipDeviceSynchronize());
@@ -143,9 +148,12 @@ int main() {
     printf(" \"f16_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", f16_w1, f16_w1_ms, cyc / (f16_w1_ms * 1e-3) / 1e9);
     printf(" \"bf16_2waves_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", bf16_w2, bf16_w2_ms, cyc / (bf16_w2_ms * 1e-3) / 1e9);
     printf(" \"bf16_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", bf16_w1, bf16_w1_ms, cyc / (bf16_w1_ms * 1e-3) / 1e9);
+    printf(" \"f16_uniform01_2waves_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", u01_w2, u01_w2_ms, cyc / (u01_w2_ms * 1e-3) / 1e9);
+    printf(" \"f16_uniform01_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", u01_w1, u01_w1_ms, cyc / (u01_w1_ms * 1e-3) / 1e9);
     printf(" \"f16_zero_operands_2waves\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", zero_w2, zero_w2_ms, cyc / (zero_w2_ms * 1e-3) / 1e9);
     printf(" \"f16_cold_20_launches_after_idle\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", cold, cold_ms);
-    printf(" \"sustained_tflops_f16\": %.1f,\n", f16_w2 > f16_w1 ? f16_w2 : f16_w1);
+    printf(" \"sustained_tflops_f16_signed\": %.1f,\n", f16_w2 > f16_w1 ? f16_w2 : f16_w1);
+    printf(" \"sustained_tflops_f16\": %.1f,\n", u01_w2 > u01_w1 ? u01_w2 : u01_w1);   // operands distributed like bench.py's inputs
     printf(" \"sustained_tflops_bf16\": %.1f\n", bf16_w2 > bf16_w1 ? bf16_w2 : bf16_w1);
     printf("}\n");
     return 0;

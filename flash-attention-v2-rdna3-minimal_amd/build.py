@@ -23,7 +23,9 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 STAMP_PATH = LIB_PATH + ".stamp"
 
 SOURCES = ["host.cpp"]
-HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h")]
+HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
+           os.path.join("gen", "isa.py"), os.path.join("gen", "fwd_d128_gen.py")]
+GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_clobbers.inc"]   # written by gen/fwd_d128_gen.py
 
 HIPCC_FLAGS = [
     "-x", "hip",
@@ -53,6 +55,13 @@ def _source_digest():
     return h.hexdigest()
 
 
+def generate():
+    """Run the asm generator: the hand-scheduled D = 128 forward body is emitted as .inc files next to the kernels."""
+    res = subprocess.run([sys.executable, os.path.join(CSRC, "gen", "fwd_d128_gen.py")], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("fwd_d128_gen.py failed:\n%s\n%s" % (res.stdout, res.stderr))
+
+
 def is_current():
     if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
         return False
@@ -65,6 +74,7 @@ def build(force=False, verbose=False):
     digest = _source_digest()
     if not force and is_current():
         return LIB_PATH
+    generate()
     cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()

@@ -11,11 +11,13 @@
 // launch is asynchronous on the caller's stream, and failures are returned, not printf'ed
 // (reference: kernel_fp16.cu:854-863).
 #include "fa2_fwd_kernel.hip.h"
+#include "fa2_fwd_d128.hip.h"
 #include "fa2_bwd_kernel.hip.h"
 
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "fa2_gfx950.h"
 
@@ -61,8 +63,36 @@ int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// Head dim exactly 128 with a positive scale runs the hand-scheduled 4-wave kernel (fa2_fwd_d128.hip.h); FA2_FWD_D128=hip
+// in the environment selects the compiler-scheduled 8-wave kernel instead (A/B measurements, tools/kbench.py).
+#ifndef FA2_D128_ASM
+#define FA2_D128_ASM 1      // build-time default of the switch below
+#endif
+bool use_d128_asm() {
+    static const bool on = [] {
+        const char* e = std::getenv("FA2_FWD_D128");
+        if (e && e[0] == 'h') return false;
+        if (e && e[0] == 'a') return true;
+        return FA2_D128_ASM != 0;
+    }();
+    return on;
+}
+
+template <bool BF16, bool CAUSAL>
+int launch_d128(const fa2::FwdParams& p, hipStream_t stream) {
+    static_assert(kFwdRows == 256, "the d128 kernel covers 256 Q rows per workgroup, like the default shape");
+    constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL>;
+    if (int rc = set_lds<kern>(fa2::kD128LdsBytes)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nqblk)), dim3(256), fa2::kD128LdsBytes, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <int HD, bool BF16>
 int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    if constexpr (HD == 128) {
+        if (p.D == 128 && !p.negate_q && use_d128_asm())
+            return causal ? launch_d128<BF16, true>(p, stream) : launch_d128<BF16, false>(p, stream);
+    }
     return causal ? launch_t<HD, BF16, true>(p, stream) : launch_t<HD, BF16, false>(p, stream);
 }
 

@@ -41,7 +41,7 @@ THR = 8.0            # deferred rescale threshold, log2 units (FA2_DEFER_THR of 
 NEG_INF = float("-inf")
 
 # ---- inline-asm operands (order = the operand list of the asm statement in fa2_fwd_d128.hip.h)
-A_LSE0, A_LSE1 = Arg(0), Arg(1)                    # "=v" outputs: log2-domain LSE of this lane's row in q block 0 / 1
+A_LSE0, A_LSE1 = Arg(0), Arg(1)                    # "=&v" outputs: log2-domain LSE of this lane's row in q block 0 / 1
 A_Q0, A_Q1 = Arg(2, "v", 2), Arg(3, "v", 2)        # 64-bit global address of this lane's 16 Q bytes (k-step 0) in block 0 / 1
 A_KRS, A_VRS = Arg(4, "s", 4), Arg(5, "s", 4)      # buffer descriptors of this head's K / V matrix
 A_KD0, A_VD0 = Arg(6), Arg(7)                      # per-lane LDS-DMA source byte offset (piece 0, tile 0), K / V
@@ -50,8 +50,8 @@ A_LIM0, A_LIM1 = Arg(10), Arg(11)                  # last-tile mask: kv index (l
 A_C = Arg(12, "s")                                 # scale * log2(e), f32 bits
 A_NTW, A_NTWG = Arg(13, "s"), Arg(14, "s")         # KV tiles of this wave / of the workgroup
 A_KTILE, A_VTILE = Arg(15, "s"), Arg(16, "s")      # bytes between consecutive KV tiles in K / V
-A_KROW16, A_VROW16 = Arg(17, "s"), Arg(18, "s")    # bytes of 16 rows of K / V (stride between DMA pieces)
-A_LDSW = Arg(19, "s")                              # wave * 1024: this wave's slice of a DMA piece
+A_KROW4, A_VROW4 = Arg(17, "s"), Arg(18, "s")      # 4 * row bytes - 1024: source stride between the DMA pieces of a wave
+A_LDSW = Arg(19, "s")                              # wave * 4096: this wave's quarter of a tile image
 A_EPI = Arg(20)                                    # per-lane LDS byte address of the epilogue image: row l31, half hi
 N_ARGS = 21
 
@@ -67,28 +67,35 @@ def VF(dt, ks):                                    # V^T fragment (4 VGPRs)
     return V(152 + 16 * ks + 4 * dt, 4)
 
 
-KR = [V(216 + i) for i in range(8)]
-VR = [V(224 + i) for i in range(4)]
-MREF = [V(228), V(229)]                            # running reference max (raw score units)
-MC = [V(230), V(231)]                              # MREF * c
-LA = [V(232), V(233)]                              # running row sums (two chains per q block)
-LB = [V(234), V(235)]
-FSC = [V(236), V(237)]                             # pending O rescale factor
-MXA = [V(238), V(239)]                             # row-max chains
-MXB = [V(240), V(241)]
-TMP = [V(242 + i) for i in range(10)]              # v242..v251
-NEGINF = V(252)
-T2 = [V(253), V(254), V(255)]
+KR = [V(216 + i) for i in range(8)]                # K fragment read addresses, k-step ks
+VR = [V(224 + i) for i in range(4)]                # V^T fragment read addresses, d block dt
+KD = [V(228 + i) for i in range(4)]                # LDS-DMA source offsets of this wave's 4 pieces of a K tile
+VD = [V(232 + i) for i in range(4)]
+SPARE = [V(236), V(237)]
+LSUM = [V(238, 2), V(240, 2)]                      # running row sums, two chains (even / odd elements) per q block
+LA = [LSUM[0][0], LSUM[1][0]]
+LB = [LSUM[0][1], LSUM[1][1]]
+FSC = [V(242), V(243)]                             # pending O rescale factor
+CPAIR = V(244, 2)                                  # {c, c} (packed-f32 option)
+MCP = [V(246, 2), V(248, 2)]                       # reference max * c (second register: copy for the packed-f32 option)
+MC = [MCP[0][0], MCP[1][0]]
+TMP = [V(250 + i) for i in range(6)] + SPARE       # 8 scratch registers: row-max chains, rescale block, epilogue
+EP_LT, EP_T, EP_INV = V(242), V(243), V(244)       # epilogue scratch (the softmax state above is dead by then)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
-S_KR2, S_KR3, S_VR2, S_VR3, S_NFAST, S_D = S(66), S(67), S(68), S(69), S(70), S(71)
-S_T2, S_T3 = S(72), S(73)
-CLOBBER_S = list(range(60, 74))
+S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
+S_TA, S_TB, S_TC = S(74, 2), S(76, 2), S(78, 2)      # "trace" builds: s_memtime samples (body start, phase boundary, body end)
+S_SUM = [S(80), S(81), S(82), S(83)]                 # cycle sums over the fast bodies: PV phase, QK phase, barrier, bodies
+S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, first main body, epilogue start, block end
+CLOBBER_S = list(range(60, 94))
 CLOBBER_V = list(range(VBASE, 256))
 
 K_SLOT, V_BASE, SLOT_B = 0, 32768, 16384
 EPI_ROWB = 272                                     # bytes per staged O row (256 + 16 pad)
 LDS_BYTES = 4 * 64 * EPI_ROWB                      # 69632: the epilogue image is the high-water mark
+
+# relative issue cost of the instruction classes (the scheduler balances this, not the instruction count)
+WEIGHT = {"valu": 1.0, "trans": 1.7, "lds": 1.6, "dma": 3.5, "salu": 0.4, "branch": 0.5, None: 0.0}
 
 
 def OACC(qb, dt):
@@ -103,8 +110,22 @@ def KF(kvb, ks):
     return A(192 + 32 * kvb + 4 * ks, 4)
 
 
+def _weight(item):
+    if isinstance(item, list):
+        return sum(_weight(i) for i in item)
+    return 0.0 if item.op == "label" else WEIGHT.get(item.tag, 1.0)
+
+
 class Gen:
-    def __init__(self, bf16=False):
+    # Tunables of the schedule (gap windows [a, b) of the filler streams of a body), code-generation options, and
+    # timing-only ablations ("abl": stream names left out of the FAST bodies — wrong results, tools/kbench.py prices the parts)
+    DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 58.0), "kread": (0.0, 31.0), "dma": (3.0, 22.0),
+                "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0)}
+
+    def __init__(self, bf16=False, **cfg):
+        self.cfg = dict(self.DEFAULTS)
+        self.cfg.update(cfg)
+        self.opt = set(self.cfg["opt"])
         self.bf16 = bf16
         self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if bf16 else "v_cvt_pk_f16_f32"
@@ -121,79 +142,95 @@ class Gen:
                 out.append(mk(self.mfma, OACC(qb, dt), VF(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
         return out
 
-    def qk_mfmas(self, par, qb):
+    def qk_mfmas(self, par):
+        """S(t+2) for both q blocks; the four 32x32 accumulators take turns (a dependent MFMA is four issues away)."""
         out = []
         for ks in range(8):
-            for kvb in range(2):
-                dst = SB(qb, par).sub(16 * kvb, 16)
-                out.append(mk(self.mfma, dst, KF(kvb, ks), QF(qb, ks), 0 if ks == 0 else dst, tag="mfma"))
+            for qb in range(2):
+                for kvb in range(2):
+                    dst = SB(qb, par).sub(16 * kvb, 16)
+                    out.append(mk(self.mfma, dst, KF(kvb, ks), QF(qb, ks), 0 if ks == 0 else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
     def stream_exp(self, qb, par):
-        """P = 2^(S*c - m*c) in place, two row-sum chains, pack pairs in place (112 instructions), skewed so that
-        consecutive instructions of the stream are independent."""
+        """P = 2^(S*c - m*c) in place, two row-sum chains, pairs packed in place; skewed by pair so that consecutive
+        instructions of the stream are independent.  Options: pkfma / pkadd use the packed-f32 forms for the scale and
+        the row sums (half the instructions)."""
         b = SB(qb, par)
         out = []
-        for k in range(32 + 3):
-            if k < 32:
-                out.append(mk("v_fma_f32", b[k], b[k], A_C, Neg(MC[qb]), tag="valu"))
-            if 0 <= k - 1 < 32:
-                out.append(mk("v_exp_f32", b[k - 1], b[k - 1], tag="trans"))
-            if 0 <= k - 2 < 32:
-                e = k - 2
-                acc = LA[qb] if (e & 1) == 0 else LB[qb]
-                out.append(mk("v_add_f32", acc, acc, b[e], tag="valu"))
-            if 0 <= k - 3 < 32 and ((k - 3) & 1) == 1:
-                e = k - 4                                     # pair (e, e+1)
-                dst = b[8 * (e // 8) + (e % 8) // 2]
-                out.append(mk(self.cvt, dst, b[e], b[e + 1], tag="valu"))
+        for k in range(16 + 3):
+            if k < 16 and "nofma" not in self.opt:            # stage 0: x = s*c - m*c
+                e = 2 * k
+                if "pkfma" in self.opt:
+                    out.append(mk("v_pk_fma_f32", b.sub(e, 2), b.sub(e, 2), CPAIR, MCP[qb], tag="valu", neg_lo="[0,0,1]", neg_hi="[0,0,1]"))
+                else:
+                    out.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
+                    out.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
+            if 0 <= k - 1 < 16:                               # stage 1: 2^x
+                e = 2 * (k - 1)
+                out.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
+                out.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
+            if 0 <= k - 2 < 16:                               # stage 2: row sums
+                e = 2 * (k - 2)
+                if "noadd" in self.opt:
+                    pass
+                elif "pkadd" in self.opt:
+                    out.append(mk("v_pk_add_f32", LSUM[qb], LSUM[qb], b.sub(e, 2), tag="valu"))
+                else:
+                    out.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
+                    out.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
+            if 0 <= k - 3 < 16:                               # stage 3: pack the pair in place
+                e = 2 * (k - 3)
+                out.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
         return out
 
-    def stream_max(self, qb, par, masked):
+    def stream_max(self, qb, par, masked, first=False):
         """mask (tail bodies) -> row max of the 32 scores of this lane -> half-wave exchange -> rescale decision."""
         b = SB(qb, par)
         out = []
         lim = A_LIM0 if qb == 0 else A_LIM1
+        mxa, mxb, t, t2 = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2], TMP[4 * qb + 3]
         if masked:
-            # element r of kv half kvb is kv_local = 32*kvb + (r&3) + 8*(r>>2) (+ 4*hi folded into lim): masked iff > lim
+            # element r of kv half kvb is kv_local = 32*kvb + (r&3) + 8*(r>>2) (4*hi is folded into lim): kept iff <= lim
+            out.append(mk("v_mov_b32", t2, NEG_INF, tag="valu"))      # (a literal next to vcc would need two constant-bus reads)
             for kvb in range(2):
                 for r in range(16):
                     kvl = 32 * kvb + (r & 3) + 8 * (r >> 2)
-                    out.append(mk("v_cmp_gt_i32", VCC, kvl, lim, tag="valu"))
-                    out.append(mk("v_cndmask_b32", b[16 * kvb + r], b[16 * kvb + r], NEGINF, VCC, tag="valu"))
-        for (mx, off) in ((MXA[qb], 0), (MXB[qb], 16)):
+                    out.append([mk("v_cmp_le_i32", VCC, kvl, lim, tag="valu"),
+                                mk("v_cndmask_b32", b[16 * kvb + r], t2, b[16 * kvb + r], VCC, tag="valu")])
+        for (mx, off) in ((mxa, 0), (mxb, 16)):
             out.append(mk("v_max3_f32", mx, b[off], b[off + 1], b[off + 2], tag="valu"))
         for i in range(6):
-            for (mx, off) in ((MXA[qb], 0), (MXB[qb], 16)):
+            for (mx, off) in ((mxa, 0), (mxb, 16)):
                 out.append(mk("v_max3_f32", mx, mx, b[off + 3 + 2 * i], b[off + 4 + 2 * i], tag="valu"))
-        out.append(mk("v_max3_f32", MXA[qb], MXA[qb], b[15], b[31], tag="valu"))
-        t = TMP[0 + 2 * qb]
-        t2 = TMP[1 + 2 * qb]
-        out.append(mk("v_max_f32", MXA[qb], MXA[qb], MXB[qb], tag="valu"))
-        out.append(mk("v_mov_b32", t, MXA[qb], tag="valu"))
-        out.append(mk("s_nop", 1, tag="salu"))
-        out.append(mk("v_permlane32_swap_b32", MXA[qb], t, tag="valu"))
-        out.append(mk("v_max_f32", MXA[qb], MXA[qb], t, tag="valu"))
-        out.append(mk("v_fma_f32", t2, MXA[qb], A_C, Neg(MC[qb]), tag="valu"))
+        out.append(mk("v_max3_f32", mxa, mxa, b[15], b[31], tag="valu"))
+        out.append(mk("v_max_f32", mxa, mxa, mxb, tag="valu"))
+        out.append(mk("v_mov_b32", t, mxa, tag="valu"))
+        out.append([mk("s_nop", 1, tag="salu"), mk("v_permlane32_swap_b32", mxa, t, tag="valu")])
+        out.append(mk("v_max_f32", mxa, mxa, t, tag="valu"))
+        out.append(mk("v_fma_f32", t2, mxa, A_C, Neg(MC[qb]), tag="valu"))
         lab = self.p.fresh("rare_m")
-        # (a list inside a stream is an atomic group: the scheduler keeps it contiguous — a branch and its return label)
+        # (a list inside a stream is an atomic group: the scheduler keeps it contiguous — here a branch and its return label)
         out.append([mk("v_cmp_lt_f32", VCC, THR, t2, tag="valu"), mk("s_cbranch_vccnz", Label(lab), tag="branch"),
                     Ins("label", (Label(lab + "_ret"),))])
-        # out-of-line: move the reference, scale the row sums now, leave the O rescale pending
-        r = []
-        r.append(Ins("label", (Label(lab),)))
-        r.append(mk("v_max_f32", t, MREF[qb], MXA[qb]))                 # m_new
-        r.append(mk("v_mul_f32", t2, A_C, t))                           # m_new * c
-        r.append(mk("v_sub_f32", MXB[qb], MC[qb], t2))                  # (m_old - m_new) * c   (<= 0; -inf on the first tile)
-        r.append(mk("v_mov_b32", MREF[qb], t))
-        r.append(mk("v_exp_f32", MXB[qb], MXB[qb]))
-        r.append(mk("v_mov_b32", MC[qb], t2))
-        r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+        # out-of-line: move the reference (kept in scaled units m*c), scale the row sums now, leave the O rescale pending
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("v_mul_f32", t, A_C, mxa))                          # tile max * c
         r.append(mk("s_nop", 0))
-        r.append(mk("v_mul_f32", LA[qb], LA[qb], MXB[qb]))
-        r.append(mk("v_mul_f32", LB[qb], LB[qb], MXB[qb]))
-        r.append(mk("v_mov_b32", FSC[qb], MXB[qb]))
+        r.append(mk("v_max_f32", t, t, MC[qb]))                         # new reference
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_sub_f32", mxb, MC[qb], t))                       # (m_old - m_new) * c  (<= 0; -inf on the first tile)
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_exp_f32", mxb, mxb))
+        r.append(mk("v_mov_b32", MCP[qb][0], t))
+        r.append(mk("v_mov_b32", MCP[qb][1], t))
+        if not first:               # the q block's first tile: O is still all zeros, nothing to rescale later
+            r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_mul_f32", LA[qb], LA[qb], mxb))
+        r.append(mk("v_mul_f32", LB[qb], LB[qb], mxb))
+        r.append(mk("v_mov_b32", FSC[qb], mxb))
         r.append(mk("s_branch", Label(lab + "_ret")))
         self.rare.append(r)
         return out
@@ -215,10 +252,11 @@ class Gen:
         return out
 
     def dma_group(self, which, slot_par, guarded, ahead):
-        """4 LDS-DMA pieces of one K or V tile (tile index = t + ahead)."""
+        """The 4 LDS-DMA pieces of this wave's quarter of one K or V tile (tile index = t + ahead): image bytes
+        [wave*4096 + i*1024, +1024), i.e. tile rows 16*wave + 4*i + lane/16.  M0 holds the quarter's LDS address, the piece
+        is selected by the instruction offset (which also advances the source address: KD / VD are biased by -1024*i)."""
         out = []
-        rs, vd, soff = (A_KRS, A_KD0, S_KOFF) if which == "k" else (A_VRS, A_VD0, S_VOFF)
-        r2, r3, r1 = (S_KR2, S_KR3, A_KROW16) if which == "k" else (S_VR2, S_VR3, A_VROW16)
+        rs, vd, soff = (A_KRS, KD, S_KOFF) if which == "k" else (A_VRS, VD, S_VOFF)
         base = (K_SLOT if which == "k" else V_BASE) + slot_par * SLOT_B
         skip = None
         if guarded:
@@ -226,58 +264,144 @@ class Gen:
             out.append(mk("s_add_u32", S_TMP2, S_T, ahead, tag="salu"))
             out.append(mk("s_cmp_lt_i32", S_TMP2, A_NTWG, tag="salu"))
             out.append(mk("s_cbranch_scc0", Label(skip), tag="branch"))
+        out.append([mk("s_add_u32", M0, A_LDSW, base, tag="salu"), mk("s_nop", 0, tag="salu")])
         for i in range(4):
-            out.append(mk("s_add_u32", M0, A_LDSW, base + i * 4096, tag="salu"))
-            if i == 0:
-                so = soff
-                out.append(mk("s_nop", 0, tag="salu"))
-            else:
-                out.append(mk("s_add_u32", S_TMP, soff, (r1, r2, r3)[i - 1], tag="salu"))
-                so = S_TMP
-            out.append(mk("buffer_load_dwordx4", vd, rs, so, tag="dma", offen=True, lds=True))
+            out.append(mk("buffer_load_dwordx4", vd[i], rs, soff, tag="dma", offen=True, offset=1024 * i, lds=True))
         if guarded:
             out.append(Ins("label", (Label(skip),)))
-            return [out]          # one atomic group: the guard's SCC and branch must not be interleaved with other streams
+            flat = []
+            for x in out:
+                flat.extend(x if isinstance(x, list) else [x])
+            return [flat]         # one atomic group: the guard's SCC and branch must not be interleaved with other streams
         return out
 
+    # ------------------------------------------------------------------ scheduler
+    @staticmethod
+    def place(load, slots, items, a, b, sid):
+        """Put the ordered `items` of one stream into the MFMA gaps [a, b), filling the least loaded gaps first
+        (water-filling on the weighted load) while keeping the stream's order."""
+        if not items:
+            return
+        gaps = list(range(int(a), min(64, int(b + 0.999))))
+        w = [_weight(it) for it in items]
+        total = sum(w)
+        lo, hi = min(load[g] for g in gaps), max(load[g] for g in gaps) + total + 1.0
+        for _ in range(50):                     # water level: sum(max(0, L - load)) == total
+            mid = 0.5 * (lo + hi)
+            if sum(max(0.0, mid - load[g]) for g in gaps) >= total:
+                hi = mid
+            else:
+                lo = mid
+        cap = [max(0.0, hi - load[g]) for g in gaps]
+        cum, acc = [], 0.0
+        for c in cap:
+            acc += c
+            cum.append(acc)
+        gi, done, counts = 0, 0.0, {}
+        for it, wi in zip(items, w):
+            centre = done + 0.5 * wi                # the item goes where its centre of weight falls in the free capacity
+            while gi < len(gaps) - 1 and cum[gi] < centre:
+                gi += 1
+            g = gaps[gi]
+            done += wi
+            load[g] += wi
+            counts.setdefault(g, []).append(it)
+        for g, lst in counts.items():
+            n = len(lst)
+            for j, it in enumerate(lst):
+                slots[g].append((g + (j + 0.5) / n, sid, it))
+
     # ------------------------------------------------------------------ one body
-    def body(self, par, pv=True, s1=True, s2=True, mask_m0=False, mask_m1=False, guarded=True, name="body"):
-        """B(t) with t & 1 == par.  pv: PV(t); s1: tile t+1 work (E0, M1, E1, V(t+1) reads); s2: tile t+2 work
-        (K(t+2) reads, QK(t+2), M0).  Returns nothing; appends to self.p."""
+    def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False):
+        """B(t) with t & 1 == par.  pv: PV(t); s1: softmax of tile t+1 (M0, M1, E0, E1) and the V(t+1) reads; s2: K(t+2)
+        reads and QK(t+2).  masked: tile t+1 is this wave's last one (causal diagonal / ragged tail masks); first: tile
+        t+1 is tile 0.  Appends to self.p."""
         p = self.p
         self.body_id += 1
+        cfg = self.cfg
+        fast = name.startswith("F")
+        abl = set(cfg["abl"]) if fast else set()
         mf = []
         mf += self.pv_mfmas(par, 0) if pv else [None] * 16
         mf += self.pv_mfmas(par, 1) if pv else [None] * 16
-        mf += self.qk_mfmas(par, 0) if s2 else [None] * 16
-        mf += self.qk_mfmas(par, 1) if s2 else [None] * 16
-        # filler streams with their gap windows [a, b)
-        streams = []
+        mf += self.qk_mfmas(par) if s2 else [None] * 32
+        if "mfma" in abl:
+            mf = [None] * 64
+        trace = fast and cfg["trace"][0] > 0
+        if trace:
+            p.emit("s_memtime", S_TA)
+        if cfg["stagger"][0] > 0 and (pv or s1 or s2):
+            # the four waves leave the barrier together and run the same stream: without a skew they meet at every LDS
+            # instruction and queue behind each other.  Wave w waits w * (stagger) issue slots.
+            go = p.fresh("stag")
+            for w in range(1, 4):
+                p.emit("s_cmp_lt_u32", S_WAVE, w)
+                p.emit("s_cbranch_scc1", Label(go))
+                p.emit("s_nop", int(cfg["stagger"][0]) - 1)
+            p.label(go)
+        if not pv:
+            # no PV MFMAs separate this body's first VALU reads of S from the QK^T MFMAs that ended the previous body
+            p.emit("s_nop", 15)
+            p.emit("s_nop", 15)
+        load = [0.0] * 64
+        slots = [[] for _ in range(64)]
         if s1:
-            streams.append((self.stream_exp(0, par ^ 1), 0.0, 48.0))
-            m1 = self.stream_max(1, par ^ 1, mask_m1)
-            w_m1 = 10.0 if not mask_m1 else 20.0
-            streams.append((m1, 2.0, 2.0 + w_m1))
-            streams.append((self.stream_exp(1, par ^ 1), 2.5 + w_m1, 64.0))
-            streams.append((self.stream_vread(par ^ 1), 33.0, 63.0))
-        if s2:
-            streams.append((self.stream_kread(par), 0.0, 26.0))
-            m0 = self.stream_max(0, par, mask_m0)
-            streams.append((m0, 50.0, 63.9))
-        dma = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
-        streams.append((dma, 8.0, 24.0))
-        slots = [[] for _ in range(65)]
-        for (lst, a, b) in streams:
-            n = len(lst)
-            for k, ins in enumerate(lst):
-                pos = a + (b - a) * (k + 0.5) / n
-                slots[int(pos)].append((pos, ins))
+            mw = cfg["mmask"] if masked else cfg["m"]
+            ew = (mw[1], cfg["e"][1])
+            if "max" not in abl:
+                self.place(load, slots, self.stream_max(0, par ^ 1, masked, first), mw[0], mw[1], 0)
+                self.place(load, slots, self.stream_max(1, par ^ 1, masked, first), mw[0], mw[1], 1)
+        if "dma" not in abl:
+            dma = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
+            self.place(load, slots, dma, cfg["dma"][0], cfg["dma"][1], 2)
+        if s2 and "kread" not in abl:
+            self.place(load, slots, self.stream_kread(par), cfg["kread"][0], cfg["kread"][1], 3)
+        if s1 and "vread" not in abl:
+            self.place(load, slots, self.stream_vread(par ^ 1), cfg["vread"][0], cfg["vread"][1], 4)
+        if s1 and "exp" not in abl:
+            self.place(load, slots, self.stream_exp(0, par ^ 1), ew[0], ew[1] - 1.0, 5)
+            self.place(load, slots, self.stream_exp(1, par ^ 1), ew[0], ew[1], 6)
+        self.last_load = load
+        if fast and cfg["syn"]:
+            # timing probe (wrong results): every gap of the fast bodies carries the same synthetic fillers, e.g.
+            # syn=fma:3+exp:2 -> 3 v_fma_f32 and 2 v_exp_f32 per gap, on scratch registers
+            slots = [[] for _ in range(64)]
+            for g in range(64):
+                j = 0
+                for spec in cfg["syn"]:
+                    kind, _, cnt = spec.partition(":")
+                    for _ in range(int(cnt)):
+                        r = TMP[j % 8]
+                        j += 1
+                        if kind == "fma":
+                            ins = mk("v_fma_f32", r, r, A_C, Neg(MC[0]), tag="valu")
+                        elif kind == "add":
+                            ins = mk("v_add_f32", r, r, MC[0], tag="valu")
+                        elif kind == "exp":
+                            ins = mk("v_exp_f32", r, r, tag="trans")
+                        elif kind == "cvt":
+                            ins = mk(self.cvt, r, r, MC[0], tag="valu")
+                        elif kind == "max3":
+                            ins = mk("v_max3_f32", r, r, MC[0], MC[1], tag="valu")
+                        elif kind == "kread":
+                            ins = mk("ds_read_b128", KF(j & 1, (g + j) & 7), KR[(g + j) & 7], tag="lds", offset=par * SLOT_B)
+                        elif kind == "vread":
+                            ins = mk("ds_read_b64_tr_b16", VF(j & 3, g & 3).sub(0, 2), VR[j & 3], tag="lds", offset=V_BASE)
+                        elif kind == "dot2":
+                            ins = mk("v_dot2_f32_f16", r, MC[0], MC[1], r, tag="valu")
+                        elif kind == "dot2c":
+                            ins = mk("v_dot2c_f32_f16", r, MC[0], MC[1], tag="valu")
+                        elif kind == "mov":
+                            ins = mk("v_mov_b32", r, MC[0], tag="valu")
+                        elif kind == "salu":
+                            ins = mk("s_add_u32", S_TMP, S_TMP, 1, tag="salu")
+                        elif kind == "nop":
+                            ins = mk("s_nop", 0, tag="salu")
+                        else:
+                            raise ValueError(kind)
+                        slots[g].append((g, 0, ins))
         for g in range(64):
-            slots[g].sort(key=lambda x: x[0])
-            flat = []
-            for (pos, item) in slots[g]:
-                flat.extend((pos, i) for i in (item if isinstance(item, list) else [item]))
-            slots[g] = flat
+            slots[g].sort(key=lambda x: (x[0], x[1]))
         # emit: gap g fillers come AFTER mfma g
         for g in range(64):
             if g == 32:
@@ -289,16 +413,31 @@ class Gen:
                 self.rare.append(self.rare_rescale(lab))
                 if s2:
                     p.emit("s_waitcnt", lgkmcnt=0)
+                if trace:
+                    p.emit("s_memtime", S_TB)
             if mf[g] is not None:
                 p.ins.append(mf[g])
-            for (_, ins) in slots[g]:
-                p.ins.append(ins)
+            for (_, _, item) in slots[g]:
+                p.ins.extend(item if isinstance(item, list) else [item])
         # end of body: DMA landed, my LDS reads done, then everybody
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)
         p.emit("s_add_u32", S_VOFF, S_VOFF, A_VTILE)
         p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
-        p.emit("s_barrier")
+        if trace:
+            p.emit("s_memtime", S_TC)
+        if "barrier" not in abl:
+            p.emit("s_barrier")
+        if trace:       # sums of the low words: PV phase, QK phase (+ end-of-body wait), barrier
+            p.emit("s_memtime", S(84, 2))
+            p.emit("s_waitcnt", lgkmcnt=0)
+            p.emit("s_sub_u32", S_TMP, S_TB[0], S_TA[0])
+            p.emit("s_add_u32", S_SUM[0], S_SUM[0], S_TMP)
+            p.emit("s_sub_u32", S_TMP, S_TC[0], S_TB[0])
+            p.emit("s_add_u32", S_SUM[1], S_SUM[1], S_TMP)
+            p.emit("s_sub_u32", S_TMP, S(84), S_TC[0])
+            p.emit("s_add_u32", S_SUM[2], S_SUM[2], S_TMP)
+            p.emit("s_add_u32", S_SUM[3], S_SUM[3], 1)
 
     def rare_rescale(self, lab):
         r = [Ins("label", (Label(lab),))]
@@ -328,8 +467,11 @@ class Gen:
     # ------------------------------------------------------------------ whole block
     def build(self):
         p = self.p
+        tr = int(self.cfg["trace"][0])
         # ---- entry: constants, state, Q fragments, K(0)
         p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        if tr:
+            p.emit("s_memtime", S_MARK[0])
         for ks in range(8):
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
         for dt in range(4):
@@ -337,30 +479,38 @@ class Gen:
         for qb in range(2):
             for ks in range(8):
                 p.emit("global_load_dwordx4", QF(qb, ks), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
+        # DMA source offsets of piece i: rows 4*i further down, the K granule swizzle follows the row (xor i<<6), and the
+        # instruction offset 1024*i that selects the LDS piece is taken back out of the source address
+        p.emit("v_mov_b32", KD[0], A_KD0)
+        p.emit("v_mov_b32", VD[0], A_VD0)
+        p.emit("s_mov_b32", S_TMP, 0)
+        p.emit("s_mov_b32", S_TMP2, 0)
+        for i in range(1, 4):
+            p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
+            p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
+            p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
+            p.emit("v_add_u32", VD[i], S_TMP2, A_VD0)
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", KD[i], S_TMP, KD[i])
         p.emit("s_mov_b32", S_T, -2)
+        p.emit("s_lshr_b32", S_WAVE, A_LDSW, 12)
         p.emit("s_mov_b32", S_FLAG, 0)
+        for r in S_SUM:
+            p.emit("s_mov_b32", r, 0)
         p.emit("s_mov_b32", S_KOFF, 0)
-        p.emit("s_lshl_b32", S_KR2, A_KROW16, 1)
-        p.emit("s_add_u32", S_KR3, S_KR2, A_KROW16)
-        p.emit("s_lshl_b32", S_VR2, A_VROW16, 1)
-        p.emit("s_add_u32", S_VR3, S_VR2, A_VROW16)
         # K(0) -> K slot 0 (always exists)
+        p.emit("s_add_u32", M0, A_LDSW, K_SLOT)
+        p.emit("s_nop", 0)
         for i in range(4):
-            p.emit("s_add_u32", M0, A_LDSW, K_SLOT + i * 4096)
-            if i == 0:
-                p.emit("s_nop", 0)
-                so = S_KOFF
-            else:
-                p.emit("s_add_u32", S_TMP, S_KOFF, (A_KROW16, S_KR2, S_KR3)[i - 1])
-                so = S_TMP
-            p.emit("buffer_load_dwordx4", A_KD0, A_KRS, so, offen=True, lds=True)
+            p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
         # B(-2) stages K(1) (= t + 3) and V(0) (= t + 2): the running offsets are those of tile t+3 / t+2
         p.emit("s_mov_b32", S_KOFF, A_KTILE)
         p.emit("s_mov_b32", S_VOFF, 0)
-        p.emit("v_mov_b32", NEGINF, NEG_INF)
+        p.emit("v_mov_b32", CPAIR[0], A_C)
+        p.emit("v_mov_b32", CPAIR[1], A_C)
         for qb in range(2):
-            p.emit("v_mov_b32", MREF[qb], NEG_INF)
-            p.emit("v_mov_b32", MC[qb], NEG_INF)
+            p.emit("v_mov_b32", MCP[qb][0], NEG_INF)
+            p.emit("v_mov_b32", MCP[qb][1], NEG_INF)
             p.emit("v_mov_b32", LA[qb], 0)
             p.emit("v_mov_b32", LB[qb], 0)
             p.emit("v_mov_b32", FSC[qb], 1.0)
@@ -369,23 +519,19 @@ class Gen:
         p.emit("s_waitcnt", vmcnt=0)
         p.emit("s_barrier")
 
-        # ---- head bodies: t = -2 (parity 0), t = -1 (parity 1)
-        p.emit("s_cmp_eq_u32", A_NTW, 1)
-        p.emit("s_cbranch_scc1", Label("h1m"))
+        # ---- head bodies: t = -2 (parity 0): QK(0) only; t = -1 (parity 1): softmax of tile 0, QK(1) if there is a tile 1
         self.body(0, pv=False, s1=False, s2=True, name="H1")
-        p.emit("s_cmp_eq_u32", A_NTW, 2)
-        p.emit("s_cbranch_scc1", Label("h2a"))
-        self.body(1, pv=False, s1=True, s2=True, name="H2")
+        p.emit("s_cmp_eq_u32", A_NTW, 1)
+        p.emit("s_cbranch_scc1", Label("h2b"))
+        self.body(1, pv=False, s1=True, s2=True, name="H2", first=True)
         p.emit("s_branch", Label("main"))
-        p.label("h2a")
-        self.body(1, pv=False, s1=True, s2=True, mask_m0=True, name="H2a")
-        p.emit("s_branch", Label("main"))
-        p.label("h1m")
-        self.body(0, pv=False, s1=False, s2=True, mask_m0=True, name="H1m")
-        self.body(1, pv=False, s1=True, s2=False, mask_m1=True, name="H2b")
+        p.label("h2b")
+        self.body(1, pv=False, s1=True, s2=False, masked=True, name="H2b", first=True)
 
-        # ---- main: fast bodies while ntw - t >= 4, then the dispatcher
+        # ---- main: fast bodies while ntw - t >= 4 (then tile t+1 is not the last one and the staged tiles t+2, t+3 exist)
         p.label("main")
+        if tr:
+            p.emit("s_memtime", S_MARK[1])
         p.emit("s_sub_u32", S_NFAST, A_NTW, 3)            # number of fast bodies (t = 0 .. ntw-4), if positive
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc0", Label("dispatch"))
@@ -419,10 +565,10 @@ class Gen:
             self.body(par, pv=False, s1=False, s2=False, name="ST%d" % par)     # this wave is done: stage + sync only
             p.emit("s_branch", Label("dispatch"))
             p.label("ta_" + suffix)
-            self.body(par, mask_m0=True, name="TA%d" % par)
+            self.body(par, name="TA%d" % par)                                   # like a fast body, staging guarded
             p.emit("s_branch", Label("dispatch"))
             p.label("tb_" + suffix)
-            self.body(par, s2=False, mask_m1=True, name="TB%d" % par)
+            self.body(par, s2=False, masked=True, name="TB%d" % par)            # tile t+1 is the last: masks
             p.emit("s_branch", Label("dispatch"))
             p.label("tc_" + suffix)
             self.body(par, s1=False, s2=False, name="TC%d" % par)
@@ -430,10 +576,13 @@ class Gen:
 
         # ---- epilogue: O / l -> 16 bit -> wave-private LDS image (rows of 272 B); LSE out
         p.label("epilogue")
+        if tr:
+            p.emit("s_memtime", S_MARK[2])
         p.emit("s_nop", 15)
         for qb in range(2):
-            lt, t, inv = TMP[8], TMP[9], T2[0]
+            lt, t, inv = EP_LT, EP_T, EP_INV
             p.emit("v_add_f32", lt, LA[qb], LB[qb])
+            p.emit("s_nop", 0)
             p.emit("v_mov_b32", t, lt)
             p.emit("s_nop", 1)
             p.emit("v_permlane32_swap_b32", lt, t)
@@ -452,7 +601,9 @@ class Gen:
                     for j in range(8):
                         p.emit("v_mul_f32", TMP[j], TMP[j], inv)
                     p.emit("s_nop", 0)
-                    # a0 = TMP0, a1 = TMP1 (regs 4r4+0..3), b0 = TMP2, b1 = TMP3 (regs 4r4+4..7)
+                    # a0, a1 = regs 4r4+0..3, b0, b1 = regs 4r4+4..7, packed into four consecutive scratch registers
+                    d4 = V(TMP[0].idx, 4)
+                    assert [TMP[j].idx for j in range(4)] == [d4.idx + j for j in range(4)]
                     p.emit(self.cvt, TMP[0], TMP[0], TMP[1])
                     p.emit(self.cvt, TMP[1], TMP[2], TMP[3])
                     p.emit(self.cvt, TMP[2], TMP[4], TMP[5])
@@ -461,10 +612,27 @@ class Gen:
                     p.emit("v_permlane32_swap_b32", TMP[0], TMP[2])
                     p.emit("v_permlane32_swap_b32", TMP[1], TMP[3])
                     p.emit("s_nop", 0)
-                    # 16 bytes {x0[0], x1[0], x0[1], x1[1]} = {TMP0, TMP1, TMP2, TMP3} at row (32qb + l31), column 32dt + 8(r4 + hi)
-                    p.emit("ds_write_b128", A_EPI, V(TMP[0].idx, 4), offset=32 * qb * EPI_ROWB + (32 * dt + 8 * r4) * 2)
+                    # 16 bytes {x0[0], x1[0], x0[1], x1[1]} at row (32qb + l31), column 32dt + 8(r4 + hi)
+                    p.emit("ds_write_b128", A_EPI, d4, offset=32 * qb * EPI_ROWB + (32 * dt + 8 * r4) * 2)
                     p.emit("s_nop", 1)
         p.emit("s_waitcnt", lgkmcnt=0)
+        if tr:          # developer build: the LSE outputs carry cycle counts instead
+            p.emit("s_memtime", S_MARK[3])
+            p.emit("s_waitcnt", lgkmcnt=0)
+            if tr == 1:      # PV-phase and QK-phase sums over the fast bodies
+                a, b = S_SUM[0], S_SUM[1]
+            elif tr == 2:    # barrier sum, number of fast bodies
+                a, b = S_SUM[2], S_SUM[3]
+            elif tr == 3:    # entry -> first main body, epilogue
+                p.emit("s_sub_u32", S_TMP, S_MARK[1][0], S_MARK[0][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARK[3][0], S_MARK[2][0])
+                a, b = S_TMP, S_TMP2
+            else:            # whole block, main bodies (fast + tail)
+                p.emit("s_sub_u32", S_TMP, S_MARK[3][0], S_MARK[0][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARK[2][0], S_MARK[1][0])
+                a, b = S_TMP, S_TMP2
+            p.emit("v_cvt_f32_u32", A_LSE0, a)
+            p.emit("v_cvt_f32_u32", A_LSE1, b)
         # out-of-line blocks
         p.emit("s_branch", Label("end"))
         for r in self.rare:
@@ -493,14 +661,34 @@ def clobber_list():
     return ", ".join('"%s"' % r for r in regs + ["vcc", "scc", "memory"])
 
 
+def parse_opts(text):
+    """"e=10:64,dma=3:22,abl=dma+exp,opt=pkadd+pkfma,trace=1:0" -> Gen keyword arguments"""
+    cfg = {}
+    for item in filter(None, (text or "").split(",")):
+        k, _, v = item.partition("=")
+        if k in ("abl", "opt", "syn"):
+            cfg[k] = tuple(x for x in v.split("+") if x)
+        else:
+            a, _, b = v.partition(":")
+            cfg[k] = (float(a), float(b or 0))
+    return cfg
+
+
 def main():
-    out_dir = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
+    ap.add_argument("--opt", default=os.environ.get("FA2_D128_GEN_OPT", ""), help="schedule tunables / options / ablations, see parse_opts")
+    a = ap.parse_args()
+    out_dir = a.out
+    os.makedirs(out_dir, exist_ok=True)
+    cfg = parse_opts(a.opt)
     for bf16 in (False, True):
-        g = Gen(bf16)
+        g = Gen(bf16, **cfg)
         prog = g.build()
         path = os.path.join(out_dir, "fa2_fwd_d128_%s.inc" % ("bf16" if bf16 else "f16"))
         with open(path, "w") as f:
-            f.write("// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.  %d instructions.\n" % len(prog.ins))
+            f.write("// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)))
             f.write(render_inline(prog))
         print(path, len(prog.ins), "instructions")
     with open(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"), "w") as f:

@@ -58,3 +58,25 @@ def test_emulator_flags_a_missing_wait():
             harness._PROGS[False] = saved
         else:
             harness._PROGS.pop(False, None)
+
+
+@pytest.mark.parametrize("opt", [(), ("pkadd", "pkfma")])
+def test_generated_text_assembles_for_gfx950(opt, tmp_path):
+    """Every line of the rendered body goes through the gfx950 assembler (operand classes, constant-bus limits, offsets):
+    the emulator interprets instruction objects, so this is the check that the TEXT is legal."""
+    import re
+    import shutil
+    import subprocess
+    import fwd_d128_gen as gen
+    mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    subst = {0: "v0", 1: "v1", 2: "v[2:3]", 3: "v[4:5]", 4: "s[0:3]", 5: "s[4:7]", 6: "v6", 7: "v7", 8: "v8", 9: "v9", 10: "v10",
+             11: "v11", 12: "s8", 13: "s9", 14: "s10", 15: "s11", 16: "s12", 17: "s13", 18: "s14", 19: "s15", 20: "v12"}
+    for bf16 in (False, True):
+        text = "\n".join(gen.Gen(bf16, opt=opt).build().text_lines())
+        text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))
+        src = tmp_path / ("body_%d.s" % bf16)
+        src.write_text(text + "\n")
+        res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[:2000]

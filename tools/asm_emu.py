@@ -351,7 +351,7 @@ class Machine:
                 w.last_m0_write = w.issue_idx
             else:
                 w.s[d.idx] = val
-        elif op in ("s_add_u32", "s_sub_u32", "s_lshl_b32", "s_and_b32", "s_or_b32"):
+        elif op in ("s_add_u32", "s_sub_u32", "s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
             x, y = self.rds(w, ops[1]), self.rds(w, ops[2])
             if op == "s_add_u32":
                 r = x + y
@@ -361,12 +361,14 @@ class Machine:
                 w.scc = int(y > x)
             elif op == "s_lshl_b32":
                 r = x << (y & 31)
+            elif op == "s_lshr_b32":
+                r = x >> (y & 31)
             elif op == "s_and_b32":
                 r = x & y
             else:
                 r = x | y
             r &= 0xffffffff
-            if op in ("s_lshl_b32", "s_and_b32", "s_or_b32"):
+            if op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
                 w.scc = int(r != 0)
             d = R(0)
             if isinstance(d, Sym):
@@ -391,6 +393,27 @@ class Machine:
                 w.cycle += 16
         elif op == "v_mov_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]))
+        elif op == "v_add_u32":
+            self.wr32(w, ops[0], (self.rd32(w, ops[1]).astype(np.uint64) + self.rd32(w, ops[2]).astype(np.uint64)).astype(np.uint32))
+        elif op == "v_cvt_f32_u32":
+            self.wr32(w, ops[0], self.rd32(w, ops[1]).astype(np.float32))
+        elif op in ("v_pk_add_f32", "v_pk_fma_f32"):
+            d, a_, b_ = R(0), R(1), R(2)
+            neg2 = "1]" in str(ins.mods.get("neg_lo", ""))
+            for h in range(2):
+                x, y = self.rdf(w, a_[h]), self.rdf(w, b_[h])
+                with np.errstate(invalid="ignore", over="ignore"):
+                    if op == "v_pk_add_f32":
+                        r = x + y
+                    else:
+                        z = self.rdf(w, R(3)[h])
+                        r = (x.astype(np.float64) * y.astype(np.float64) + (-z if neg2 else z).astype(np.float64)).astype(np.float32)
+                self.wr32(w, d[h], r.astype(np.float32))
+        elif op == "s_memtime":
+            d = R(0)
+            w.s[d.idx] = np.uint32(int(w.cycle) & 0xffffffff)
+            w.s[d.idx + 1] = 0
+            w.lgkm.append(lambda: None)
         elif op == "v_xor_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]) ^ self.rd32(w, ops[2]))
         elif op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32"):
@@ -417,9 +440,9 @@ class Machine:
             lo, hi = self.rdf(w, ops[1]), self.rdf(w, ops[2])
             cv = f32_to_bf16_bits if op.endswith("bf16_f32") else f32_to_f16_bits
             self.wr32(w, ops[0], (cv(lo) | (cv(hi) << 16)).astype(np.uint32))
-        elif op == "v_cmp_gt_i32":
+        elif op in ("v_cmp_gt_i32", "v_cmp_le_i32"):
             x, y = self.rd32(w, ops[1]).view(np.int32), self.rd32(w, ops[2]).view(np.int32)
-            w.vcc = x > y
+            w.vcc = (x > y) if op == "v_cmp_gt_i32" else (x <= y)
         elif op == "v_cmp_lt_f32":
             x, y = self.rdf(w, ops[1]), self.rdf(w, ops[2])
             with np.errstate(invalid="ignore"):
@@ -503,7 +526,7 @@ class Machine:
             soff = self.rds(w, ops[2])
             base = int(rs[0]) | ((int(rs[1]) & 0xffff) << 32)
             nrec = int(rs[2])
-            off = voff + soff
+            off = voff + soff + ins.mods.get("offset", 0)
             data = np.zeros((NLANE, 16), dtype=np.uint8)
             for l in range(NLANE):
                 o = int(off[l]) & 0xffffffff

@@ -56,7 +56,7 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         lim_c = qrow if causal else np.full(64, 0x3fffffff)
         lim = np.minimum(lim_c, Nkv - 1) - 64 * (ntw - 1) - 4 * hi
         v[10 + qb] = lim.astype(np.int32).view(np.uint32)
-    row = 4 * w + (lane >> 4)
+    row = 16 * w + (lane >> 4)
     slot = lane & 15
     gk = slot ^ (row & 15)
     v[6] = (row * row_bytes + gk * 16).astype(np.uint32)
@@ -76,8 +76,8 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     args[12] = int(np.float32(scale * LOG2E).view(np.uint32))
     args[13], args[14] = ntw, ntiles
     args[15] = args[16] = 64 * row_bytes
-    args[17] = args[18] = 16 * row_bytes
-    args[19] = w * 1024
+    args[17] = args[18] = 4 * row_bytes - 1024
+    args[19] = w * 4096
     return args
 
 

@@ -51,10 +51,18 @@ def build(specs):
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     os.makedirs(VAR_DIR, exist_ok=True)
+    b.generate()
     procs = []
     for s in specs:
         name, _, flags = s.partition(":")
-        extra = [f for f in flags.split(",") if f]
+        extra = [f for f in flags.split(",") if f and not f.startswith("gen=")]
+        gen = [f[4:] for f in flags.split(",") if f.startswith("gen=")]
+        if gen:     # schedule variant of the hand-scheduled D = 128 kernel: NAME:gen=e0=0:40;dma=4:12;abl=exp+dma (';' between options)
+            gdir = os.path.join(VAR_DIR, name + "_gen")
+            subprocess.check_call([sys.executable, os.path.join(b.CSRC, "gen", "fwd_d128_gen.py"), "--out", gdir,
+                                   "--opt", gen[0].replace(";", ",")], stdout=subprocess.DEVNULL)
+            extra += ['-DFA2_D128_INC_F16="%s"' % os.path.join(gdir, "fa2_fwd_d128_f16.inc"),
+                      '-DFA2_D128_INC_BF16="%s"' % os.path.join(gdir, "fa2_fwd_d128_bf16.inc")]
         out = os.path.join(VAR_DIR, name + ".so")
         cmd = [b._hipcc()] + b.HIPCC_FLAGS + extra + ["-I", b.INCLUDE, "-I", b.CSRC,
                                                       os.path.join(b.CSRC, "host.cpp"), "-o", out,
@@ -111,7 +119,7 @@ def ref_fp32(q, k, v, causal):
     return torch.matmul(torch.softmax(s, -1), v.float()), torch.logsumexp(s, -1) * 1.4426950408889634
 
 
-def run(names, rounds, iters, cfgs):
+def run(names, rounds, iters, cfgs, fill="rand"):
     import torch
     paths = sorted(glob.glob(os.path.join(VAR_DIR, "*.so")))
     if names:
@@ -135,13 +143,14 @@ def run(names, rounds, iters, cfgs):
             var.fwd(q, k, v, o, lse, causal, stream)
             torch.cuda.synchronize()
             o_ref, lse_ref = ref_fp32(q, k, v, causal)
-            msgs.append("%.1e/%.0e" % ((o.float() - o_ref).abs().max().item(), (lse - lse_ref).abs().max().item()))
+            msgs.append("nan" if not torch.isfinite(o.float()).all() else"%.1e/%.0e" % ((o.float() - o_ref).abs().max().item(), (lse - lse_ref).abs().max().item()))
         print("check %-14s max|O-ref|/max|L-ref|: %s" % (var.name, "  ".join(msgs)))
     # timing
     for cname in cfgs:
         B, H, N, D, dts, causal = CFGS[cname]
         dt = torch.float16 if dts == "f16" else torch.bfloat16
-        q, k, v = (torch.rand((B, H, N, D), device=dev, dtype=torch.float32).to(dt) for _ in range(3))
+        mk = {"rand": torch.rand, "randn": torch.randn, "zeros": torch.zeros}[fill]   # zeros: no data toggling -> the chip is not power-limited
+        q, k, v = (mk((B, H, N, D), device=dev, dtype=torch.float32).to(dt) for _ in range(3))
         o = torch.empty_like(q)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
         flops = 4.0 * B * H * N * N * D * (0.5 if causal else 1.0)
@@ -160,6 +169,13 @@ def run(names, rounds, iters, cfgs):
                 torch.cuda.synchronize()
                 times[var.name].append(e0.elapsed_time(e1) / iters)
         print("-- %s: B%d H%d N%d D%d %s causal=%d" % (cname, B, H, N, D, dts, causal))
+        for var in variants:
+            if "trace" in var.name:     # developer builds of the d128 kernel that return cycle sums in the LSE tensor
+                var.fwd(q, k, v, o, lse, causal, stream)
+                torch.cuda.synchronize()
+                x = lse[0, 0].reshape(-1, 64)      # [q block * 4 + wave, 64]: first 32 = output 0, next 32 = output 1
+                print("   %s: per-wave sums (out0, out1) of q block 0: %s  last q block: %s" % (
+                    var.name, [(float(x[w, 0]), float(x[w, 32])) for w in range(4)], [(float(x[-4 + w, 0]), float(x[-4 + w, 32])) for w in range(4)]))
         for name, ts in times.items():
             med, mn = statistics.median(ts), min(ts)
             print("   %-16s median %8.1f us  %7.1f TF (%4.1f%%)   best %8.1f us  %7.1f TF"
@@ -173,7 +189,8 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--cfg", default="c2")
+    ap.add_argument("--fill", default="rand", choices=["rand", "randn", "zeros"])
     a = ap.parse_args()
     if a.cmd == "build":
         sys.exit(0 if build(a.names) else 1)
-    run(a.names, a.rounds, a.iters, a.cfg.split(","))
+    run(a.names, a.rounds, a.iters, a.cfg.split(","), a.fill)

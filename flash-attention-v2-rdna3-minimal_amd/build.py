@@ -25,7 +25,8 @@ STAMP_PATH = LIB_PATH + ".stamp"
 SOURCES = ["host.cpp"]
 HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
            os.path.join("gen", "isa.py"), os.path.join("gen", "fwd_d128_gen.py")]
-GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_clobbers.inc"]   # written by gen/fwd_d128_gen.py
+GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_f16_fold.inc", "fa2_fwd_d128_bf16_fold.inc",
+             "fa2_fwd_d128_clobbers.inc"]   # written by gen/fwd_d128_gen.py
 
 HIPCC_FLAGS = [
     "-x", "hip",

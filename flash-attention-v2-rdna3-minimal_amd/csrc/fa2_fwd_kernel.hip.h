@@ -163,6 +163,41 @@ struct Geo {
     }
 };
 
+#ifndef FA2_CAUSAL_HPG        // causal launch order: heads per group inside an XCD (0 = all heads of the XCD in one group).
+#define FA2_CAUSAL_HPG 0      // Pairs of heads (2) cut config 4's HBM-side traffic from 2.17x to 1.40x of the algorithmic bytes but are
+#endif                        // no faster there (1237 vs 1250 TF: the path is MFMA/power-bound, the re-reads hit the Infinity Cache) and
+                              // cost 20 % at N = 2048 (fewer long blocks in flight): measured, left off
+
+// Workgroup -> (batch*head, q block).  blockIdx % 8 is the XCD a block lands on (observed placement; speed only).
+//   non-causal: all q blocks of a head run on one XCD, back to back, so the head's K/V stay in that XCD's L2 (equal work
+//               per block: order is irrelevant for balance);
+//   causal:     work grows with the q block index and blocks are handed to CUs in launch order, so blocks go longest
+//               first ACROSS heads (with per-head ordering the long blocks of the later heads arrive last: makespan 100
+//               instead of 68 tile-steps at B2 H16 N4096).  FA2_CAUSAL_HPG > 0 restricts the interleave to that many
+//               heads at a time (interleaving all heads of an XCD cycles their K/V through one 4 MiB L2).
+template <bool CAUSAL>
+__device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid, int& bh, int& qblk) {
+    const int nbh = p.B * p.H;
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
+        if (CAUSAL) {
+            const int hpg = (FA2_CAUSAL_HPG > 0 && hpx % FA2_CAUSAL_HPG == 0) ? FA2_CAUSAL_HPG : hpx;
+            const int per_group = hpg * p.nqblk, g = slot / per_group, r = slot % per_group;
+            bh = (bid & 7) + 8 * (g * hpg + r % hpg);
+            qblk = p.nqblk - 1 - r / hpg;
+        } else {
+            bh = (bid & 7) + 8 * (slot / p.nqblk);
+            qblk = slot % p.nqblk;
+        }
+    } else if (CAUSAL) {
+        bh = bid % nbh;
+        qblk = p.nqblk - 1 - bid / nbh;
+    } else {
+        bh = bid / p.nqblk;
+        qblk = bid % p.nqblk;
+    }
+}
+
 // NW waves per workgroup, each owning QB consecutive 32-row Q blocks (NW * QB * 32 == 256):
 //   <8, 1>: two waves per SIMD, 256 VGPRs each;  <4, 2>: one wave per SIMD with the 512-register
 //   budget — every K / V^T fragment read from LDS then feeds two MFMAs instead of one.
@@ -191,32 +226,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p)
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
-    // ---- workgroup -> (batch*head, q block).  blockIdx % 8 is the XCD a block lands on.
-    //   non-causal: all q blocks of a head run on one XCD, back to back, so the head's K/V stay in that
-    //               XCD's L2 (equal work per block: order is irrelevant for balance);
-    //   causal:     work grows with the q block index, and blocks are handed to CUs in launch order, so
-    //               the order is longest-first ACROSS heads (all heads' last q block, then the one before,
-    //               ...): with per-head ordering the long blocks of the later heads arrive last and the
-    //               makespan was 100 tile-steps instead of 68 at B2 H16 N4096.
-    const int nbh = p.B * p.H;
-    const int bid = blockIdx.x;
     int bh, qblk;
-    if ((nbh & 7) == 0) {
-        const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
-        if (CAUSAL) {
-            bh = (bid & 7) + 8 * (slot % hpx);
-            qblk = p.nqblk - 1 - slot / hpx;
-        } else {
-            bh = (bid & 7) + 8 * (slot / p.nqblk);
-            qblk = slot % p.nqblk;
-        }
-    } else if (CAUSAL) {
-        bh = bid % nbh;
-        qblk = p.nqblk - 1 - bid / nbh;
-    } else {
-        bh = bid / p.nqblk;
-        qblk = bid % p.nqblk;
-    }
+    block_to_head_qblock<CAUSAL>(p, blockIdx.x, bh, qblk);
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * kRowsPerBlock;
     const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave

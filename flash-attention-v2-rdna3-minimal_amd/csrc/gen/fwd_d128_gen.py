@@ -56,7 +56,7 @@ A_EPI = Arg(20)                                    # per-lane LDS byte address o
 N_ARGS = 21
 
 # ---- fixed registers (everything below is clobbered by the asm statement)
-VBASE = 24
+VBASE = 16
 
 
 def SB(qb, par):                                   # S / P bank of q block qb, tile parity par: 32 VGPRs
@@ -64,23 +64,24 @@ def SB(qb, par):                                   # S / P bank of q block qb, t
 
 
 def VF(dt, ks):                                    # V^T fragment (4 VGPRs)
-    return V(152 + 16 * ks + 4 * dt, 4)
+    return V(144 + 16 * ks + 4 * dt, 4)
 
 
-KR = [V(216 + i) for i in range(8)]                # K fragment read addresses, k-step ks
-VR = [V(224 + i) for i in range(4)]                # V^T fragment read addresses, d block dt
-KD = [V(228 + i) for i in range(4)]                # LDS-DMA source offsets of this wave's 4 pieces of a K tile
-VD = [V(232 + i) for i in range(4)]
-SPARE = [V(236), V(237)]
-LSUM = [V(238, 2), V(240, 2)]                      # running row sums, two chains (even / odd elements) per q block
+KR = [V(208 + i) for i in range(8)]                # K fragment read addresses, k-step ks
+VR = [V(216 + i) for i in range(4)]                # V^T fragment read addresses, d block dt
+KD = [V(220 + i) for i in range(4)]                # LDS-DMA source offsets of this wave's 4 pieces of a K tile
+VD = [V(224 + i) for i in range(4)]
+LSUM = [V(228, 2), V(230, 2)]                      # running row sums, two chains (even / odd elements) per q block
 LA = [LSUM[0][0], LSUM[1][0]]
 LB = [LSUM[0][1], LSUM[1][1]]
-FSC = [V(242), V(243)]                             # pending O rescale factor
-CPAIR = V(244, 2)                                  # {c, c} (packed-f32 option)
-MCP = [V(246, 2), V(248, 2)]                       # reference max * c (second register: copy for the packed-f32 option)
-MC = [MCP[0][0], MCP[1][0]]
-TMP = [V(250 + i) for i in range(6)] + SPARE       # 8 scratch registers: row-max chains, rescale block, epilogue
-EP_LT, EP_T, EP_INV = V(242), V(243), V(244)       # epilogue scratch (the softmax state above is dead by then)
+FSC = [V(232), V(233)]                             # pending O rescale factor
+MC = [V(234), V(235)]                              # reference max in log2 units (m * c)
+TMP = [V(236 + i) for i in range(8)]               # scratch: row-max chains, rescale block, epilogue
+KX = V(244, 4)                                     # folded-scale kernels: the K side of the extra k-step (ones / zeros)
+QX = [V(248, 4), V(252, 4)]                        # ... and the Q side: -(reference max) split into three 16-bit terms
+CPAIR = KX.sub(0, 2)                               # packed-f32 experiments of the unfolded kernel only
+MCP = [QX[0].sub(0, 2), QX[1].sub(0, 2)]
+EP_LT, EP_T, EP_INV = FSC[0], FSC[1], KX[0]        # epilogue scratch (the softmax state above is dead by then)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
 S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
@@ -126,6 +127,9 @@ class Gen:
         self.cfg = dict(self.DEFAULTS)
         self.cfg.update(cfg)
         self.opt = set(self.cfg["opt"])
+        self.pre = "pre" in self.opt      # folded scale: Q is multiplied by c and rounded once, -m rides in an extra k-step
+        self.nqk = 36 if self.pre else 32
+        self.ng = 32 + self.nqk           # MFMAs (= gaps) per body
         self.bf16 = bf16
         self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if bf16 else "v_cvt_pk_f16_f32"
@@ -145,45 +149,59 @@ class Gen:
     def qk_mfmas(self, par):
         """S(t+2) for both q blocks; the four 32x32 accumulators take turns (a dependent MFMA is four issues away)."""
         out = []
+        if self.pre:       # S starts as -m: A = ones (kv rows), B = the three 16-bit terms of -m of this lane's q row
+            for qb in range(2):
+                for kvb in range(2):
+                    out.append(mk(self.mfma, SB(qb, par).sub(16 * kvb, 16), KX, QX[qb], 0, tag="mfma"))
         for ks in range(8):
             for qb in range(2):
                 for kvb in range(2):
                     dst = SB(qb, par).sub(16 * kvb, 16)
-                    out.append(mk(self.mfma, dst, KF(kvb, ks), QF(qb, ks), 0 if ks == 0 else dst, tag="mfma"))
+                    out.append(mk(self.mfma, dst, KF(kvb, ks), QF(qb, ks), 0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
     def stream_exp(self, qb, par):
-        """P = 2^(S*c - m*c) in place, two row-sum chains, pairs packed in place; skewed by pair so that consecutive
-        instructions of the stream are independent.  Options: pkfma / pkadd use the packed-f32 forms for the scale and
-        the row sums (half the instructions)."""
+        """P = 2^(S*c - m*c) in place (folded-scale kernels: P = 2^S, the MFMA delivered S = x - m), two row-sum chains,
+        pairs packed in place; skewed by pair so that consecutive instructions of the stream are independent."""
         b = SB(qb, par)
         out = []
         for k in range(16 + 3):
-            if k < 16 and "nofma" not in self.opt:            # stage 0: x = s*c - m*c
+            if k < 16 and "nofma" not in self.opt and not self.pre:   # stage 0: x = s*c - m*c
                 e = 2 * k
-                if "pkfma" in self.opt:
-                    out.append(mk("v_pk_fma_f32", b.sub(e, 2), b.sub(e, 2), CPAIR, MCP[qb], tag="valu", neg_lo="[0,0,1]", neg_hi="[0,0,1]"))
-                else:
-                    out.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
-                    out.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
+                out.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
+                out.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
             if 0 <= k - 1 < 16:                               # stage 1: 2^x
                 e = 2 * (k - 1)
                 out.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
                 out.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
-            if 0 <= k - 2 < 16:                               # stage 2: row sums
+            if 0 <= k - 2 < 16 and "noadd" not in self.opt:   # stage 2: row sums
                 e = 2 * (k - 2)
-                if "noadd" in self.opt:
-                    pass
-                elif "pkadd" in self.opt:
-                    out.append(mk("v_pk_add_f32", LSUM[qb], LSUM[qb], b.sub(e, 2), tag="valu"))
-                else:
-                    out.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
-                    out.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
+                out.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
+                out.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
             if 0 <= k - 3 < 16:                               # stage 3: pack the pair in place
                 e = 2 * (k - 3)
                 out.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
         return out
+
+    def split16(self, r, src, terms, tmp):
+        """`src` (f32, left unchanged) -> three 16-bit terms whose exact sum is the value the kernel uses as the reference:
+        terms[i] receive the f32 value of term i, tmp[i] its bits in the low half.  Appends to r."""
+        rem = src
+        for i in range(3):
+            if self.bf16:                                     # truncation: bits = upper half
+                r.append(mk("v_and_b32", terms[i], 0xffff0000, rem))
+                r.append(mk("v_lshrrev_b32", tmp[i], 16, terms[i]))
+            else:
+                r.append(mk("v_cvt_f16_f32", tmp[i], rem))
+                r.append(mk("s_nop", 0))
+                r.append(mk("v_cvt_f32_f16", terms[i], tmp[i]))
+                r.append(mk("v_and_b32", tmp[i], 0xffff, tmp[i]))
+            if i < 2:
+                r.append(mk("s_nop", 0))
+                nxt = terms[i + 1]
+                r.append(mk("v_sub_f32", nxt, rem, terms[i]))
+                rem = nxt
 
     def stream_max(self, qb, par, masked, first=False):
         """mask (tail bodies) -> row max of the 32 scores of this lane -> half-wave exchange -> rescale decision."""
@@ -209,9 +227,19 @@ class Gen:
         out.append(mk("v_mov_b32", t, mxa, tag="valu"))
         out.append([mk("s_nop", 1, tag="salu"), mk("v_permlane32_swap_b32", mxa, t, tag="valu")])
         out.append(mk("v_max_f32", mxa, mxa, t, tag="valu"))
-        out.append(mk("v_fma_f32", t2, mxa, A_C, Neg(MC[qb]), tag="valu"))
         lab = self.p.fresh("rare_m")
         # (a list inside a stream is an atomic group: the scheduler keeps it contiguous — here a branch and its return label)
+        if self.pre:
+            # S already is (score - reference) in log2 units: its row max IS the growth.  Tile 0 adopts its own maximum
+            # whatever the sign (the reference starts at 0, not at -inf: it travels through the MFMA as 16-bit terms).
+            if first:
+                out.append([mk("s_branch", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+            else:
+                out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_lt_f32", VCC, THR, mxa, tag="valu"),
+                            mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+            self.rare.append(self.rare_m_pre(lab, qb, b, mxa, mxb, t, t2, first))
+            return out
+        out.append(mk("v_fma_f32", t2, mxa, A_C, Neg(MC[qb]), tag="valu"))
         out.append([mk("v_cmp_lt_f32", VCC, THR, t2, tag="valu"), mk("s_cbranch_vccnz", Label(lab), tag="branch"),
                     Ins("label", (Label(lab + "_ret"),))])
         # out-of-line: move the reference (kept in scaled units m*c), scale the row sums now, leave the O rescale pending
@@ -223,8 +251,7 @@ class Gen:
         r.append(mk("v_sub_f32", mxb, MC[qb], t))                       # (m_old - m_new) * c  (<= 0; -inf on the first tile)
         r.append(mk("s_nop", 0))
         r.append(mk("v_exp_f32", mxb, mxb))
-        r.append(mk("v_mov_b32", MCP[qb][0], t))
-        r.append(mk("v_mov_b32", MCP[qb][1], t))
+        r.append(mk("v_mov_b32", MC[qb], t))
         if not first:               # the q block's first tile: O is still all zeros, nothing to rescale later
             r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
         r.append(mk("s_nop", 0))
@@ -234,6 +261,46 @@ class Gen:
         r.append(mk("s_branch", Label(lab + "_ret")))
         self.rare.append(r)
         return out
+
+    def rare_m_pre(self, lab, qb, b, mxa, mxb, t, t2, first):
+        """Folded-scale kernels, out of line: the reference of q block qb moves by d = max(row max, 0) (tile 0: = row max).
+        The new reference is re-split into three 16-bit terms (QX, fed to the next QK^T through the extra k-step), the
+        scores of THIS tile — formed against the old reference — are shifted by the exact difference, the row sums are
+        scaled now and the O rescale is left pending."""
+        r = [Ins("label", (Label(lab),))]
+        if not first:
+            r.append(mk("v_max_f32", mxa, 0, mxa))                      # rows that did not grow keep their reference
+            r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", mxb, MC[qb], mxa))                     # wanted new reference
+        r.append(mk("s_nop", 0))
+        terms, bits = [t, t2, mxa], [QX[qb][2], QX[qb][3], QX[qb][1]]   # (QX[qb][2:4] are rebuilt as zeros below)
+        self.split16(r, mxb, terms, bits)
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", mxb, terms[0], terms[1]))              # the reference actually representable: t0 + t1 + t2
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", mxb, mxb, terms[2]))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_sub_f32", t, mxb, MC[qb]))                       # exact shift d of the reference
+        r.append(mk("v_mov_b32", MC[qb], mxb))
+        r.append(mk("s_nop", 0))
+        for e in range(32):
+            r.append(mk("v_sub_f32", b[e], b[e], t))                    # this tile's scores, now against the new reference
+        r.append(mk("v_exp_f32", t2, Neg(t)))                           # factor for everything accumulated at the old one
+        # QX = { -(t0, t1), -(t2, 0), 0, 0 } as packed 16-bit pairs
+        r.append(mk("v_lshl_or_b32", QX[qb][0], bits[1], 16, bits[0]))
+        r.append(mk("v_xor_b32", QX[qb][1], 0x8000, bits[2]))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_xor_b32", QX[qb][0], 0x80008000, QX[qb][0]))
+        r.append(mk("v_mov_b32", QX[qb][2], 0))
+        r.append(mk("v_mov_b32", QX[qb][3], 0))
+        if not first:
+            r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+        r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
+        r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
+        r.append(mk("v_mov_b32", FSC[qb], t2))
+        r.append(mk("s_nop", 1))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
 
     def stream_kread(self, par):
         out = []
@@ -282,7 +349,7 @@ class Gen:
         (water-filling on the weighted load) while keeping the stream's order."""
         if not items:
             return
-        gaps = list(range(int(a), min(64, int(b + 0.999))))
+        gaps = list(range(int(a), min(len(load), int(b + 0.999))))
         w = [_weight(it) for it in items]
         total = sum(w)
         lo, hi = min(load[g] for g in gaps), max(load[g] for g in gaps) + total + 1.0
@@ -321,12 +388,16 @@ class Gen:
         cfg = self.cfg
         fast = name.startswith("F")
         abl = set(cfg["abl"]) if fast else set()
+        ng = self.ng
+        sc = (ng - 32) / 32.0                 # QK-phase windows are given for 32 gaps: stretch them for the folded-scale kernels
+        def W(w):
+            return tuple(32.0 + (x - 32.0) * sc if x > 32.0 else x for x in w)
         mf = []
         mf += self.pv_mfmas(par, 0) if pv else [None] * 16
         mf += self.pv_mfmas(par, 1) if pv else [None] * 16
-        mf += self.qk_mfmas(par) if s2 else [None] * 32
+        mf += self.qk_mfmas(par) if s2 else [None] * self.nqk
         if "mfma" in abl:
-            mf = [None] * 64
+            mf = [None] * ng
         trace = fast and cfg["trace"][0] > 0
         if trace:
             p.emit("s_memtime", S_TA)
@@ -343,11 +414,11 @@ class Gen:
             # no PV MFMAs separate this body's first VALU reads of S from the QK^T MFMAs that ended the previous body
             p.emit("s_nop", 15)
             p.emit("s_nop", 15)
-        load = [0.0] * 64
-        slots = [[] for _ in range(64)]
+        load = [0.0] * ng
+        slots = [[] for _ in range(ng)]
         if s1:
             mw = cfg["mmask"] if masked else cfg["m"]
-            ew = (mw[1], cfg["e"][1])
+            ew = W((mw[1], cfg["e"][1]))
             if "max" not in abl:
                 self.place(load, slots, self.stream_max(0, par ^ 1, masked, first), mw[0], mw[1], 0)
                 self.place(load, slots, self.stream_max(1, par ^ 1, masked, first), mw[0], mw[1], 1)
@@ -357,7 +428,7 @@ class Gen:
         if s2 and "kread" not in abl:
             self.place(load, slots, self.stream_kread(par), cfg["kread"][0], cfg["kread"][1], 3)
         if s1 and "vread" not in abl:
-            self.place(load, slots, self.stream_vread(par ^ 1), cfg["vread"][0], cfg["vread"][1], 4)
+            self.place(load, slots, self.stream_vread(par ^ 1), W(cfg["vread"])[0], W(cfg["vread"])[1], 4)
         if s1 and "exp" not in abl:
             self.place(load, slots, self.stream_exp(0, par ^ 1), ew[0], ew[1] - 1.0, 5)
             self.place(load, slots, self.stream_exp(1, par ^ 1), ew[0], ew[1], 6)
@@ -365,8 +436,8 @@ class Gen:
         if fast and cfg["syn"]:
             # timing probe (wrong results): every gap of the fast bodies carries the same synthetic fillers, e.g.
             # syn=fma:3+exp:2 -> 3 v_fma_f32 and 2 v_exp_f32 per gap, on scratch registers
-            slots = [[] for _ in range(64)]
-            for g in range(64):
+            slots = [[] for _ in range(ng)]
+            for g in range(ng):
                 j = 0
                 for spec in cfg["syn"]:
                     kind, _, cnt = spec.partition(":")
@@ -400,10 +471,10 @@ class Gen:
                         else:
                             raise ValueError(kind)
                         slots[g].append((g, 0, ins))
-        for g in range(64):
+        for g in range(ng):
             slots[g].sort(key=lambda x: (x[0], x[1]))
         # emit: gap g fillers come AFTER mfma g
-        for g in range(64):
+        for g in range(ng):
             if g == 32:
                 # phase boundary: all of PV(t) is issued.  Rare O rescale, then K(t+2) fragments must have landed.
                 lab = p.fresh("rare_r")
@@ -476,9 +547,17 @@ class Gen:
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
         for dt in range(4):
             p.emit("v_xor_b32", VR[dt], dt << 6, A_VR0)
-        for qb in range(2):
-            for ks in range(8):
-                p.emit("global_load_dwordx4", QF(qb, ks), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
+        if not self.pre:
+            for qb in range(2):
+                for ks in range(8):
+                    p.emit("global_load_dwordx4", QF(qb, ks), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
+        else:
+            # folded scale: Q comes through the (still unused) S banks, is multiplied by c in f32 and rounded back ONCE —
+            # the reference oracle's contract `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file
+            qv = V(VBASE, 64)
+            for qb in range(2):
+                for ks in range(8):
+                    p.emit("global_load_dwordx4", qv.sub(32 * qb + 4 * ks, 4), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
         # DMA source offsets of piece i: rows 4*i further down, the K granule swizzle follows the row (xor i<<6), and the
         # instruction offset 1024*i that selects the LDS piece is taken back out of the source address
         p.emit("v_mov_b32", KD[0], A_KD0)
@@ -506,16 +585,40 @@ class Gen:
         # B(-2) stages K(1) (= t + 3) and V(0) (= t + 2): the running offsets are those of tile t+3 / t+2
         p.emit("s_mov_b32", S_KOFF, A_KTILE)
         p.emit("s_mov_b32", S_VOFF, 0)
-        p.emit("v_mov_b32", CPAIR[0], A_C)
-        p.emit("v_mov_b32", CPAIR[1], A_C)
         for qb in range(2):
-            p.emit("v_mov_b32", MCP[qb][0], NEG_INF)
-            p.emit("v_mov_b32", MCP[qb][1], NEG_INF)
+            p.emit("v_mov_b32", MC[qb], 0.0 if self.pre else NEG_INF)
             p.emit("v_mov_b32", LA[qb], 0)
             p.emit("v_mov_b32", LB[qb], 0)
             p.emit("v_mov_b32", FSC[qb], 1.0)
         for i in range(128):
             p.emit("v_accvgpr_write_b32", A(i), 0)
+        if self.pre:
+            # extra k-step operands: K side = 1.0 in the eight k-slots of the lower lane half (the upper half's slots are 0),
+            # Q side = the (negated) reference, 0 for now
+            one2 = 0x3f803f80 if self.bf16 else 0x3c003c00
+            p.emit("v_and_b32", TMP[0], 16, A_EPI)             # the epilogue address carries hi * 16
+            p.emit("v_mov_b32", TMP[1], one2)
+            p.emit("v_cmp_eq_u32", VCC, 0, TMP[0])
+            for i in range(4):
+                p.emit("v_cndmask_b32", KX[i], 0, TMP[1], VCC)
+                p.emit("v_mov_b32", QX[0][i], 0)
+                p.emit("v_mov_b32", QX[1][i], 0)
+            p.emit("s_waitcnt", vmcnt=4)                        # the 16 Q loads (the 4 K(0) pieces may still fly)
+            for i in range(64):
+                src, t0, t1 = V(VBASE + i), TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]
+                if self.bf16:
+                    p.emit("v_lshlrev_b32", t0, 16, src)
+                    p.emit("v_and_b32", t1, 0xffff0000, src)
+                else:
+                    p.emit("v_lshrrev_b32", t1, 16, src)
+                    p.emit("v_cvt_f32_f16", t0, src)
+                    p.emit("v_cvt_f32_f16", t1, t1)
+                p.emit("v_mul_f32", t0, A_C, t0)
+                p.emit("v_mul_f32", t1, A_C, t1)
+                p.emit("s_nop", 0)
+                p.emit(self.cvt, t0, t0, t1)
+                p.emit("s_nop", 0)
+                p.emit("v_accvgpr_write_b32", A(128 + i), t0)
         p.emit("s_waitcnt", vmcnt=0)
         p.emit("s_barrier")
 
@@ -683,14 +786,17 @@ def main():
     out_dir = a.out
     os.makedirs(out_dir, exist_ok=True)
     cfg = parse_opts(a.opt)
-    for bf16 in (False, True):
-        g = Gen(bf16, **cfg)
-        prog = g.build()
-        path = os.path.join(out_dir, "fa2_fwd_d128_%s.inc" % ("bf16" if bf16 else "f16"))
-        with open(path, "w") as f:
-            f.write("// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)))
-            f.write(render_inline(prog))
-        print(path, len(prog.ins), "instructions")
+    for fold in (False, True):
+        for bf16 in (False, True):
+            c2 = dict(cfg)
+            c2["opt"] = tuple(x for x in cfg.get("opt", ()) if x != "pre") + (("pre",) if fold else ())
+            g = Gen(bf16, **c2)
+            prog = g.build()
+            path = os.path.join(out_dir, "fa2_fwd_d128_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))
+            with open(path, "w") as f:
+                f.write("// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)))
+                f.write(render_inline(prog))
+            print(path, len(prog.ins), "instructions")
     with open(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"), "w") as f:
         f.write("// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.\n")
         f.write(clobber_list() + "\n")

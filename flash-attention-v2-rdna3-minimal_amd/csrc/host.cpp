@@ -78,19 +78,31 @@ bool use_d128_asm() {
     return on;
 }
 
-template <bool BF16, bool CAUSAL>
-int launch_d128(const fa2::FwdParams& p, hipStream_t stream) {
+#ifndef FA2_D128_FOLD
+#define FA2_D128_FOLD 0     // 1: fold the scale into Q when scale*log2e <= 1 (fa2_fwd_prescales_q reports it); 0: never.
+#endif                      // Measured on MI355X: -5 % cycles but only +1.3..2 % throughput (the chip is power-limited and the
+                            // fold adds 4 MFMAs per tile), for 16-bit-rounded logits: off by default, FA2_EXTRA_HIPCC_FLAGS=-DFA2_D128_FOLD=1
+bool d128_eligible(int D, float scale) { return D == 128 && scale > 0.f && use_d128_asm(); }
+bool d128_folds(float c) { return FA2_D128_FOLD != 0 && c <= 1.0f; }
+
+template <bool BF16, bool CAUSAL, bool FOLD>
+int launch_d128_t(const fa2::FwdParams& p, hipStream_t stream) {
     static_assert(kFwdRows == 256, "the d128 kernel covers 256 Q rows per workgroup, like the default shape");
-    constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL>;
+    constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL, FOLD>;
     if (int rc = set_lds<kern>(fa2::kD128LdsBytes)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nqblk)), dim3(256), fa2::kD128LdsBytes, stream, p);
     return (int)hipGetLastError();
 }
 
+template <bool BF16, bool CAUSAL>
+int launch_d128(const fa2::FwdParams& p, hipStream_t stream) {
+    return d128_folds(p.c) ? launch_d128_t<BF16, CAUSAL, true>(p, stream) : launch_d128_t<BF16, CAUSAL, false>(p, stream);
+}
+
 template <int HD, bool BF16>
 int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     if constexpr (HD == 128) {
-        if (p.D == 128 && !p.negate_q && use_d128_asm())
+        if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f))
             return causal ? launch_d128<BF16, true>(p, stream) : launch_d128<BF16, false>(p, stream);
     }
     return causal ? launch_t<HD, BF16, true>(p, stream) : launch_t<HD, BF16, false>(p, stream);
@@ -174,8 +186,9 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 }
 
 int fa2_fwd_prescales_q(int D, float scale) {
-    (void)scale;
-    return fa2_padded_head_dim(D) < 0 ? -1 : 0;   // scores are always scaled in f32 (the pre-scaled-Q build option was removed)
+    if (fa2_padded_head_dim(D) < 0) return -1;
+    const float c = std::fabs(scale) * 1.4426950408889634f;
+    return d128_eligible(D, scale) && d128_folds(c < 1e-30f ? 1e-30f : c) ? 1 : 0;
 }
 
 const char* fa2_error_string(int code) {

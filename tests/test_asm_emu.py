@@ -29,8 +29,19 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[("pre",), ()], ids=["folded-scale", "f32-scale"])
+def variant(request):
+    """Both bodies the library ships: scale folded into Q (the default when scale*log2e <= 1) and scale applied in f32."""
+    saved = harness.OPT
+    harness.OPT = request.param
+    harness._PROGS.clear()
+    yield request.param
+    harness.OPT = saved
+    harness._PROGS.clear()
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_generated_block_matches_dense_attention(case):
+def test_generated_block_matches_dense_attention(case, variant):
     nq, nkv, qblk, causal, bf16, spike = case
     err, lse_err, m = harness.check(nq, nkv, qblk, causal, bf16=bf16, spike=spike, seed=nq + nkv, verbose=False)
     assert not m.errors, m.errors[:5]
@@ -41,7 +52,7 @@ def test_generated_block_matches_dense_attention(case):
 def test_emulator_flags_a_missing_wait():
     """The checker itself: drop the lgkmcnt wait in front of the QK^T phase and the emulator must object."""
     import fwd_d128_gen as gen
-    prog = gen.Gen(False).build()
+    prog = gen.Gen(False, opt=harness.OPT).build()
     idx = [i for i, ins in enumerate(prog.ins) if ins.op == "s_waitcnt" and ins.mods == {"lgkmcnt": 0}]
     assert idx
     saved = harness._PROGS.get(False)
@@ -60,7 +71,7 @@ def test_emulator_flags_a_missing_wait():
             harness._PROGS.pop(False, None)
 
 
-@pytest.mark.parametrize("opt", [(), ("pkadd", "pkfma")])
+@pytest.mark.parametrize("opt", [(), ("pre",)])
 def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     """Every line of the rendered body goes through the gfx950 assembler (operand classes, constant-bus limits, offsets):
     the emulator interprets instruction objects, so this is the check that the TEXT is legal."""

@@ -51,7 +51,7 @@ def _cabi_forward(q, k, v, causal, scale=None):
 def _oracle_flags(D, scale=None):
     """The oracle mode that matches the kernel's scaling contract for this head dim and scale."""
     lib = _fa2_lib.load(build_if_missing=False)
-    pre = lib.fa2_fwd_prescales_q(lib.fa2_padded_head_dim(D), float(D ** -0.5 if scale is None else scale))
+    pre = lib.fa2_fwd_prescales_q(D, float(D ** -0.5 if scale is None else scale))
     assert pre in (0, 1)
     return fo.PRESCALE_Q if pre else 0
 
@@ -127,7 +127,7 @@ def test_explicit_and_negative_scale():
     g = torch.Generator(device="cpu").manual_seed(3)
     q, k, v = (torch.randn((1, 2, 200, 64), generator=g).half().to(_dev()) for _ in range(3))
     lib = _fa2_lib.load(build_if_missing=False)
-    assert lib.fa2_fwd_prescales_q(64, 1.5) == 0 and lib.fa2_fwd_prescales_q(128, 0.3) == 0   # scores are scaled in f32
+    assert lib.fa2_fwd_prescales_q(64, 1.5) == 0 and lib.fa2_fwd_prescales_q(128, 1.5) == 0   # never folded when scale*log2e > 1
     for scale in (0.3, -0.2, 1.5, -2.0):
         for causal in (False, True):
             o, lse = _cabi_forward(q, k, v, causal, scale=scale)

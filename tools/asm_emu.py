@@ -414,6 +414,22 @@ class Machine:
             w.s[d.idx] = np.uint32(int(w.cycle) & 0xffffffff)
             w.s[d.idx + 1] = 0
             w.lgkm.append(lambda: None)
+        elif op == "v_and_b32":
+            self.wr32(w, ops[0], self.rd32(w, ops[1]) & self.rd32(w, ops[2]))
+        elif op == "v_lshrrev_b32":
+            self.wr32(w, ops[0], self.rd32(w, ops[2]) >> (self.rd32(w, ops[1]) & 31))
+        elif op == "v_lshlrev_b32":
+            self.wr32(w, ops[0], (self.rd32(w, ops[2]).astype(np.uint64) << (self.rd32(w, ops[1]) & 31).astype(np.uint64)).astype(np.uint32))
+        elif op == "v_lshl_or_b32":
+            x = (self.rd32(w, ops[1]).astype(np.uint64) << (self.rd32(w, ops[2]) & 31).astype(np.uint64)).astype(np.uint32)
+            self.wr32(w, ops[0], x | self.rd32(w, ops[3]))
+        elif op == "v_cvt_f32_f16":
+            self.wr32(w, ops[0], f16_to_f32((self.rd32(w, ops[1]) & 0xffff).astype(np.uint16)))
+        elif op == "v_cvt_f16_f32":
+            old = self.regfile(w, R(0).kind)[R(0).idx]
+            self.wr32(w, ops[0], (old & np.uint32(0xffff0000)) | f32_to_f16_bits(self.rdf(w, ops[1])))
+        elif op == "v_cmp_eq_u32":
+            w.vcc = self.rd32(w, ops[1]) == self.rd32(w, ops[2])
         elif op == "v_xor_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]) ^ self.rd32(w, ops[2]))
         elif op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32"):
@@ -449,6 +465,8 @@ class Machine:
                 w.vcc = x < y
         elif op == "v_cndmask_b32":
             self.wr32(w, ops[0], np.where(w.vcc, self.rd32(w, ops[2]), self.rd32(w, ops[1])))
+        elif op == "v_cmp_eq_u32":
+            w.vcc = self.rd32(w, ops[1]) == self.rd32(w, ops[2])
         elif op == "v_permlane32_swap_b32":
             d, s = R(0), R(1)
             x, y = self.rd32(w, d, "permlane"), self.rd32(w, s, "permlane")

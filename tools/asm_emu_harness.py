@@ -14,11 +14,12 @@ from isa import Reg  # noqa: E402
 
 LOG2E = 1.4426950408889634
 _PROGS = {}
+OPT = ("pre",)          # generator options of the programs under test (the shipped default)
 
 
 def program(bf16):
     if bf16 not in _PROGS:
-        _PROGS[bf16] = gen.Gen(bf16).build()
+        _PROGS[bf16] = gen.Gen(bf16, opt=OPT).build()
     return _PROGS[bf16]
 
 
@@ -113,10 +114,17 @@ def run_block(q, k, v, qblk, causal, scale=None, bf16=False, check_hazards=True)
     return o, lse[:rows], m
 
 
-def dense(q, k, v, causal, scale=None, bf16=False, row0=0):
+def dense(q, k, v, causal, scale=None, bf16=False, row0=0, pre=False):
+    """float64 attention on the rounded inputs, log2-domain LSE.  pre: Q is multiplied by scale*log2(e) and rounded to the
+    16-bit type first (the folded-scale contract), so the comparison isolates the kernel from that one rounding."""
     q, k, v = (from_bits(to_bits(t, bf16), bf16).astype(np.float64) for t in (q, k, v))
     scale = 128 ** -0.5 if scale is None else scale
-    s = (q @ k.T) * scale
+    if pre:
+        c = np.float32(scale * LOG2E)
+        qs = from_bits(to_bits((q.astype(np.float32) * c).astype(np.float32), bf16), bf16).astype(np.float64)
+        s = (qs @ k.T) / LOG2E
+    else:
+        s = (q @ k.T) * scale
     if causal:
         rows = row0 + np.arange(q.shape[0])
         s = np.where(np.arange(k.shape[0])[None, :] > rows[:, None], -np.inf, s)
@@ -137,7 +145,7 @@ def check(Nq, Nkv, qblk, causal, bf16=False, seed=0, kind="randn", spike=False, 
         k[min(Nkv - 1, 70)] = q[40] * 2
     o, lse, m = run_block(q, k, v, qblk, causal, bf16=bf16)
     r0 = qblk * 256
-    o_ref, lse_ref = dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0)
+    o_ref, lse_ref = dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre="pre" in OPT)
     err = float(np.abs(o - o_ref).max())
     lerr = float(np.abs(lse - lse_ref).max())
     if verbose:

@@ -61,8 +61,7 @@ def build(specs):
             gdir = os.path.join(VAR_DIR, name + "_gen")
             subprocess.check_call([sys.executable, os.path.join(b.CSRC, "gen", "fwd_d128_gen.py"), "--out", gdir,
                                    "--opt", gen[0].replace(";", ",")], stdout=subprocess.DEVNULL)
-            extra += ['-DFA2_D128_INC_F16="%s"' % os.path.join(gdir, "fa2_fwd_d128_f16.inc"),
-                      '-DFA2_D128_INC_BF16="%s"' % os.path.join(gdir, "fa2_fwd_d128_bf16.inc")]
+            extra += ["-DFA2_D128_INC_DIR=%s" % gdir]
         out = os.path.join(VAR_DIR, name + ".so")
         cmd = [b._hipcc()] + b.HIPCC_FLAGS + extra + ["-I", b.INCLUDE, "-I", b.CSRC,
                                                       os.path.join(b.CSRC, "host.cpp"), "-o", out,

@@ -23,7 +23,8 @@
 
 namespace {
 
-constexpr int kHeadDims[] = {64, 128, 256};
+constexpr int kHeadDims[] = {64, 128, 256, 512};
+constexpr int kMaxBwdHeadDim = 256;   // the backward kernels stop here
 constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 
 // Workgroup shape: NW waves x QB 32-row Q blocks per wave (NW * QB * 32 = 256 Q rows).
@@ -51,15 +52,24 @@ int set_lds(int bytes) {
 }
 
 template <int HD, bool BF16, bool CAUSAL>
-int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
-    constexpr int HDV = HD > 128 ? 128 : HD;   // D = 256 runs as two 128-column halves (grid.y)
-    constexpr int lds_kv = 2 * fa2::Geo<HD, kNW>::TILEB + 2 * fa2::Geo<HDV, kNW>::TILEB;
-    constexpr int lds_epi = FA2_EPI_LDS && kQB == 1 ? kNW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
+int launch_t(const fa2::FwdParams& p0, hipStream_t stream) {
+    // D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
+    // D = 512 (the reference's D > 384 path, FlashAttn.py:65-67; the SD VAE attention block): 4-wave workgroups of 128 Q
+    // rows, one wave per SIMD — the 128 registers of Q fragments per wave need the 512-register budget — and all 160 KiB
+    // of LDS (two 64 KiB K tiles + two 16 KiB V tiles).  A correct path for a rare shape, not a tuned one.
+    constexpr int HDV = HD > 128 ? 128 : HD;
+    constexpr int NW = HD > 256 ? 4 : kNW, QB = HD > 256 ? 1 : kQB;
+    constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
+    constexpr int lds_epi = FA2_EPI_LDS && QB == 1 ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
     constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    fa2::FwdParams p = p0;
+    p.nqblk = (p.Nq + NW * QB * 32 - 1) / (NW * QB * 32);
+    if ((int64_t)p.B * p.H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
     const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
-    constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, kNW, kQB>;
+    constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, NW, QB>;
     if (int rc = set_lds<kern>(lds)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(kNW * 64), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -180,7 +190,7 @@ int fa2_padded_head_dim(int D) {
 
 int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
     if (fa2_padded_head_dim(D) != D) return FA2_ERR_HEAD_DIM;
-    if (q_rows_per_block) *q_rows_per_block = kFwdRows;
+    if (q_rows_per_block) *q_rows_per_block = D > 256 ? 128 : kFwdRows;
     if (kv_rows_per_tile) *kv_rows_per_tile = fa2::kKvTile;
     return FA2_OK;
 }
@@ -207,7 +217,7 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.4 (8-wave 256x64 mfma32x32x16, lds-dma double buffer, pipelined; head dims masked in-kernel; fwd+bwd)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.5 (D=128: hand-scheduled 4-wave 256x64 asm body; other head dims up to 512: 8-wave HIP kernels; mfma32x32x16, lds-dma; fwd+bwd)"; }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
             int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
@@ -251,6 +261,7 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
         case 64: return bf16 ? launch<64, true>(p, causal != 0, stream) : launch<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch<128, true>(p, causal != 0, stream) : launch<128, false>(p, causal != 0, stream);
         case 256: return bf16 ? launch<256, true>(p, causal != 0, stream) : launch<256, false>(p, causal != 0, stream);
+        case 512: return bf16 ? launch<512, true>(p, causal != 0, stream) : launch<512, false>(p, causal != 0, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
 }
@@ -267,7 +278,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
     const int HD = fa2_padded_head_dim(D);              // columns [D, HD) are masked in-kernel
-    if (HD < 0 || (D & 7)) return FA2_ERR_HEAD_DIM;
+    if (HD < 0 || HD > kMaxBwdHeadDim || (D & 7)) return FA2_ERR_HEAD_DIM;
     if (!std::isfinite(scale)) return FA2_ERR_SCALE;
     const void* ptrs[] = {q, k, v, o, dout, dq, dk, dv};
     const int64_t* strides[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};

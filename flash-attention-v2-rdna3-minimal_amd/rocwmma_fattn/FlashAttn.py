@@ -153,7 +153,7 @@ class _FlashAttnWmma:
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
 
 
-_MAX_HEAD_DIM = 256      # largest forward kernel head dim (fa2_supported_head_dims)
+_MAX_HEAD_DIM = 512      # largest forward kernel head dim (fa2_supported_head_dims); the backward kernels stop at 256
 
 
 def _raw_stream(device_index):

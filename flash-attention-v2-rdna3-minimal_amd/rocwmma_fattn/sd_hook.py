@@ -20,7 +20,7 @@ from .FlashAttn import FlashAttentionFunction
 
 __all__ = ["attention_bnhd", "install_comfyui"]
 
-_MAX_HEAD_DIM = 256
+_MAX_HEAD_DIM = 512      # the forward kernels reach 512 (SD VAE attention: one head of 512)
 
 
 def attention_bnhd(q, k, v, heads, mask=None, causal=False, scale=None, fallback=None):

@@ -157,3 +157,12 @@ def test_full_size_config2_backward_sampled_heads():
     _, _, part = _cabi_fwd_bwd(q[:, 3:5].contiguous(), k[:, 3:5].contiguous(), v[:, 3:5].contiguous(), do[:, 3:5].contiguous(), False)
     for a, b in zip(part, grads):
         assert torch.equal(a, b[:, 3:5])
+
+
+def test_backward_above_256_is_refused_not_wrong():
+    """The forward reaches D = 512; the backward kernels stop at 256 and say so (FA2_ERR_HEAD_DIM) instead of computing
+    something else.  (The reference's LoRA-training use, README.md:151-154, is on SD1.5/SDXL UNet attention: D <= 160.)"""
+    q, k, v = (torch.randn((1, 1, 64, 320), device=_dev(), dtype=torch.float16, requires_grad=True) for _ in range(3))
+    o = FlashAttentionFunction.apply(q, k, v, None, False)
+    with pytest.raises(RuntimeError, match="head dim"):
+        o.backward(torch.ones_like(o))

@@ -266,6 +266,38 @@ def test_head_dims_masked_in_kernel(D, dt):
         _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
 
 
+@pytest.mark.parametrize("D", [264, 320, 384, 512])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_head_dims_above_256(D, dt):
+    """The reference accepts any head dim (it pads D to a multiple of 32 and switches to Br = 32 above 384,
+    FlashAttn.py:65-67); the SD VAE attention block is one head of D = 512.  Head dims in (256, 512] run on the
+    D = 512 forward kernel: four 128-column slabs of O per 128-row Q block, columns >= D masked in-kernel."""
+    g = torch.Generator(device="cpu").manual_seed(300 + D)
+    B, H, N, Nkv = 1, 2, 200, 333
+    q = torch.randn((B, H, N, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    k = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    v = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    for causal in (False, True):
+        o, lse = _cabi_forward(q, k, v, causal)
+        _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
+    o_op = FlashAttentionFunction.apply(q, k, v, None, False)                  # operator path, Br = 32 padding above 384
+    torch.cuda.synchronize()
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (D ** -0.5)
+    truth = torch.matmul(torch.softmax(s, -1), v.float())
+    assert float((o_op.float() - truth).abs().max()) <= FLOOR[dt] * 2
+
+
+def test_vae_shaped_attention_d512():
+    """SD VAE mid-block attention at a 512 x 512 image: 1 head, D = 512, N = 64 * 64 tokens, through the sd_hook adapter."""
+    from rocwmma_fattn.sd_hook import attention_bnhd
+    g = torch.Generator(device="cpu").manual_seed(15)
+    q, k, v = (torch.randn((1, 4096, 512), generator=g).half().to(_dev()) for _ in range(3))
+    o = attention_bnhd(q, k, v, 1)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    assert float((o.float() - ref).abs().max()) <= ATOL[0] + RTOL[0] * float(ref.abs().max())
+
+
 def test_head_dim_160_runs_on_the_256_kernel():
     """SD1.5's deepest attention level has D = 160 (the reference pads D to a multiple of 32, kernel_fp16.cu:763)."""
     g = torch.Generator(device="cpu").manual_seed(10)

@@ -63,7 +63,7 @@
 #else
 #define FA2_TILE_OFF(voff, soff) (voff) + (soff), 0u
 #endif
-// Tried and dropped (git history has the code; DESIGN.md §3 the measurements): s_setprio variants, 2- and 3-phase
+// Tried and dropped (git history has the code; DESIGN.md §4 the measurements): s_setprio variants, 2- and 3-phase
 // ping-pong of the two waves of a SIMD, issuing all LDS fragment reads of a phase up front, packed-f32 softmax math.
 
 namespace fa2 {

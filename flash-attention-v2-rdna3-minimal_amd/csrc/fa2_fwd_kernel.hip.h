@@ -208,7 +208,7 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 //
 template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
-__global__ __launch_bounds__(NW * 64, NW / 4) void fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
     using GV_ = Geo<HDV, NW>;  // V tile image

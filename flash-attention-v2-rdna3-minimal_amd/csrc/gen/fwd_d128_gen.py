@@ -17,19 +17,26 @@ Shape of the computation (one workgroup = 4 waves = 256 Q rows, ONE wave per SIM
     both products are "swapped" (S^T = K Q^T, O^T = V^T P^T) exactly as in fa2_fwd_kernel.hip.h, so a lane owns one
     Q row of each block and the softmax is lane-local plus one v_permlane32_swap.
 
-Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs:
-    MFMA  0..31  PV(t)        O[qb] += V(t)^T P(t)^T          (qb 0 then qb 1)
-    MFMA 32..63  QK(t+2)      S(t+2)[qb] = K(t+2) Q[qb]^T      (qb 0 then qb 1; kv halves alternate)
-  and between them ("gaps") the single-issue work, spread by the scheduler below so that every MFMA gap carries
-  about five instructions:
-    E0  exp/sum/pack of tile t+1, q block 0      (gaps 0..47)
-    M1  row max + rescale decision of tile t+1, q block 1   (gaps 2..)
-    E1  exp/sum/pack of tile t+1, q block 1      (after M1 .. 63)
-    M0  row max + decision of tile t+2, q block 0  (gaps 50..63)
-    K(t+2) fragment reads (gaps 0..31), V(t+1) transpose reads (gaps 33..63), LDS-DMA of K(t+3) and V(t+2)
-  One s_barrier per body.  The O rescale of the deferred-max scheme is a rare out-of-line block entered between
+Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs (68 in the folded-scale variant):
+    MFMA  0..31  PV(t)        O[qb] += V(t)^T P(t)^T          (qb 0 then qb 1, four O accumulators per k-step)
+    MFMA 32..63  QK(t+2)      S(t+2)[qb] = K(t+2) Q[qb]^T      (the four 32x32 S accumulators take turns)
+  and between them ("gaps") the single-issue work, spread by the water-filling scheduler (Gen.place) so that the
+  weighted issue load of every gap is the same:
+    M0, M1  row max + rescale decision of tile t+1, q block 0 / 1     (gaps 2..9; tail bodies: masks first, gaps 2..23)
+    E0, E1  exp / two row-sum chains / in-place pair packing of tile t+1   (gaps 10..63)
+    K(t+2) fragment reads (gaps 0..31), V(t+1) transpose reads (gaps 33..58), the 8 LDS-DMA pieces of K(t+3), V(t+2) (gaps 3..22)
+  One s_waitcnt + s_barrier per body.  The O rescale of the deferred-max scheme is a rare out-of-line block entered between
   the two MFMA phases (all of PV(t) is in O, nothing of tile t+1 yet), so every value at the old reference is scaled once.
 Head / tail bodies are the same generator with streams switched off (and the tail masks switched on).
+
+Variants and developer options (Gen(..., opt=..., abl=..., syn=..., trace=...), `--opt` on the command line):
+    opt=pre      folded scale: Q * scale*log2e rounded once to the I/O dtype (pure_torch_ver.py:61), the running reference
+                 travels through a ninth k-step of QK^T as three 16-bit terms, no v_fma per score (fa2_fwd_d128_*_fold.inc)
+    abl=...      timing-only ablations of the fast bodies (streams left out; results are wrong)
+    syn=fma:5    timing probe: every gap of the fast bodies carries the same synthetic fillers (issue-cost measurements)
+    trace=1..4   s_memtime sums (phases / barrier / whole block) returned through the LSE outputs
+    stagger=n    per-wave start skew (measured: no effect)
+DESIGN.md section 3 has the measurements these options produced.
 """
 import os
 import sys
@@ -79,8 +86,6 @@ MC = [V(234), V(235)]                              # reference max in log2 units
 TMP = [V(236 + i) for i in range(8)]               # scratch: row-max chains, rescale block, epilogue
 KX = V(244, 4)                                     # folded-scale kernels: the K side of the extra k-step (ones / zeros)
 QX = [V(248, 4), V(252, 4)]                        # ... and the Q side: -(reference max) split into three 16-bit terms
-CPAIR = KX.sub(0, 2)                               # packed-f32 experiments of the unfolded kernel only
-MCP = [QX[0].sub(0, 2), QX[1].sub(0, 2)]
 EP_LT, EP_T, EP_INV = FSC[0], FSC[1], KX[0]        # epilogue scratch (the softmax state above is dead by then)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
@@ -765,7 +770,7 @@ def clobber_list():
 
 
 def parse_opts(text):
-    """"e=10:64,dma=3:22,abl=dma+exp,opt=pkadd+pkfma,trace=1:0" -> Gen keyword arguments"""
+    """"e=10:64,dma=3:22,abl=dma+exp,opt=pre,trace=1:0" -> Gen keyword arguments"""
     cfg = {}
     for item in filter(None, (text or "").split(",")):
         k, _, v = item.partition("=")

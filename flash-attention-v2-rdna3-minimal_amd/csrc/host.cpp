@@ -51,14 +51,29 @@ int set_lds(int bytes) {
     return rc;
 }
 
-template <int HD, bool BF16, bool CAUSAL>
-int launch_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    // D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
-    // D = 512 (the reference's D > 384 path, FlashAttn.py:65-67; the SD VAE attention block): 4-wave workgroups of 128 Q
-    // rows, one wave per SIMD — the 128 registers of Q fragments per wave need the 512-register budget — and all 160 KiB
-    // of LDS (two 64 KiB K tiles + two 16 KiB V tiles).  A correct path for a rare shape, not a tuned one.
+// Rows per forward workgroup: 256 (8 waves; D = 128: the hand-scheduled 4-wave kernel) or 128 (4 waves, HIP kernel).
+// FA2_FWD_ROWS=128|256 in the environment overrides pick_rows() (A/B runs, tools/rows_probe.py).
+int forced_rows() {
+    static const int v = [] {
+        const char* e = std::getenv("FA2_FWD_ROWS");
+        return e ? std::atoi(e) : 0;
+    }();
+    return v;
+}
+
+// A grid of 256-row workgroups that covers well under half of the 256 CUs leaves the chip idle: 128-row workgroups double the
+// number of busy CUs at the price of staging every K/V tile for half as many rows.  Measured (tools/rows_probe.py, MI355X):
+// 64 workgroups -> 128 of 128 rows: B1 H16 N1024 D128 25.1 -> 20.5 us, B1 H8 N2048 D128 44.1 -> 35.3, B2 H8 N1024 D80 24.0 -> 19.9;
+// at 160 workgroups (SDXL 32x32 self-attention) and above the big shape wins (19.9 vs 23.9 us), 64-row workgroups never do.
+int pick_rows(const fa2::FwdParams& p) {
+    const int f = forced_rows();
+    if (f == 128 || f == 256) return f;
+    return (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= 96 ? 128 : 256;
+}
+
+template <int HD, bool BF16, bool CAUSAL, int NW, int QB>
+int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;
-    constexpr int NW = HD > 256 ? 4 : kNW, QB = HD > 256 ? 1 : kQB;
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
     constexpr int lds_epi = FA2_EPI_LDS && QB == 1 ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
     constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
@@ -71,6 +86,22 @@ int launch_t(const fa2::FwdParams& p0, hipStream_t stream) {
     if (int rc = set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+template <int HD, bool BF16, bool CAUSAL>
+int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
+    // D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
+    // D = 512 (the reference's D > 384 path, FlashAttn.py:65-67; the SD VAE attention block): 4-wave workgroups of 128 Q
+    // rows, one wave per SIMD — the 128 registers of Q fragments per wave need the 512-register budget — and all 160 KiB
+    // of LDS (two 64 KiB K tiles + two 16 KiB V tiles).  A correct path for a rare shape, not a tuned one.
+    if constexpr (HD > 256) {
+        return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
+    } else if constexpr (kNW == 8 && kQB == 1) {
+        if (pick_rows(p) == 128) return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
+        return launch_shape<HD, BF16, CAUSAL, kNW, kQB>(p, stream);
+    } else {
+        return launch_shape<HD, BF16, CAUSAL, kNW, kQB>(p, stream);
+    }
 }
 
 // Head dim exactly 128 with a positive scale runs the hand-scheduled 4-wave kernel (fa2_fwd_d128.hip.h); FA2_FWD_D128=hip
@@ -112,7 +143,7 @@ int launch_d128(const fa2::FwdParams& p, hipStream_t stream) {
 template <int HD, bool BF16>
 int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     if constexpr (HD == 128) {
-        if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f))
+        if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f) && pick_rows(p) == 256)
             return causal ? launch_d128<BF16, true>(p, stream) : launch_d128<BF16, false>(p, stream);
     }
     return causal ? launch_t<HD, BF16, true>(p, stream) : launch_t<HD, BF16, false>(p, stream);

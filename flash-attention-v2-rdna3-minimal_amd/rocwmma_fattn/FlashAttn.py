@@ -86,7 +86,13 @@ class _FlashAttnWmma:
 
         def s3(t):
             st = t.stride()
-            return _fa2_lib.strides3(st[0], st[h_ax], st[n_ax])
+            key = (st[0], st[h_ax], st[n_ax])
+            arr = _STRIDE_CACHE.get(key)
+            if arr is None:
+                if len(_STRIDE_CACHE) > 4096:
+                    _STRIDE_CACHE.clear()
+                arr = _STRIDE_CACHE[key] = _fa2_lib.strides3(*key)
+            return arr
 
         dev = q.device.index
         args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
@@ -153,6 +159,7 @@ class _FlashAttnWmma:
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
 
 
+_STRIDE_CACHE = {}       # (batch, head, row) element strides -> ctypes int64[3] (the arrays are read-only for the library)
 _MAX_HEAD_DIM = 512      # largest forward kernel head dim (fa2_supported_head_dims); the backward kernels stop at 256
 
 
@@ -222,3 +229,18 @@ class FlashAttentionFunction(torch.autograd.Function):
         Bc = 128
         dQ, dK, dV = flash_attn_wmma.backward(q, k, v, o, do, L, N, Nkv, D, Br, Bc, causal, scale, BNHD_fmt)
         return dQ, dK, dV, None, None, None, None
+
+
+# Inference fast path: when nothing can require a gradient the autograd.Function machinery (a Python-side graph node
+# per call, ~5 us) is skipped and forward() runs directly; `FlashAttentionFunction.apply(...)` keeps the reference's
+# call shape and result either way (reference: FlashAttn.py:45-76).
+_autograd_apply = FlashAttentionFunction.apply
+
+
+def _apply(q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, **kwargs):
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _autograd_apply(q, k, v, mask, causal, scale, BNHD_fmt, *args, **kwargs)
+    return FlashAttentionFunction.forward(None, q, k, v, mask, causal, scale, BNHD_fmt)
+
+
+FlashAttentionFunction.apply = staticmethod(_apply)

@@ -154,9 +154,11 @@ def test_full_size_config2_backward_sampled_heads():
         assert torch.isfinite(t.float()).all()
     sl = (slice(1, 2), slice(5, 6))
     _check_vs_oracle(q[sl], k[sl], v[sl], do[sl], o[sl], lse[sl], [t[sl] for t in grads], 0, False)
-    _, _, part = _cabi_fwd_bwd(q[:, 3:5].contiguous(), k[:, 3:5].contiguous(), v[:, 3:5].contiguous(), do[:, 3:5].contiguous(), False)
+    # (8 heads: the forward keeps its 256-row kernel for the slice — it switches shape below 97 workgroups — so O and LSE,
+    #  and with them the gradients, are bit-identical)
+    _, _, part = _cabi_fwd_bwd(q[:, 3:11].contiguous(), k[:, 3:11].contiguous(), v[:, 3:11].contiguous(), do[:, 3:11].contiguous(), False)
     for a, b in zip(part, grads):
-        assert torch.equal(a, b[:, 3:5])
+        assert torch.equal(a, b[:, 3:11])
 
 
 def test_backward_above_256_is_refused_not_wrong():

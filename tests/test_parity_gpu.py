@@ -429,16 +429,20 @@ def test_full_size_config_properties(name):
     for (b, h) in {(0, 0), (B - 1, H - 1), (B // 2, H // 3)}:
         sl = (slice(b, b + 1), slice(h, h + 1))
         _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal)
-    # (a) head slice recomputed alone
-    o_h, lse_h = _cabi_forward(q[:, 3:5].contiguous(), k[:, 3:5].contiguous(), v[:, 3:5].contiguous(), causal)
-    assert torch.equal(o_h, o[:, 3:5]) and torch.equal(lse_h, lse[:, 3:5])
+    # (a) head slice recomputed alone: bit-identical as long as the library picks the same kernel shape for the slice
+    #     (it switches to 128-row workgroups when B*H*ceil(Nq/256) <= 96: 8 heads keep this slice above that)
+    o_h, lse_h = _cabi_forward(q[:, 3:11].contiguous(), k[:, 3:11].contiguous(), v[:, 3:11].contiguous(), causal)
+    assert torch.equal(o_h, o[:, 3:11]) and torch.equal(lse_h, lse[:, 3:11])
+    #     ... and a slice small enough to run on the other workgroup shape agrees to rounding
+    o_s, lse_s = _cabi_forward(q[:, 3:4].contiguous(), k[:, 3:4].contiguous(), v[:, 3:4].contiguous(), causal)
+    assert float((o_s.float() - o[:, 3:4].float()).abs().max()) <= ATOL[dt] and float((lse_s - lse[:, 3:4]).abs().max()) <= 1e-4
     # (b) first rows recomputed alone (top-left causal alignment keeps rows [0, 1024) unchanged)
-    o_r, _ = _cabi_forward(q[:, :2, :1024].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), causal)
+    o_r, _ = _cabi_forward(q[:, :, :1024].contiguous(), k, v, causal)
     if causal:
-        o_r2, _ = _cabi_forward(q[:, :2, :1024].contiguous(), k[:, :2, :1024].contiguous(), v[:, :2, :1024].contiguous(), True)
-        assert torch.equal(o_r2, o[:, :2, :1024])
+        o_r2, _ = _cabi_forward(q[:, :, :1024].contiguous(), k[:, :, :1024].contiguous(), v[:, :, :1024].contiguous(), True)
+        assert torch.equal(o_r2, o[:, :, :1024])
     else:
-        assert torch.equal(o_r, o[:, :2, :1024])
+        assert torch.equal(o_r, o[:, :, :1024])
     # (c) convexity
     vmin = v.float().amin(dim=2, keepdim=True)
     vmax = v.float().amax(dim=2, keepdim=True)

@@ -96,8 +96,10 @@ struct FwdParams {
     int64_t ls[2];                       // lse strides: batch, head
     float c;                             // |scale| * log2(e)
     int negate_q;                        // scale < 0: fold the sign into Q
-    int nqblk;                           // ceil(Nq / kQBlock)
+    int nqblk;                           // ceil(Nq / rows per workgroup)
     uint32_t k_bytes, v_bytes;           // addressable bytes of one head's K / V matrix
+    int bh0, nbh;                        // this launch covers the flattened (batch*H + head) range [bh0, bh0 + nbh)
+    int rows_hint;                       // host only: rows per workgroup the launcher must use (0 = its own heuristic)
 };
 
 template <bool BF16>
@@ -177,7 +179,7 @@ struct Geo {
 //               heads at a time (interleaving all heads of an XCD cycles their K/V through one 4 MiB L2).
 template <bool CAUSAL>
 __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid, int& bh, int& qblk) {
-    const int nbh = p.B * p.H;
+    const int nbh = p.nbh;               // (a launch may cover a sub-range of the heads: host.cpp, tail split)
     if ((nbh & 7) == 0) {
         const int slot = bid >> 3, hpx = nbh >> 3;   // hpx = heads per XCD
         if (CAUSAL) {
@@ -196,6 +198,7 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
         bh = bid / p.nqblk;
         qblk = bid % p.nqblk;
     }
+    bh += p.bh0;
 }
 
 // NW waves per workgroup, each owning QB consecutive 32-row Q blocks (NW * QB * 32 == 256):

@@ -68,7 +68,25 @@ int forced_rows() {
 int pick_rows(const fa2::FwdParams& p) {
     const int f = forced_rows();
     if (f == 128 || f == 256) return f;
-    return (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= 96 ? 128 : 256;
+    if (p.rows_hint == 128 || p.rows_hint == 256) return p.rows_hint;
+    return (int64_t)p.nbh * ((p.Nq + 255) / 256) <= 96 ? 128 : 256;
+}
+
+// Tail split (non-causal): B*H*ceil(Nq/256) equal workgroups on 256 CUs take ceil(x/256) rounds however empty the last one
+// is — SDXL's 64x64 self-attention (B2 H10 N4096) is 320 workgroups, two rounds for 1.25 rounds of work.  When the last
+// round would be at most half full, the heads that make it up run in a second launch as 128-row workgroups (twice as
+// many, ~0.85x as long each: they stream the same K/V for half the rows).  Measured at D = 64 (tools/rows_probe.py): B2 H10
+// N4096 130.8 -> 123.9 us, B1 H24 N3072 97.0 -> 92.5 us; one SDXL UNet step's attention 3.11 -> 3.02 ms.  Returns the number of
+// heads of the main launch (= nbh: no split).  FA2_TAIL_SPLIT=0 in the environment disables it.
+int tail_split_heads(const fa2::FwdParams& p, bool causal) {
+    static const bool on = [] { const char* e = std::getenv("FA2_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on || causal || forced_rows() != 0) return p.nbh;
+    const int64_t cus = 256, nq = (p.Nq + 255) / 256, w = (int64_t)p.nbh * nq;
+    if (w <= cus || nq > cus) return p.nbh;
+    const int64_t main_heads = (w / cus) * cus / nq;           // whole heads that fit the full rounds
+    const int64_t tail_w = (p.nbh - main_heads) * nq;           // 256-row workgroups of the remaining heads
+    if (main_heads <= 0 || tail_w <= 0 || tail_w > cus / 2) return p.nbh;
+    return (int)main_heads;
 }
 
 template <int HD, bool BF16, bool CAUSAL, int NW, int QB>
@@ -80,8 +98,8 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + NW * QB * 32 - 1) / (NW * QB * 32);
-    if ((int64_t)p.B * p.H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
-    const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nqblk), HD / HDV);
+    if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
+    const dim3 grid((unsigned)((int64_t)p.nbh * p.nqblk), HD / HDV);
     constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, NW, QB>;
     if (int rc = set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
@@ -131,7 +149,7 @@ int launch_d128_t(const fa2::FwdParams& p, hipStream_t stream) {
     static_assert(kFwdRows == 256, "the d128 kernel covers 256 Q rows per workgroup, like the default shape");
     constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL, FOLD>;
     if (int rc = set_lds<kern>(fa2::kD128LdsBytes)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nqblk)), dim3(256), fa2::kD128LdsBytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(256), fa2::kD128LdsBytes, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -141,7 +159,27 @@ int launch_d128(const fa2::FwdParams& p, hipStream_t stream) {
 }
 
 template <int HD, bool BF16>
-int launch(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+int launch_range(const fa2::FwdParams& p, bool causal, hipStream_t stream);
+
+template <int HD, bool BF16>
+int launch(const fa2::FwdParams& p0, bool causal, hipStream_t stream) {
+    if constexpr (HD <= 64) {     // (measured at D = 128, B1 H24 N4096: 188 -> 194 us — the 128-row shape is too slow there; D = 64: see below)
+        const int main_heads = tail_split_heads(p0, causal);
+        if (main_heads < p0.nbh) {
+            fa2::FwdParams p = p0;
+            p.nbh = main_heads;
+            if (int rc = launch_range<HD, BF16>(p, causal, stream)) return rc;
+            p.bh0 = p0.bh0 + main_heads;
+            p.nbh = p0.nbh - main_heads;
+            p.rows_hint = 128;
+            return launch_range<HD, BF16>(p, causal, stream);
+        }
+    }
+    return launch_range<HD, BF16>(p0, causal, stream);
+}
+
+template <int HD, bool BF16>
+int launch_range(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     if constexpr (HD == 128) {
         if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f) && pick_rows(p) == 256)
             return causal ? launch_d128<BF16, true>(p, stream) : launch_d128<BF16, false>(p, stream);
@@ -282,6 +320,9 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     if (p.c < 1e-30f) p.c = 1e-30f;
     p.negate_q = scale < 0.f;
     p.nqblk = (Nq + kFwdRows - 1) / kFwdRows;
+    p.bh0 = 0;
+    p.nbh = B * H;
+    p.rows_hint = 0;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;

@@ -531,3 +531,21 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
         assert rec["scaling"] == ("strong" if workload == "c5" else "weak")
         assert rec["config"]["global_batch"] == (64 if workload == "c5" else 4)
         assert "roofline" in rec and rec["check"]["max_abs_err_vs_dense_fp32"] <= rec["check"]["tol"]
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 4096, 64), (1, 24, 4096, 128), (3, 7, 2816, 128), (1, 20, 3500, 80)])
+def test_tail_split_launches_cover_every_head(shape):
+    """Grids whose last round of 256-row workgroups would be at most half full are issued as two launches (whole heads: the
+    full rounds as they are, the remaining heads as 128-row workgroups — host.cpp tail_split_heads).  Every head must come
+    out right, in particular the ones of the second launch."""
+    B, H, N, D = shape
+    g = torch.Generator(device="cpu").manual_seed(41 + H)
+    q, k, v = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(3))
+    o, lse = _cabi_forward(q, k, v, False)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    for (b, h) in {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2)}:
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False)
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (D ** -0.5)
+    truth = torch.matmul(torch.softmax(s, -1), v.float())
+    assert float((o.float() - truth).abs().max()) <= FLOOR[0] * 2

@@ -384,7 +384,7 @@ class Gen:
                 slots[g].append((g + (j + 0.5) / n, sid, it))
 
     # ------------------------------------------------------------------ one body
-    def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False):
+    def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True):
         """B(t) with t & 1 == par.  pv: PV(t); s1: softmax of tile t+1 (M0, M1, E0, E1) and the V(t+1) reads; s2: K(t+2)
         reads and QK(t+2).  masked: tile t+1 is this wave's last one (causal diagonal / ragged tail masks); first: tile
         t+1 is tile 0.  Appends to self.p."""
@@ -427,9 +427,9 @@ class Gen:
             if "max" not in abl:
                 self.place(load, slots, self.stream_max(0, par ^ 1, masked, first), mw[0], mw[1], 0)
                 self.place(load, slots, self.stream_max(1, par ^ 1, masked, first), mw[0], mw[1], 1)
-        if "dma" not in abl:
-            dma = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
-            self.place(load, slots, dma, cfg["dma"][0], cfg["dma"][1], 2)
+        if dma and "dma" not in abl:
+            grp = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
+            self.place(load, slots, grp, cfg["dma"][0], cfg["dma"][1], 2)
         if s2 and "kread" not in abl:
             self.place(load, slots, self.stream_kread(par), cfg["kread"][0], cfg["kread"][1], 3)
         if s1 and "vread" not in abl:
@@ -587,9 +587,23 @@ class Gen:
         p.emit("s_nop", 0)
         for i in range(4):
             p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
-        # B(-2) stages K(1) (= t + 3) and V(0) (= t + 2): the running offsets are those of tile t+3 / t+2
+        # ... and what body B(-2) would stage, V(0) and K(1), right behind it: all three tiles' latencies overlap (B(-2) then
+        # stages nothing).  The running offsets are those of tile t+3 / t+2 of the body that uses them.
         p.emit("s_mov_b32", S_KOFF, A_KTILE)
         p.emit("s_mov_b32", S_VOFF, 0)
+        early = "lateprefetch" not in self.opt       # (A/B switch: B(-2) stages V(0), K(1) itself, as the first version did)
+        if early:
+            p.emit("s_add_u32", M0, A_LDSW, V_BASE)
+            p.emit("s_nop", 0)
+            for i in range(4):
+                p.emit("buffer_load_dwordx4", VD[i], A_VRS, S_VOFF, offen=True, offset=1024 * i, lds=True)
+            p.emit("s_cmp_lt_i32", A_NTWG, 2)
+            p.emit("s_cbranch_scc1", Label("no_k1"))
+            p.emit("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B)
+            p.emit("s_nop", 0)
+            for i in range(4):
+                p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
+            p.label("no_k1")
         for qb in range(2):
             p.emit("v_mov_b32", MC[qb], 0.0 if self.pre else NEG_INF)
             p.emit("v_mov_b32", LA[qb], 0)
@@ -608,7 +622,7 @@ class Gen:
                 p.emit("v_cndmask_b32", KX[i], 0, TMP[1], VCC)
                 p.emit("v_mov_b32", QX[0][i], 0)
                 p.emit("v_mov_b32", QX[1][i], 0)
-            p.emit("s_waitcnt", vmcnt=4)                        # the 16 Q loads (the 4 K(0) pieces may still fly)
+            p.emit("s_waitcnt", vmcnt=0)                        # the 16 Q loads (and the staged tiles behind them)
             for i in range(64):
                 src, t0, t1 = V(VBASE + i), TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]
                 if self.bf16:
@@ -624,11 +638,22 @@ class Gen:
                 p.emit(self.cvt, t0, t0, t1)
                 p.emit("s_nop", 0)
                 p.emit("v_accvgpr_write_b32", A(128 + i), t0)
-        p.emit("s_waitcnt", vmcnt=0)
+            p.emit("s_waitcnt", vmcnt=0)
+        elif not early:
+            p.emit("s_waitcnt", vmcnt=0)
+        else:
+            # Q and K(0) are needed now; V(0) and K(1) (8 or 4 pieces issued behind them) may keep flying until the end of B(-2)
+            p.emit("s_cmp_lt_i32", A_NTWG, 2)
+            p.emit("s_cbranch_scc1", Label("wait4"))
+            p.emit("s_waitcnt", vmcnt=8)
+            p.emit("s_branch", Label("waited"))
+            p.label("wait4")
+            p.emit("s_waitcnt", vmcnt=4)
+            p.label("waited")
         p.emit("s_barrier")
 
         # ---- head bodies: t = -2 (parity 0): QK(0) only; t = -1 (parity 1): softmax of tile 0, QK(1) if there is a tile 1
-        self.body(0, pv=False, s1=False, s2=True, name="H1")
+        self.body(0, pv=False, s1=False, s2=True, name="H1", dma="lateprefetch" in self.opt)
         p.emit("s_cmp_eq_u32", A_NTW, 1)
         p.emit("s_cbranch_scc1", Label("h2b"))
         self.body(1, pv=False, s1=True, s2=True, name="H2", first=True)

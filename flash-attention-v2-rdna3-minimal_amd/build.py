@@ -23,6 +23,8 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 STAMP_PATH = LIB_PATH + ".stamp"
 
 SOURCES = ["host.cpp"]
+FRONTEND_SRC = "frontend.cpp"                      # optional compiled front end of the operator (host-only C++, g++)
+FRONTEND_PATH = os.path.join(PKG_DIR, "rocwmma_fattn", "_fa2_frontend.so")
 HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
            os.path.join("gen", "isa.py"), os.path.join("gen", "fwd_d128_gen.py")]
 GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_f16_fold.inc", "fa2_fwd_d128_bf16_fold.inc",
@@ -49,7 +51,7 @@ def _hipcc():
 def _source_digest():
     h = hashlib.sha256()
     h.update(" ".join(HIPCC_FLAGS).encode())
-    for name in SOURCES + HEADERS:
+    for name in SOURCES + HEADERS + [FRONTEND_SRC]:
         path = name if os.path.isabs(name) else os.path.join(CSRC, name)
         with open(path, "rb") as f:
             h.update(f.read())
@@ -61,6 +63,38 @@ def generate():
     res = subprocess.run([sys.executable, os.path.join(CSRC, "gen", "fwd_d128_gen.py")], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("fwd_d128_gen.py failed:\n%s\n%s" % (res.stdout, res.stderr))
+
+
+def build_frontend(verbose=False):
+    """rocwmma_fattn/_fa2_frontend.so: the forward of the reference's pybind module in C++ over the C-ABI (csrc/frontend.cpp).
+    Optional — the Python implementation in FlashAttn.py is used when it is absent — so a failure here is reported, not raised."""
+    try:
+        import sysconfig
+        import torch
+        from torch.utils import cpp_extension as ce
+        gxx = shutil.which("g++") or shutil.which("c++")
+        if not gxx:
+            raise RuntimeError("no g++")
+        tlib = ce.library_paths()[0]
+        cmd = [gxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_fa2_frontend",
+               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+        for inc in ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include", INCLUDE]:
+            cmd += ["-I", inc]
+        tmp = FRONTEND_PATH + ".tmp.%d" % os.getpid()
+        cmd += [os.path.join(CSRC, FRONTEND_SRC), "-o", tmp, "-L", tlib, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
+                "-ltorch_python", "-L", PKG_DIR, "-lfa2_gfx950", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + tlib]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError(res.stderr[-2000:])
+        os.replace(tmp, FRONTEND_PATH)
+        return FRONTEND_PATH
+    except Exception as e:   # noqa: BLE001 - optional component
+        if os.path.exists(FRONTEND_PATH):
+            os.remove(FRONTEND_PATH)
+        print("fa2 build: compiled front end not built (%s); the Python front end will be used" % str(e)[:500], file=sys.stderr)
+        return None
 
 
 def is_current():
@@ -89,6 +123,7 @@ def build(force=False, verbose=False):
             os.remove(tmp)
         raise RuntimeError("hipcc failed (%d):\n%s\n%s" % (res.returncode, res.stdout or "", res.stderr or ""))
     os.replace(tmp, LIB_PATH)
+    build_frontend(verbose)
     with open(STAMP_PATH, "w") as f:
         f.write(digest + "\n")
     return LIB_PATH

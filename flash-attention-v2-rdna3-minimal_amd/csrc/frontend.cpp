@@ -1,0 +1,98 @@
+// frontend.cpp — the reference's pybind module `flash_attn_wmma` (rocwmma_fattn/host.cpp:60-64:
+// forward(q, k, v, Br, Bc, causal, scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]) as a compiled front end
+// over the C-ABI of libfa2_gfx950.so.  It does exactly what rocwmma_fattn/FlashAttn.py::_FlashAttnWmma.forward does in
+// Python (dtype switch of host.cpp:30-45, D padded to a multiple of 8 only, O/L allocated on q's device with the
+// reference's N-padded shapes, launch on torch's current stream) — about 6 us of host time per call instead of 11, which
+// only matters for back-to-back tiny calls (an SDXL cross-attention layer).  Optional: when this module is not built the
+// Python implementation is used; results are identical (tests/test_parity_gpu.py::test_compiled_front_end_matches_python).
+//
+// Host-only C++ (g++): no device code here, the kernels live in libfa2_gfx950.so.
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm presents its devices as "cuda": the masquerading guard / stream
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include "fa2_gfx950.h"
+
+namespace {
+
+bool strides_ok(const at::Tensor& t) {
+    const auto s = t.strides();
+    return s[3] == 1 && ((s[0] | s[1] | s[2]) & 7) == 0 && (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15u) == 0;
+}
+
+at::Tensor kernel_ready(const at::Tensor& t) { return strides_ok(t) ? t : t.contiguous(); }
+
+std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_t Br, int64_t Bc, bool causal, double scale,
+                                bool permute_NH) {
+    (void)Bc;
+    TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)");
+    TORCH_CHECK(q.is_cuda() && k.is_cuda() && v.is_cuda(), "fa2: q, k, v must be on a ROCm device (no CPU path in this operator)");
+    TORCH_CHECK(k.device() == q.device() && v.device() == q.device(), "fa2: q, k, v must be on the same device");
+    int dtype_code;
+    if (q.scalar_type() == at::kHalf) {
+        TORCH_CHECK(k.scalar_type() == at::kHalf && v.scalar_type() == at::kHalf, "fa2: q, k, v must share one dtype");
+        dtype_code = FA2_DTYPE_F16;
+    } else {
+        dtype_code = FA2_DTYPE_BF16;     // host.cpp:42-45: everything else runs (and returns) as bf16
+        if (q.scalar_type() != at::kBFloat16 || k.scalar_type() != at::kBFloat16 || v.scalar_type() != at::kBFloat16) {
+            q = q.to(at::kBFloat16);
+            k = k.to(at::kBFloat16);
+            v = v.to(at::kBFloat16);
+        }
+    }
+    const int n_ax = permute_NH ? 1 : 2, h_ax = permute_NH ? 2 : 1;
+    const int64_t b = q.size(0), h = q.size(h_ax), n = q.size(n_ax), d = q.size(3), n_kv = k.size(n_ax);
+    TORCH_CHECK(k.size(0) == b && k.size(h_ax) == h && k.size(3) == d && v.sizes() == k.sizes(), "fa2: inconsistent q/k/v shapes");
+    TORCH_CHECK(fa2_padded_head_dim((int)(d + ((8 - d % 8) % 8))) > 0, "fa2: head dim ", d, " is larger than the largest gfx950 kernel");
+    const int64_t d_pad = (8 - d % 8) % 8, d_kernel = d + d_pad;
+    at::Tensor qp = q, kp = k, vp = v;
+    if (d_pad) {
+        qp = at::constant_pad_nd(q, {0, d_pad});
+        kp = at::constant_pad_nd(k, {0, d_pad});
+        vp = at::constant_pad_nd(v, {0, d_pad});
+    }
+    qp = kernel_ready(qp);
+    kp = kernel_ready(kp);
+    vp = kernel_ready(vp);
+
+    const int64_t nq_pad = (Br - n % Br) % Br;
+    at::Tensor O, L;
+    const auto f32 = q.options().dtype(at::kFloat);
+    if (nq_pad) {
+        std::vector<int64_t> oshape = permute_NH ? std::vector<int64_t>{b, n + nq_pad, h, d_kernel} : std::vector<int64_t>{b, h, n + nq_pad, d_kernel};
+        O = at::empty(oshape, qp.options());
+        O.narrow(n_ax, n, nq_pad).zero_();
+        L = at::empty({b, h, n + nq_pad}, f32);
+        L.narrow(2, n, nq_pad).zero_();
+    } else {
+        O = at::empty_like(qp);
+        if (!strides_ok(O)) O = at::empty(qp.sizes(), qp.options());
+        L = at::empty({b, h, n}, f32);
+    }
+    auto s3 = [&](const at::Tensor& t, int64_t* out) {
+        out[0] = t.stride(0);
+        out[1] = t.stride(h_ax);
+        out[2] = t.stride(n_ax);
+    };
+    int64_t qs[3], ks[3], vs[3], os[3], ls[2] = {h * (n + nq_pad), n + nq_pad};
+    s3(qp, qs);
+    s3(kp, ks);
+    s3(vp, vs);
+    s3(O, os);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
+    const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream();
+    const int rc = fa2_fwd(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
+                           (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, causal ? 1 : 0, (void*)stream);
+    TORCH_CHECK(rc == 0, "fa2 call failed (", rc, "): ", fa2_error_string(rc));
+    at::Tensor O_fwd = O;
+    if (nq_pad) O_fwd = O_fwd.narrow(n_ax, 0, n);
+    if (d_pad) O_fwd = O_fwd.narrow(3, 0, d);
+    return {O_fwd, qp, kp, vp, O, L};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "compiled front end of the gfx950 FlashAttention-2 operator (forward of the reference's flash_attn_wmma module)";
+    m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal, scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
+}

@@ -16,6 +16,8 @@ Layers (reference counterpart in brackets):
 The host is PyTorch-ROCm for memory and streams only; the compute is the C-ABI library
 (include/fa2_gfx950.h).  There is no CPU path: tensors must live on a ROCm device.
 """
+import os
+
 import torch
 
 from . import _fa2_lib
@@ -29,6 +31,15 @@ class _FlashAttnWmma:
 
     @staticmethod
     def forward(q, k, v, Br, Bc, causal, scale, permute_NH):
+        """forward() of the reference's module: the compiled front end (csrc/frontend.cpp, same logic in C++: ~6 us of host
+        time per call instead of ~11) when it was built, else forward_py below."""
+        fe = _frontend()
+        if fe is not None:
+            return fe.forward(q, k, v, int(Br), int(Bc), bool(causal), float(scale), bool(permute_NH))
+        return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, causal, scale, permute_NH)
+
+    @staticmethod
+    def forward_py(q, k, v, Br, Bc, causal, scale, permute_NH):
         """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16 (kernel_fp16.cu:744-876).
         O and L keep the reference's shapes — rows padded to a multiple of Br with a zero tail, O_fwd a view into
         O (kernel_fp16.cu:761, :793-796, :865-875) — but nothing is COPIED to get there: the gfx950 kernels mask
@@ -157,6 +168,23 @@ class _FlashAttnWmma:
         if permute_NH:
             return [dQ[:, :act_n, :, :act_d], dK[:, :act_nkv, :, :act_d], dV[:, :act_nkv, :, :act_d]]
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
+
+
+_FRONTEND = [False]      # False = not looked for yet, None = absent
+
+
+def _frontend():
+    """The optional compiled front end (rocwmma_fattn/_fa2_frontend.so, built by build.py); FA2_FRONTEND=py disables it."""
+    if _FRONTEND[0] is False:
+        mod = None
+        if os.environ.get("FA2_FRONTEND", "") != "py":
+            _fa2_lib.load()                       # the kernel library first: the front end links against it
+            try:
+                from . import _fa2_frontend as mod  # noqa: F401
+            except ImportError:
+                mod = None
+        _FRONTEND[0] = mod
+    return _FRONTEND[0]
 
 
 _STRIDE_CACHE = {}       # (batch, head, row) element strides -> ctypes int64[3] (the arrays are read-only for the library)

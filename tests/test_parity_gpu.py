@@ -581,3 +581,32 @@ def test_bnhd_d128_zero_copy():
         o_ref_bits, _ = fo.fwd_c(_bits(q[:1, :2]), _bits(k[:1, :2]), _bits(v[:1, :2]), 0, causal)
         o_ref = fo.bits_to_f32(o_ref_bits, 0)
         assert np.all(np.abs(o_bhnd[:1, :2].float().cpu().numpy() - o_ref) <= ATOL[0] + RTOL[0] * np.abs(o_ref))
+
+
+def test_compiled_front_end_matches_python():
+    """csrc/frontend.cpp is the Python forward of the reference's module transcribed to C++: same six tensors, bit for bit,
+    for aligned, N-padded, D-padded (D = 37), BNHD, causal and non-half inputs."""
+    from rocwmma_fattn.FlashAttn import _frontend
+    fe = _frontend()
+    if fe is None:
+        pytest.skip("compiled front end not built")
+    g = torch.Generator(device="cpu").manual_seed(23)
+    cases = [((2, 3, 100, 40), (2, 3, 77, 40), torch.float16, False, False), ((1, 2, 256, 128), (1, 2, 256, 128), torch.bfloat16, True, False),
+             ((2, 3, 100, 37), (2, 3, 77, 37), torch.float16, True, False), ((2, 130, 4, 64), (2, 90, 4, 64), torch.float16, False, True),
+             ((1, 2, 64, 64), (1, 2, 64, 64), torch.float32, False, False), ((1, 1, 70, 320), (1, 1, 50, 320), torch.float16, False, False)]
+    for qs, ks, dt, causal, bnhd in cases:
+        q = torch.randn(qs, generator=g).to(dt).to(_dev())
+        k = torch.randn(ks, generator=g).to(dt).to(_dev())
+        v = torch.randn(ks, generator=g).to(dt).to(_dev())
+        d = qs[3]
+        br = 32 if d > 384 else 64
+        a = fe.forward(q, k, v, br, 128, causal, d ** -0.5, bnhd)
+        b = flash_attn_wmma.forward_py(q, k, v, br, 128, causal, d ** -0.5, bnhd)
+        torch.cuda.synchronize()
+        assert len(a) == len(b) == 6
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and x.dtype == y.dtype and x.device == y.device and x.stride() == y.stride()
+            assert torch.equal(x, y)
+        assert a[0].data_ptr() == a[4].data_ptr()
+    with pytest.raises(RuntimeError):
+        fe.forward(q.cpu(), k.cpu(), v.cpu(), 64, 128, False, 0.1, False)

@@ -24,7 +24,7 @@ Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs (68 in the folded
   weighted issue load of every gap is the same:
     M0, M1  row max + rescale decision of tile t+1, q block 0 / 1     (gaps 2..9; tail bodies: masks first, gaps 2..23)
     E0, E1  exp / two row-sum chains / in-place pair packing of tile t+1   (gaps 10..63)
-    K(t+2) fragment reads (gaps 0..31), V(t+1) transpose reads (gaps 33..58), the 8 LDS-DMA pieces of K(t+3), V(t+2) (gaps 3..22)
+    K(t+2) fragment reads (gaps 0..15), V(t+1) transpose reads (gaps 33..39), the 8 LDS-DMA pieces of K(t+3), V(t+2) (gaps 10..27)
   One s_waitcnt + s_barrier per body.  The O rescale of the deferred-max scheme is a rare out-of-line block entered between
   the two MFMA phases (all of PV(t) is in O, nothing of tile t+1 yet), so every value at the old reference is scaled once.
 Head / tail bodies are the same generator with streams switched off (and the tail masks switched on).
@@ -125,7 +125,9 @@ def _weight(item):
 class Gen:
     # Tunables of the schedule (gap windows [a, b) of the filler streams of a body), code-generation options, and
     # timing-only ablations ("abl": stream names left out of the FAST bodies — wrong results, tools/kbench.py prices the parts)
-    DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 58.0), "kread": (0.0, 31.0), "dma": (3.0, 22.0),
+    # (windows: measured sweep in profiles/r02_window_sweep.txt — fragment reads early in their phase shorten the waits at the
+    #  phase boundary and at the end of the body: 2664 -> 2580 cycles per body)
+    DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 40.0), "kread": (0.0, 16.0), "dma": (10.0, 28.0),
                 "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0)}
 
     def __init__(self, bf16=False, **cfg):

@@ -489,7 +489,7 @@ class Gen:
                 p.emit("s_cbranch_scc1", Label(lab))
                 p.label(lab + "_ret")
                 self.rare.append(self.rare_rescale(lab))
-                if s2:
+                if s2 and "wait32" not in abl:
                     p.emit("s_waitcnt", lgkmcnt=0)
                 if trace:
                     p.emit("s_memtime", S_TB)
@@ -501,7 +501,8 @@ class Gen:
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)
         p.emit("s_add_u32", S_VOFF, S_VOFF, A_VTILE)
-        p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        if "waitend" not in abl:
+            p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
         if trace:
             p.emit("s_memtime", S_TC)
         if "barrier" not in abl:

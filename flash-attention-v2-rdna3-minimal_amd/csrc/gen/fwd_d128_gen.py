@@ -128,7 +128,9 @@ class Gen:
     # (windows: measured sweep in profiles/r02_window_sweep.txt — fragment reads early in their phase shorten the waits at the
     #  phase boundary and at the end of the body: 2664 -> 2580 cycles per body)
     DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 40.0), "kread": (0.0, 16.0), "dma": (10.0, 28.0),
-                "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0)}
+                "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0),
+                "shift": (0.0, 0.0),
+                "dmaw": (0.0, 0.0)}      # (width, step) > 0: one copy of the fast loop per wave, wave w stages in gaps [dma0 + w*step, +width)     # code-placement probe: (n s_nop before the fast loop, log2 alignment of its first instruction)
 
     def __init__(self, bf16=False, **cfg):
         self.cfg = dict(self.DEFAULTS)
@@ -672,15 +674,35 @@ class Gen:
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc0", Label("dispatch"))
         p.emit("s_nop", 0)
-        p.label("fast0")
-        self.body(0, guarded=False, name="F0")
-        p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
-        p.emit("s_cmp_gt_i32", S_NFAST, 0)
-        p.emit("s_cbranch_scc0", Label("dispatch"))
-        self.body(1, guarded=False, name="F1")
-        p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
-        p.emit("s_cmp_gt_i32", S_NFAST, 0)
-        p.emit("s_cbranch_scc1", Label("fast0"))
+        for _ in range(int(self.cfg["shift"][0])):
+            p.emit("s_nop", 0)
+        if self.cfg["shift"][1] > 0:
+            p.ins.append(Ins("raw", (".p2align %d" % int(self.cfg["shift"][1]),)))
+        per_wave = self.cfg["dmaw"][0] > 0
+        base_dma = self.cfg["dma"]
+        if per_wave:
+            # the four waves run the same stream in lock step, so their LDS-DMA pieces reach the one address/texture path of
+            # the CU together; a private copy of the fast loop per wave lets each wave stage in its own gap window
+            for w in range(1, 4):
+                p.emit("s_cmp_eq_u32", S_WAVE, w)
+                p.emit("s_cbranch_scc1", Label("fast0_w%d" % w))
+        for w in range(4 if per_wave else 1):
+            sfx = "_w%d" % w if w else ""
+            if per_wave:
+                a0 = base_dma[0] + w * self.cfg["dmaw"][1]
+                self.cfg["dma"] = (a0, a0 + self.cfg["dmaw"][0])
+            p.label("fast0" + sfx)
+            self.body(0, guarded=False, name="F0")
+            p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
+            p.emit("s_cmp_gt_i32", S_NFAST, 0)
+            p.emit("s_cbranch_scc0", Label("dispatch"))
+            self.body(1, guarded=False, name="F1")
+            p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
+            p.emit("s_cmp_gt_i32", S_NFAST, 0)
+            p.emit("s_cbranch_scc1", Label("fast0" + sfx))
+            if per_wave and w < 3:
+                p.emit("s_branch", Label("dispatch"))
+        self.cfg["dma"] = base_dma
 
         p.label("dispatch")
         p.emit("s_cmp_ge_i32", S_T, A_NTWG)

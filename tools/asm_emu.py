@@ -280,7 +280,7 @@ class Machine:
         ins = self.ins[w.pc]
         op = ins.op
         nxt = w.pc + 1
-        if op == "label":
+        if op == "label" or op == "raw":       # raw = assembler directive (alignment)
             w.pc = nxt
             return
         w.n_issued += 1

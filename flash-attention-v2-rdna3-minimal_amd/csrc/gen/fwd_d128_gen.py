@@ -116,6 +116,19 @@ def KF(kvb, ks):
     return A(192 + 32 * kvb + 4 * ks, 4)
 
 
+def KF_POOL(kvb, ks):                              # "ct" kernels: a 32-register pool, k-step ks lives in slot ks % 4
+    return A(192 + 8 * (ks % 4) + 4 * kvb, 4)
+
+
+# "ct" kernels: the C operand of the first QK^T k-step = -(reference max), per q block.  An MFMA takes C and D from the same
+# register file, so the tuples live in arch VGPRs — v[176:207], which the V^T fragments of k-steps 2, 3 vacate for a[224:255]
+CT = [V(176, 16), V(192, 16)]
+
+
+def VF_CT(dt, ks):
+    return V(144 + 16 * ks + 4 * dt, 4) if ks < 2 else A(224 + 16 * (ks - 2) + 4 * dt, 4)
+
+
 def _weight(item):
     if isinstance(item, list):
         return sum(_weight(i) for i in item)
@@ -129,6 +142,8 @@ class Gen:
     #  phase boundary and at the end of the body: 2664 -> 2580 cycles per body)
     DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 40.0), "kread": (0.0, 16.0), "dma": (10.0, 28.0),
                 "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0),
+                "kread_ct": (16.0, 32.0),   # "ct" kernels: gap window of the K reads of k-steps 0..3 (4..7 follow their pool slots)
+                "vsplit": (0.0, 0.0),       # timing probe (wrong results): 16 of the 32 V^T reads go into this PV-phase window
                 "shift": (0.0, 0.0),
                 "dmaw": (0.0, 0.0)}      # (width, step) > 0: one copy of the fast loop per wave, wave w stages in gaps [dma0 + w*step, +width)     # code-placement probe: (n s_nop before the fast loop, log2 alignment of its first instruction)
 
@@ -137,6 +152,11 @@ class Gen:
         self.cfg.update(cfg)
         self.opt = set(self.cfg["opt"])
         self.pre = "pre" in self.opt      # folded scale: Q is multiplied by c and rounded once, -m rides in an extra k-step
+        self.ct = "ct" in self.opt        # folded scale, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
+        assert not (self.pre and self.ct)
+        self.fold = self.pre or self.ct   # what the two share: prescaled Q, S leaves the MFMA as (score - reference)
+        self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else KF      # ctk64: timing probe (K and V^T fragments collide)
+        self.vf = VF_CT if self.ct else VF
         self.nqk = 36 if self.pre else 32
         self.ng = 32 + self.nqk           # MFMAs (= gaps) per body
         self.bf16 = bf16
@@ -152,7 +172,7 @@ class Gen:
         for ks in range(4):
             pfrag = SB(qb, par).sub(16 * (ks >> 1) + 8 * (ks & 1), 4)
             for dt in range(4):
-                out.append(mk(self.mfma, OACC(qb, dt), VF(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
+                out.append(mk(self.mfma, OACC(qb, dt), self.vf(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
         return out
 
     def qk_mfmas(self, par):
@@ -166,7 +186,8 @@ class Gen:
             for qb in range(2):
                 for kvb in range(2):
                     dst = SB(qb, par).sub(16 * kvb, 16)
-                    out.append(mk(self.mfma, dst, KF(kvb, ks), QF(qb, ks), 0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
+                    c0 = CT[qb] if (self.ct and "ctc0" not in self.opt) else 0        # ctc0: timing probe (no reference in S)
+                    out.append(mk(self.mfma, dst, self.kf(kvb, ks), QF(qb, ks), c0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
@@ -176,7 +197,7 @@ class Gen:
         b = SB(qb, par)
         out = []
         for k in range(16 + 3):
-            if k < 16 and "nofma" not in self.opt and not self.pre:   # stage 0: x = s*c - m*c
+            if k < 16 and "nofma" not in self.opt and not self.fold:   # stage 0: x = s*c - m*c
                 e = 2 * k
                 out.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
                 out.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
@@ -238,7 +259,7 @@ class Gen:
         out.append(mk("v_max_f32", mxa, mxa, t, tag="valu"))
         lab = self.p.fresh("rare_m")
         # (a list inside a stream is an atomic group: the scheduler keeps it contiguous — here a branch and its return label)
-        if self.pre:
+        if self.fold:
             # S already is (score - reference) in log2 units: its row max IS the growth.  Tile 0 adopts its own maximum
             # whatever the sign (the reference starts at 0, not at -inf: it travels through the MFMA as 16-bit terms).
             if first:
@@ -246,7 +267,7 @@ class Gen:
             else:
                 out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_lt_f32", VCC, THR, mxa, tag="valu"),
                             mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
-            self.rare.append(self.rare_m_pre(lab, qb, b, mxa, mxb, t, t2, first))
+            self.rare.append((self.rare_m_ct if self.ct else self.rare_m_pre)(lab, qb, b, mxa, mxb, t, t2, first))
             return out
         out.append(mk("v_fma_f32", t2, mxa, A_C, Neg(MC[qb]), tag="valu"))
         out.append([mk("v_cmp_lt_f32", VCC, THR, t2, tag="valu"), mk("s_cbranch_vccnz", Label(lab), tag="branch"),
@@ -311,11 +332,40 @@ class Gen:
         r.append(mk("s_branch", Label(lab + "_ret")))
         return r
 
+    def rare_m_ct(self, lab, qb, b, mxa, mxb, t, t2, first):
+        """"ct" kernels, out of line: the reference of q block qb moves by d = max(row max, 0) (tile 0: = row max).  The C tuple
+        of the next QK^T is rewritten with the new -reference, the scores of THIS tile — formed against the old reference — are
+        shifted by the difference actually applied, the row sums are scaled now and the O rescale is left pending."""
+        r = [Ins("label", (Label(lab),))]
+        if not first:
+            r.append(mk("v_max_f32", mxa, 0, mxa))                      # rows that did not grow keep their reference
+            r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", mxb, MC[qb], mxa))                     # new reference
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_sub_f32", t, mxb, MC[qb]))                       # the shift as applied
+        r.append(mk("v_sub_f32", mxa, 0, mxb))                          # -reference for the C tuple
+        r.append(mk("v_mov_b32", MC[qb], mxb))
+        r.append(mk("s_nop", 0))
+        for e in range(32):
+            r.append(mk("v_sub_f32", b[e], b[e], t))                    # this tile's scores, now against the new reference
+        for i in range(16):
+            r.append(mk("v_mov_b32", CT[qb][i], mxa))
+        r.append(mk("v_exp_f32", t2, Neg(t)))                           # factor for everything accumulated at the old one
+        if not first:
+            r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
+        r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
+        r.append(mk("v_mov_b32", FSC[qb], t2))
+        r.append(mk("s_nop", 1))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
+
     def stream_kread(self, par):
         out = []
         for ks in range(8):
             for kvb in range(2):
-                out.append(mk("ds_read_b128", KF(kvb, ks), KR[ks], tag="lds", offset=K_SLOT + par * SLOT_B + kvb * 8192))
+                out.append(mk("ds_read_b128", self.kf(kvb, ks), KR[ks], tag="lds", offset=K_SLOT + par * SLOT_B + kvb * 8192))
         return out
 
     def stream_vread(self, par):
@@ -323,8 +373,8 @@ class Gen:
         for ks in range(4):
             for dt in range(4):
                 off = V_BASE + par * SLOT_B + 16 * ks * 256
-                out.append(mk("ds_read_b64_tr_b16", VF(dt, ks).sub(0, 2), VR[dt], tag="lds", offset=off))
-                out.append(mk("ds_read_b64_tr_b16", VF(dt, ks).sub(2, 2), VR[dt], tag="lds", offset=off + 8 * 256))
+                out.append(mk("ds_read_b64_tr_b16", self.vf(dt, ks).sub(0, 2), VR[dt], tag="lds", offset=off))
+                out.append(mk("ds_read_b64_tr_b16", self.vf(dt, ks).sub(2, 2), VR[dt], tag="lds", offset=off + 8 * 256))
         return out
 
     def dma_group(self, which, slot_par, guarded, ahead):
@@ -434,9 +484,24 @@ class Gen:
         if dma and "dma" not in abl:
             grp = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
             self.place(load, slots, grp, cfg["dma"][0], cfg["dma"][1], 2)
-        if s2 and "kread" not in abl:
+        if s2 and "kread" not in abl and self.ct and "ctk64" not in self.opt:
+            # 32-register fragment pool: k-steps 0..3 are read during the PV phase, k-step ks >= 4 goes into the slot of ks - 4
+            # as soon as the four MFMAs of that k-step are issued (12 MFMAs ahead of its own first use)
+            kr = self.stream_kread(par)
+            self.place(load, slots, kr[:8], cfg["kread_ct"][0], cfg["kread_ct"][1], 3)
+            for ks in range(4, 8):
+                g = 32 + 4 * (ks - 4) + 3
+                for kvb in range(2):
+                    it = kr[2 * ks + kvb]
+                    load[g] += _weight(it)
+                    slots[g].append((g + 0.5 + 0.1 * kvb, 3, it))
+        elif s2 and "kread" not in abl:
             self.place(load, slots, self.stream_kread(par), cfg["kread"][0], cfg["kread"][1], 3)
-        if s1 and "vread" not in abl:
+        if s1 and "vread" not in abl and cfg["vsplit"][1] > 0 and fast:
+            vr = self.stream_vread(par ^ 1)
+            self.place(load, slots, vr[16:], cfg["vsplit"][0], cfg["vsplit"][1], 4)
+            self.place(load, slots, vr[:16], W(cfg["vread"])[0], W(cfg["vread"])[1], 4)
+        elif s1 and "vread" not in abl:
             self.place(load, slots, self.stream_vread(par ^ 1), W(cfg["vread"])[0], W(cfg["vread"])[1], 4)
         if s1 and "exp" not in abl:
             self.place(load, slots, self.stream_exp(0, par ^ 1), ew[0], ew[1] - 1.0, 5)
@@ -483,6 +548,7 @@ class Gen:
         for g in range(ng):
             slots[g].sort(key=lambda x: (x[0], x[1]))
         # emit: gap g fillers come AFTER mfma g
+        body_start = len(p.ins)
         for g in range(ng):
             if g == 32:
                 # phase boundary: all of PV(t) is issued.  Rare O rescale, then K(t+2) fragments must have landed.
@@ -499,6 +565,8 @@ class Gen:
                 p.ins.append(mf[g])
             for (_, _, item) in slots[g]:
                 p.ins.extend(item if isinstance(item, list) else [item])
+        if self.ct:
+            p.ins[body_start:] = self.lds_waits(p.ins[body_start:])
         # end of body: DMA landed, my LDS reads done, then everybody
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)
@@ -519,6 +587,69 @@ class Gen:
             p.emit("s_sub_u32", S_TMP, S(84), S_TC[0])
             p.emit("s_add_u32", S_SUM[2], S_SUM[2], S_TMP)
             p.emit("s_add_u32", S_SUM[3], S_SUM[3], 1)
+
+    @staticmethod
+    def _regs(ins):
+        """(reads, writes) of an instruction as lists of (kind, lo, hi) register ranges (what the LDS-wait pass needs)."""
+        def rng(o):
+            if isinstance(o, Neg):
+                o = o.reg
+            return (o.kind, o.idx, o.idx + o.n) if hasattr(o, "kind") and hasattr(o, "idx") else None
+        ops = [rng(o) for o in ins.ops]
+        if ins.op.startswith("s_") or ins.op in ("label", "raw"):
+            return [], []
+        if ins.op.startswith("v_permlane"):
+            both = [o for o in ops if o]
+            return both, both
+        if ins.op.startswith("v_cmp") or ins.op.startswith("buffer_load") or ins.op.startswith("ds_write"):
+            return [o for o in ops if o], []
+        return [o for o in ops[1:] if o], [o for o in ops[:1] if o]
+
+    def lds_waits(self, items, look=3):
+        """Counted `s_waitcnt lgkmcnt(n)` in front of the first instruction that touches the destination of an LDS read still
+        in flight (LDS reads return in order, so n = the number of reads issued after the one needed).  One wait also covers
+        what the next `look` MFMAs need, so a k-step costs one wait, not four."""
+        out, pend = [], []                     # pend: destinations of the reads in flight, oldest first
+        def need(ins):
+            rd, wr = self._regs(ins)
+            j = -1
+            for (k, lo, hi) in rd + wr:
+                for i, (pk, plo, phi) in enumerate(pend):
+                    if pk == k and lo < phi and plo < hi:
+                        j = max(j, i)
+            return j
+        for idx, ins in enumerate(items):
+            if ins.op == "s_waitcnt":
+                if "lgkmcnt" in ins.mods:
+                    keep = ins.mods["lgkmcnt"]
+                    pend = pend[len(pend) - keep:] if keep else []
+                out.append(ins)
+                continue
+            if ins.op == "s_memtime":          # SMEM shares the counter and may return out of order: drain, then count afresh
+                if pend:
+                    out.append(mk("s_waitcnt", lgkmcnt=0))
+                    pend = []
+                out.append(ins)
+                out.append(mk("s_waitcnt", lgkmcnt=0))
+                continue
+            j = need(ins)
+            if j >= 0:
+                if ins.op.startswith("v_mfma"):
+                    seen = 0
+                    for nxt in items[idx + 1:]:
+                        if nxt.op.startswith("v_mfma"):
+                            j = max(j, need(nxt))
+                            seen += 1
+                            if seen >= look:
+                                break
+                n = len(pend) - 1 - j
+                out.append(mk("s_waitcnt", lgkmcnt=min(n, 15)))
+                pend = pend[j + 1:] if n <= 15 else pend[len(pend) - 15:]
+            if ins.op.startswith("ds_read"):
+                _, wr = self._regs(ins)
+                pend.append(wr[0])
+            out.append(ins)
+        return out
 
     def rare_rescale(self, lab):
         r = [Ins("label", (Label(lab),))]
@@ -557,7 +688,7 @@ class Gen:
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
         for dt in range(4):
             p.emit("v_xor_b32", VR[dt], dt << 6, A_VR0)
-        if not self.pre:
+        if not self.fold:
             for qb in range(2):
                 for ks in range(8):
                     p.emit("global_load_dwordx4", QF(qb, ks), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
@@ -610,24 +741,39 @@ class Gen:
                 p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
             p.label("no_k1")
         for qb in range(2):
-            p.emit("v_mov_b32", MC[qb], 0.0 if self.pre else NEG_INF)
+            p.emit("v_mov_b32", MC[qb], 0.0 if self.fold else NEG_INF)
             p.emit("v_mov_b32", LA[qb], 0)
             p.emit("v_mov_b32", LB[qb], 0)
             p.emit("v_mov_b32", FSC[qb], 1.0)
         for i in range(128):
             p.emit("v_accvgpr_write_b32", A(i), 0)
-        if self.pre:
+        if self.ct:
+            for qb in range(2):
+                for i in range(16):
+                    p.emit("v_mov_b32", CT[qb][i], 0)              # C tuples: the reference starts at 0
+        if self.fold:
             # extra k-step operands: K side = 1.0 in the eight k-slots of the lower lane half (the upper half's slots are 0),
             # Q side = the (negated) reference, 0 for now
             one2 = 0x3f803f80 if self.bf16 else 0x3c003c00
-            p.emit("v_and_b32", TMP[0], 16, A_EPI)             # the epilogue address carries hi * 16
-            p.emit("v_mov_b32", TMP[1], one2)
-            p.emit("v_cmp_eq_u32", VCC, 0, TMP[0])
-            for i in range(4):
-                p.emit("v_cndmask_b32", KX[i], 0, TMP[1], VCC)
-                p.emit("v_mov_b32", QX[0][i], 0)
-                p.emit("v_mov_b32", QX[1][i], 0)
-            p.emit("s_waitcnt", vmcnt=0)                        # the 16 Q loads (and the staged tiles behind them)
+            if self.pre:
+                p.emit("v_and_b32", TMP[0], 16, A_EPI)             # the epilogue address carries hi * 16
+                p.emit("v_mov_b32", TMP[1], one2)
+                p.emit("v_cmp_eq_u32", VCC, 0, TMP[0])
+                for i in range(4):
+                    p.emit("v_cndmask_b32", KX[i], 0, TMP[1], VCC)
+                    p.emit("v_mov_b32", QX[0][i], 0)
+                    p.emit("v_mov_b32", QX[1][i], 0)
+            if self.ct and early:
+                # the 16 Q loads were issued first: K(0), V(0) and K(1) (12 or 8 pieces behind them) keep flying during the prescale
+                p.emit("s_cmp_lt_i32", A_NTWG, 2)
+                p.emit("s_cbranch_scc1", Label("qwait8"))
+                p.emit("s_waitcnt", vmcnt=12)
+                p.emit("s_branch", Label("qwaited"))
+                p.label("qwait8")
+                p.emit("s_waitcnt", vmcnt=8)
+                p.label("qwaited")
+            else:
+                p.emit("s_waitcnt", vmcnt=0)                        # the 16 Q loads (and the staged tiles behind them)
             for i in range(64):
                 src, t0, t1 = V(VBASE + i), TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]
                 if self.bf16:
@@ -643,7 +789,10 @@ class Gen:
                 p.emit(self.cvt, t0, t0, t1)
                 p.emit("s_nop", 0)
                 p.emit("v_accvgpr_write_b32", A(128 + i), t0)
-            p.emit("s_waitcnt", vmcnt=0)
+            if not (self.ct and early):
+                p.emit("s_waitcnt", vmcnt=0)
+        if self.fold and not (self.ct and early):
+            pass
         elif not early:
             p.emit("s_waitcnt", vmcnt=0)
         else:
@@ -844,7 +993,9 @@ def main():
     for fold in (False, True):
         for bf16 in (False, True):
             c2 = dict(cfg)
-            c2["opt"] = tuple(x for x in cfg.get("opt", ()) if x != "pre") + (("pre",) if fold else ())
+            # the *_fold.inc bodies: "ct" (reference rides in the C operand) unless opt=usepre asks for the extra-k-step form
+            fopt = "pre" if "usepre" in cfg.get("opt", ()) else "ct"
+            c2["opt"] = tuple(x for x in cfg.get("opt", ()) if x not in ("pre", "ct", "usepre")) + ((fopt,) if fold else ())
             g = Gen(bf16, **c2)
             prog = g.build()
             path = os.path.join(out_dir, "fa2_fwd_d128_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))

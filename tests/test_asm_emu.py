@@ -29,9 +29,11 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[("pre",), ()], ids=["folded-scale", "f32-scale"])
+@pytest.fixture(params=[("ct",), (), ("pre",)], ids=["folded-scale", "f32-scale", "folded-scale-extra-k-step"])
 def variant(request):
-    """Both bodies the library ships: scale folded into Q (the default when scale*log2e <= 1) and scale applied in f32."""
+    """The bodies the library ships — scale applied in f32 (default) and scale folded into Q with the running reference in the
+    C operand of the first QK^T k-step (opt-in, FA2_D128_FOLD=1) — and the earlier form of the fold (reference through a ninth
+    k-step; generator option usepre)."""
     saved = harness.OPT
     harness.OPT = request.param
     harness._PROGS.clear()
@@ -71,7 +73,7 @@ def test_emulator_flags_a_missing_wait():
             harness._PROGS.pop(False, None)
 
 
-@pytest.mark.parametrize("opt", [(), ("pre",)])
+@pytest.mark.parametrize("opt", [(), ("ct",), ("pre",)])
 def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     """Every line of the rendered body goes through the gfx950 assembler (operand classes, constant-bus limits, offsets):
     the emulator interprets instruction objects, so this is the check that the TEXT is legal."""

@@ -568,6 +568,27 @@ def test_d128_asm_kernel_on_small_and_ragged_grids():
     assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
 
 
+def test_d128_folded_scale_kernel_in_a_child_process():
+    """The opt-in folded-scale bodies of the D = 128 kernel (FA2_D128_FOLD=1: Q * scale*log2e rounded once to the I/O dtype, the
+    running reference in the C operand of the first QK^T k-step).  The library reads the switch once per process, so the
+    head-dim-128 parity cases run again in a child process; `_assert_close_to_oracle` asks fa2_fwd_prescales_q() which scaling
+    contract the oracle must use, so the comparison is against the same-contract oracle at the usual tolerances."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, FA2_FWD_ROWS="256", FA2_D128_FOLD="1")
+    chk = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from rocwmma_fattn import _fa2_lib as L; "
+                          "print(L.load().fa2_fwd_prescales_q(128, 128 ** -0.5))" % os.path.join(root, "flash-attention-v2-rdna3-minimal_amd")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert chk.stdout.strip().endswith("1"), chk.stdout + chk.stderr[-2000:]
+    sel = "golden or seeded or ragged_tail or scale or large_logits or bnhd_d128 or precision_shape"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
+                          "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
+
+
 def test_bnhd_d128_zero_copy():
     """[B, N, H, D] storage at head dim 128 (row stride H*D): the hand-scheduled kernel takes the same strides."""
     g = torch.Generator(device="cpu").manual_seed(16)

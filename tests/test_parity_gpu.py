@@ -215,8 +215,11 @@ def test_large_logits_and_forced_rescale(D):
     o_true, lse_true = fo.fwd_numpy(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), False)
     got = o.float().cpu().numpy()
     assert np.isfinite(got).all()
-    assert np.all(np.abs(got - o_true) <= 2e-3 + 4e-3 * np.abs(o_true))
-    assert np.abs(lse.cpu().numpy() - lse_true).max() <= 2e-2
+    # folded-scale build (opt-in): Q * scale*log2e is rounded to 16 bits, which on logits of several hundred is ~1e-2 in O and
+    # ~0.1 in the log2 LSE against the float64 truth (measured 1.3e-2); the same-contract oracle below stays at the usual tolerance
+    folded = _oracle_flags(D) != 0
+    assert np.all(np.abs(got - o_true) <= (3e-2 if folded else 2e-3) + 4e-3 * np.abs(o_true))
+    assert np.abs(lse.cpu().numpy() - lse_true).max() <= (0.3 if folded else 2e-2)
     _assert_close_to_oracle(o, lse, q, k, v, 0, False)
 
 
@@ -568,7 +571,7 @@ def test_d128_asm_kernel_on_small_and_ragged_grids():
     assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
 
 
-def test_d128_folded_scale_kernel_in_a_child_process():
+def test_d128_fold_variant_in_a_child_process():
     """The opt-in folded-scale bodies of the D = 128 kernel (FA2_D128_FOLD=1: Q * scale*log2e rounded once to the I/O dtype, the
     running reference in the C operand of the first QK^T k-step).  The library reads the switch once per process, so the
     head-dim-128 parity cases run again in a child process; `_assert_close_to_oracle` asks fa2_fwd_prescales_q() which scaling

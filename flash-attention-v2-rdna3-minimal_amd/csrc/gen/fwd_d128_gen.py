@@ -49,18 +49,25 @@ NEG_INF = float("-inf")
 
 # ---- inline-asm operands (order = the operand list of the asm statement in fa2_fwd_d128.hip.h)
 A_LSE0, A_LSE1 = Arg(0), Arg(1)                    # "=&v" outputs: log2-domain LSE of this lane's row in q block 0 / 1
-A_Q0, A_Q1 = Arg(2, "v", 2), Arg(3, "v", 2)        # 64-bit global address of this lane's 16 Q bytes (k-step 0) in block 0 / 1
-A_KRS, A_VRS = Arg(4, "s", 4), Arg(5, "s", 4)      # buffer descriptors of this head's K / V matrix
-A_KD0, A_VD0 = Arg(6), Arg(7)                      # per-lane LDS-DMA source byte offset (piece 0, tile 0), K / V
-A_KR0, A_VR0 = Arg(8), Arg(9)                      # per-lane LDS read offset of K fragment k-step 0 / V^T fragment d-block 0
-A_LIM0, A_LIM1 = Arg(10), Arg(11)                  # last-tile mask: kv index (local, minus 4*hi) must be <= this, per q block
-A_C = Arg(12, "s")                                 # scale * log2(e), f32 bits
-A_NTW, A_NTWG = Arg(13, "s"), Arg(14, "s")         # KV tiles of this wave / of the workgroup
-A_KTILE, A_VTILE = Arg(15, "s"), Arg(16, "s")      # bytes between consecutive KV tiles in K / V
-A_KROW4, A_VROW4 = Arg(17, "s"), Arg(18, "s")      # 4 * row bytes - 1024: source stride between the DMA pieces of a wave
-A_LDSW = Arg(19, "s")                              # wave * 4096: this wave's quarter of a tile image
-A_EPI = Arg(20)                                    # per-lane LDS byte address of the epilogue image: row l31, half hi
-N_ARGS = 21
+A_QO0, A_QO1 = Arg(2), Arg(3)                      # byte offset of this lane's 16 Q bytes (k-step 0) in block 0 / 1 from the head base
+A_QB = Arg(4, "s", 2)                              # 64-bit address of this head's Q matrix
+A_KRS, A_VRS = Arg(5, "s", 4), Arg(6, "s", 4)      # buffer descriptors of this head's K / V matrix
+A_KD0, A_VD0 = Arg(7), Arg(8)                      # per-lane LDS-DMA source byte offset (piece 0, tile 0), K / V
+A_KR0, A_VR0 = Arg(9), Arg(10)                     # per-lane LDS read offset of K fragment k-step 0 / V^T fragment d-block 0
+A_LIM0, A_LIM1 = Arg(11), Arg(12)                  # last-tile mask: kv index (local, minus 4*hi) must be <= this, per q block
+A_C = Arg(13, "s")                                 # scale * log2(e), f32 bits
+A_NTW, A_NTWG = Arg(14, "s"), Arg(15, "s")         # KV tiles of this wave / of the workgroup
+A_KTILE, A_VTILE = Arg(16, "s"), Arg(17, "s")      # bytes between consecutive KV tiles in K / V
+A_KROW4, A_VROW4 = Arg(18, "s"), Arg(19, "s")      # 4 * row bytes - 1024: source stride between the DMA pieces of a wave
+A_LDSW = Arg(20, "s")                              # wave * 4096: this wave's quarter of a tile image
+A_EPI = Arg(21)                                    # per-lane LDS byte address of the epilogue image: row l31, half hi
+# persistent workgroups: the asm statement runs once per (head, q block) item of the workgroup's list; the last two bodies of
+# an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
+A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists
+A_NQO0, A_NQO1 = Arg(23), Arg(24)                  # the next item's Q offsets / head base / K and V descriptors
+A_NQB = Arg(25, "s", 2)
+A_NKRS, A_NVRS = Arg(26, "s", 4), Arg(27, "s", 4)
+N_ARGS = 28
 
 # ---- fixed registers (everything below is clobbered by the asm statement)
 VBASE = 16
@@ -90,6 +97,7 @@ EP_LT, EP_T, EP_INV = FSC[0], FSC[1], KX[0]        # epilogue scratch (the softm
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
 S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
+S_NOVM, S_PF = S(66), S(67)                          # next item's loads are in flight (do not drain vmcnt) / this item came prefetched
 S_TA, S_TB, S_TC = S(74, 2), S(76, 2), S(78, 2)      # "trace" builds: s_memtime samples (body start, phase boundary, body end)
 S_SUM = [S(80), S(81), S(82), S(83)]                 # cycle sums over the fast bodies: PV phase, QK phase, barrier, bodies
 S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, first main body, epilogue start, block end
@@ -98,7 +106,8 @@ CLOBBER_V = list(range(VBASE, 256))
 
 K_SLOT, V_BASE, SLOT_B = 0, 32768, 16384
 EPI_ROWB = 272                                     # bytes per staged O row (256 + 16 pad)
-LDS_BYTES = 4 * 64 * EPI_ROWB                      # 69632: the epilogue image is the high-water mark
+EPI_BASE = 65536                                   # the epilogue image sits above the K / V rings: they hold the next item's first tiles by then
+LDS_BYTES = EPI_BASE + 4 * 64 * EPI_ROWB           # 135168
 
 # relative issue cost of the instruction classes (the scheduler balances this, not the instruction count)
 WEIGHT = {"valu": 1.0, "trans": 1.7, "lds": 1.6, "dma": 3.5, "salu": 0.4, "branch": 0.5, None: 0.0}
@@ -125,6 +134,18 @@ def KF_POOL(kvb, ks):                              # "ct" kernels: a 32-register
 CT = [V(176, 16), V(192, 16)]
 
 
+def VF_ACC(dt, ks):                                # "vagpr": every LDS read returns into the accumulator file
+    return A(128 + 16 * ks + 4 * dt, 4)
+
+
+def QF_ARCH(qb, ks):                               # ... and the Q fragments (loaded once) take the V^T fragments' arch VGPRs
+    return V(144 + 32 * qb + 4 * ks, 4)
+
+
+def QF_SPLIT(qb, ks):                              # "ct" + "vagpr": v[176:207] are the C tuples, so half of Q stays in a[224:255]
+    return V(144 + 16 * qb + 4 * ks, 4) if ks < 4 else A(224 + 16 * qb + 4 * (ks - 4), 4)
+
+
 def VF_CT(dt, ks):
     return V(144 + 16 * ks + 4 * dt, 4) if ks < 2 else A(224 + 16 * (ks - 2) + 4 * dt, 4)
 
@@ -133,6 +154,10 @@ def _weight(item):
     if isinstance(item, list):
         return sum(_weight(i) for i in item)
     return 0.0 if item.op == "label" else WEIGHT.get(item.tag, 1.0)
+
+
+def set_weights(trans, lds, dma, salu):
+    WEIGHT.update({"trans": trans, "lds": lds, "dma": dma, "salu": salu, "branch": salu})
 
 
 class Gen:
@@ -150,6 +175,8 @@ class Gen:
     def __init__(self, bf16=False, **cfg):
         self.cfg = dict(self.DEFAULTS)
         self.cfg.update(cfg)
+        if "w1" in self.cfg and "w2" in self.cfg:     # scheduler weights: w1=trans:lds, w2=dma:salu
+            set_weights(self.cfg["w1"][0], self.cfg["w1"][1], self.cfg["w2"][0], self.cfg["w2"][1])
         self.opt = set(self.cfg["opt"])
         self.pre = "pre" in self.opt      # folded scale: Q is multiplied by c and rounded once, -m rides in an extra k-step
         self.ct = "ct" in self.opt        # folded scale, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
@@ -157,6 +184,10 @@ class Gen:
         self.fold = self.pre or self.ct   # what the two share: prescaled Q, S leaves the MFMA as (score - reference)
         self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else KF      # ctk64: timing probe (K and V^T fragments collide)
         self.vf = VF_CT if self.ct else VF
+        self.qf = QF
+        if "vagpr" in self.opt:
+            self.vf = VF_ACC
+            self.qf = QF_SPLIT if self.ct else QF_ARCH
         self.nqk = 36 if self.pre else 32
         self.ng = 32 + self.nqk           # MFMAs (= gaps) per body
         self.bf16 = bf16
@@ -187,7 +218,7 @@ class Gen:
                 for kvb in range(2):
                     dst = SB(qb, par).sub(16 * kvb, 16)
                     c0 = CT[qb] if (self.ct and "ctc0" not in self.opt) else 0        # ctc0: timing probe (no reference in S)
-                    out.append(mk(self.mfma, dst, self.kf(kvb, ks), QF(qb, ks), c0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
+                    out.append(mk(self.mfma, dst, self.kf(kvb, ks), self.qf(qb, ks), c0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
@@ -197,21 +228,34 @@ class Gen:
         b = SB(qb, par)
         out = []
         for k in range(16 + 3):
+            F, E, Ad, C = [], [], [], []
             if k < 16 and "nofma" not in self.opt and not self.fold:   # stage 0: x = s*c - m*c
                 e = 2 * k
-                out.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
-                out.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
+                F.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
+                F.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
             if 0 <= k - 1 < 16:                               # stage 1: 2^x
                 e = 2 * (k - 1)
-                out.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
-                out.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
+                E.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
+                E.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
             if 0 <= k - 2 < 16 and "noadd" not in self.opt:   # stage 2: row sums
                 e = 2 * (k - 2)
-                out.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
-                out.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
+                Ad.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
+                Ad.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
             if 0 <= k - 3 < 16:                               # stage 3: pack the pair in place
                 e = 2 * (k - 3)
-                out.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
+                C.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
+            if "expsep" in self.opt:
+                # never two transcendentals back to back: the second one would wait for the unit (8 cycles per v_exp_f32,
+                # 4 to issue) — every v_exp is followed by a plain VALU instruction of another pair
+                plain = F + Ad + C
+                order = []
+                for x in E:
+                    order.append(x)
+                    if plain:
+                        order.append(plain.pop(0))
+                out += order + plain
+            else:
+                out += F + E + Ad + C
         return out
 
     def split16(self, r, src, terms, tmp):
@@ -380,16 +424,47 @@ class Gen:
     def dma_group(self, which, slot_par, guarded, ahead):
         """The 4 LDS-DMA pieces of this wave's quarter of one K or V tile (tile index = t + ahead): image bytes
         [wave*4096 + i*1024, +1024), i.e. tile rows 16*wave + 4*i + lane/16.  M0 holds the quarter's LDS address, the piece
-        is selected by the instruction offset (which also advances the source address: KD / VD are biased by -1024*i)."""
+        is selected by the instruction offset (which also advances the source address: KD / VD are biased by -1024*i).
+        Guarded bodies (everything but the fast loop): past this item's last tile, the K group of body ntwg-2 stages the
+        NEXT item's K(0), K(1) and Q fragments and the V group of body ntwg-1 its V(0) (out of line; both rings and the Q
+        registers are idle by then), and the end-of-body wait stops draining vmcnt."""
         out = []
         rs, vd, soff = (A_KRS, KD, S_KOFF) if which == "k" else (A_VRS, VD, S_VOFF)
         base = (K_SLOT if which == "k" else V_BASE) + slot_par * SLOT_B
         skip = None
         if guarded:
             skip = self.p.fresh("dma_skip")
+            nxt = self.p.fresh("dma_next")
             out.append(mk("s_add_u32", S_TMP2, S_T, ahead, tag="salu"))
             out.append(mk("s_cmp_lt_i32", S_TMP2, A_NTWG, tag="salu"))
-            out.append(mk("s_cbranch_scc0", Label(skip), tag="branch"))
+            out.append(mk("s_cbranch_scc0", Label(nxt), tag="branch"))
+            r = [Ins("label", (Label(nxt),))]
+            r.append(mk("s_bitcmp1_b32", A_FLAGS, 1))
+            r.append(mk("s_cbranch_scc0", Label(skip)))
+            r.append(mk("s_sub_u32", S_TMP2, S_TMP2, 1))          # K: t + 2, V: t + 1 ...
+            r.append(mk("s_cmp_eq_u32", S_TMP2, A_NTWG))         # ... == ntwg: body ntwg-2 (K) / ntwg-1 (V)
+            r.append(mk("s_cbranch_scc0", Label(skip)))
+            r.append(mk("s_mov_b32", S_NOVM, 1))
+            nrs = A_NKRS if which == "k" else A_NVRS
+            nbase = K_SLOT if which == "k" else V_BASE
+            r.append(mk("s_add_u32", M0, A_LDSW, nbase))
+            r.append(mk("s_nop", 0))
+            for i in range(4):
+                r.append(mk("buffer_load_dwordx4", vd[i], nrs, 0, offen=True, offset=1024 * i, lds=True))
+            if which == "k":
+                one = self.p.fresh("dma_next_one")
+                r.append(mk("s_cmp_lt_i32", A_NTWG, 2))          # (items of one launch have the same number of tiles)
+                r.append(mk("s_cbranch_scc1", Label(one)))
+                r.append(mk("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B))
+                r.append(mk("s_nop", 0))
+                for i in range(4):
+                    r.append(mk("buffer_load_dwordx4", vd[i], nrs, A_KTILE, offen=True, offset=1024 * i, lds=True))
+                r.append(Ins("label", (Label(one),)))
+                for qb in range(2):
+                    for ks in range(8):
+                        r.append(mk("global_load_dwordx4", self.qf(qb, ks), A_NQO0 if qb == 0 else A_NQO1, A_NQB, offset=32 * ks))
+            r.append(mk("s_branch", Label(skip)))
+            self.rare.append(r)
         out.append([mk("s_add_u32", M0, A_LDSW, base, tag="salu"), mk("s_nop", 0, tag="salu")])
         for i in range(4):
             out.append(mk("buffer_load_dwordx4", vd[i], rs, soff, tag="dma", offen=True, offset=1024 * i, lds=True))
@@ -571,7 +646,15 @@ class Gen:
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)
         p.emit("s_add_u32", S_VOFF, S_VOFF, A_VTILE)
-        if "waitend" not in abl:
+        if "waitend" not in abl and guarded and dma:
+            # (bodies that may have staged the next item's tiles: those loads are waited for by the next statement)
+            lab = p.fresh("novm")
+            p.emit("s_cmp_eq_u32", S_NOVM, 0)
+            p.emit("s_cbranch_scc0", Label(lab))
+            p.emit("s_waitcnt", vmcnt=0)
+            p.label(lab)
+            p.emit("s_waitcnt", lgkmcnt=0)
+        elif "waitend" not in abl:
             p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
         if trace:
             p.emit("s_memtime", S_TC)
@@ -688,17 +771,28 @@ class Gen:
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
         for dt in range(4):
             p.emit("v_xor_b32", VR[dt], dt << 6, A_VR0)
+        # Q fragments: 16 loads, unless the previous item of this persistent workgroup already fetched them (flag bit 0)
+        p.emit("s_and_b32", S_PF, A_FLAGS, 1)
+        p.emit("s_cmp_eq_u32", S_PF, 1)
+        p.emit("s_cbranch_scc1", Label("have_q"))
         if not self.fold:
             for qb in range(2):
                 for ks in range(8):
-                    p.emit("global_load_dwordx4", QF(qb, ks), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
+                    p.emit("global_load_dwordx4", self.qf(qb, ks), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
+            p.label("have_q")
         else:
             # folded scale: Q comes through the (still unused) S banks, is multiplied by c in f32 and rounded back ONCE —
             # the reference oracle's contract `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file
             qv = V(VBASE, 64)
             for qb in range(2):
                 for ks in range(8):
-                    p.emit("global_load_dwordx4", qv.sub(32 * qb + 4 * ks, 4), A_Q0 if qb == 0 else A_Q1, OFF, offset=32 * ks)
+                    p.emit("global_load_dwordx4", qv.sub(32 * qb + 4 * ks, 4), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
+            p.emit("s_branch", Label("q_issued"))
+            p.label("have_q")
+            for i in range(64):       # prefetched raw Q sits in the fragment registers: back through the S banks for the prescale
+                qreg = self.qf(i // 32, (i % 32) // 4)[i % 4]
+                p.emit("v_accvgpr_read_b32" if qreg.kind == "a" else "v_mov_b32", V(VBASE + i), qreg)
+            p.label("q_issued")
         # DMA source offsets of piece i: rows 4*i further down, the K granule swizzle follows the row (xor i<<6), and the
         # instruction offset 1024*i that selects the LDS piece is taken back out of the source address
         p.emit("v_mov_b32", KD[0], A_KD0)
@@ -718,6 +812,10 @@ class Gen:
         for r in S_SUM:
             p.emit("s_mov_b32", r, 0)
         p.emit("s_mov_b32", S_KOFF, 0)
+        p.emit("s_mov_b32", S_NOVM, 0)
+        p.emit("s_mov_b32", S_VOFF, 0)
+        p.emit("s_cmp_eq_u32", S_PF, 1)
+        p.emit("s_cbranch_scc1", Label("staged"))
         # K(0) -> K slot 0 (always exists)
         p.emit("s_add_u32", M0, A_LDSW, K_SLOT)
         p.emit("s_nop", 0)
@@ -725,9 +823,7 @@ class Gen:
             p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
         # ... and what body B(-2) would stage, V(0) and K(1), right behind it: all three tiles' latencies overlap (B(-2) then
         # stages nothing).  The running offsets are those of tile t+3 / t+2 of the body that uses them.
-        p.emit("s_mov_b32", S_KOFF, A_KTILE)
-        p.emit("s_mov_b32", S_VOFF, 0)
-        early = "lateprefetch" not in self.opt       # (A/B switch: B(-2) stages V(0), K(1) itself, as the first version did)
+        early = True
         if early:
             p.emit("s_add_u32", M0, A_LDSW, V_BASE)
             p.emit("s_nop", 0)
@@ -738,8 +834,10 @@ class Gen:
             p.emit("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B)
             p.emit("s_nop", 0)
             for i in range(4):
-                p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
+                p.emit("buffer_load_dwordx4", KD[i], A_KRS, A_KTILE, offen=True, offset=1024 * i, lds=True)
             p.label("no_k1")
+        p.label("staged")
+        p.emit("s_mov_b32", S_KOFF, A_KTILE)     # the running offsets are those of tile t+3 / t+2 of the body that uses them
         for qb in range(2):
             p.emit("v_mov_b32", MC[qb], 0.0 if self.fold else NEG_INF)
             p.emit("v_mov_b32", LA[qb], 0)
@@ -788,7 +886,8 @@ class Gen:
                 p.emit("s_nop", 0)
                 p.emit(self.cvt, t0, t0, t1)
                 p.emit("s_nop", 0)
-                p.emit("v_accvgpr_write_b32", A(128 + i), t0)
+                qreg = self.qf(i // 32, (i % 32) // 4)[i % 4]
+                p.emit("v_accvgpr_write_b32" if qreg.kind == "a" else "v_mov_b32", qreg, t0)
             if not (self.ct and early):
                 p.emit("s_waitcnt", vmcnt=0)
         if self.fold and not (self.ct and early):
@@ -807,7 +906,7 @@ class Gen:
         p.emit("s_barrier")
 
         # ---- head bodies: t = -2 (parity 0): QK(0) only; t = -1 (parity 1): softmax of tile 0, QK(1) if there is a tile 1
-        self.body(0, pv=False, s1=False, s2=True, name="H1", dma="lateprefetch" in self.opt)
+        self.body(0, pv=False, s1=False, s2=True, name="H1", dma=False)
         p.emit("s_cmp_eq_u32", A_NTW, 1)
         p.emit("s_cbranch_scc1", Label("h2b"))
         self.body(1, pv=False, s1=True, s2=True, name="H2", first=True)
@@ -898,7 +997,7 @@ class Gen:
             p.emit("v_rcp_f32", inv, lt)
             p.emit("v_log_f32", t, lt)
             p.emit("s_nop", 0)
-            p.emit("v_add_f32", A_LSE0 if qb == 0 else A_LSE1, MC[qb], t)
+            p.emit("v_add_f32", KD[qb], MC[qb], t)            # (the outputs may share registers with inputs: written last)
             for dt in range(4):
                 acc = OACC(qb, dt)
                 for r4 in (0, 2):
@@ -923,6 +1022,8 @@ class Gen:
                     p.emit("ds_write_b128", A_EPI, d4, offset=32 * qb * EPI_ROWB + (32 * dt + 8 * r4) * 2)
                     p.emit("s_nop", 1)
         p.emit("s_waitcnt", lgkmcnt=0)
+        p.emit("v_mov_b32", A_LSE0, KD[0])
+        p.emit("v_mov_b32", A_LSE1, KD[1])
         if tr:          # developer build: the LSE outputs carry cycle counts instead
             p.emit("s_memtime", S_MARK[3])
             p.emit("s_waitcnt", lgkmcnt=0)

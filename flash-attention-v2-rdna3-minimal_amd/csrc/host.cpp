@@ -155,14 +155,37 @@ bool use_d128_fold() {
     return on;
 }
 bool d128_eligible(int D, float scale) { return D == 128 && scale > 0.f && use_d128_asm(); }
+// (the asm block addresses a head's Q rows with 32-bit byte offsets)
+bool d128_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + 128) * 2 < ((int64_t)1 << 32); }
 bool d128_folds(float c) { return use_d128_fold() && c <= 1.0f; }
+
+// Persistent workgroups of the d128 kernel (non-causal launches): at most one workgroup per CU, each working through a
+// strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
+// (fa2_fwd_d128.hip.h).  FA2_D128_PERSIST=0 in the environment launches one workgroup per item instead (A/B measurements).
+#ifndef FA2_D128_PERSIST
+#define FA2_D128_PERSIST 1     // build-time default of the switch
+#endif
+int d128_persistent_grid() {
+    static const int grid = [] {
+        const char* e = std::getenv("FA2_D128_PERSIST");
+        if (e ? e[0] == '0' : FA2_D128_PERSIST == 0) return 0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return cus & ~7;          // a multiple of 8: an item stays on the XCD its head is mapped to
+    }();
+    return grid;
+}
 
 template <bool BF16, bool CAUSAL, bool FOLD>
 int launch_d128_t(const fa2::FwdParams& p, hipStream_t stream) {
     static_assert(kFwdRows == 256, "the d128 kernel covers 256 Q rows per workgroup, like the default shape");
     constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL, FOLD>;
     if (int rc = set_lds<kern>(fa2::kD128LdsBytes)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(256), fa2::kD128LdsBytes, stream, p);
+    int64_t grid = (int64_t)p.nbh * p.nqblk;
+    const int pg = d128_persistent_grid();
+    if (!CAUSAL && pg > 0 && grid > pg) grid = pg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), fa2::kD128LdsBytes, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -194,7 +217,7 @@ int launch(const fa2::FwdParams& p0, bool causal, hipStream_t stream) {
 template <int HD, bool BF16>
 int launch_range(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     if constexpr (HD == 128) {
-        if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f) && pick_rows(p) == 256)
+        if (d128_eligible(p.D, p.negate_q ? -1.f : 1.f) && pick_rows(p) == 256 && d128_q_span_ok(p))
             return causal ? launch_d128<BF16, true>(p, stream) : launch_d128<BF16, false>(p, stream);
     }
     return causal ? launch_t<HD, BF16, true>(p, stream) : launch_t<HD, BF16, false>(p, stream);

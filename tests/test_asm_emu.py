@@ -51,6 +51,35 @@ def test_generated_block_matches_dense_attention(case, variant):
     assert lse_err <= 1e-4, lse_err
 
 
+SEAMS = [
+    # Nq, [Nkv per item], [q block per item], bf16
+    (512, [256, 256], [0, 1], False),
+    (512, [64, 64, 64], [0, 1, 0], False),        # one tile per item: the staging body is a head body
+    (512, [100, 128], [1, 0], False),             # two tiles, ragged first item
+    (768, [640, 640, 600], [0, 2, 1], False),     # fast loop on both sides of two seams
+    (256, [192, 192], [0, 0], True),              # odd number of tiles (the parities of the rings flip at the seam)
+]
+
+
+@pytest.mark.parametrize("seam", SEAMS)
+def test_persistent_workgroup_seams(seam, variant):
+    """One workgroup runs the statement for several items in a row (fa2_fwd_d128.hip.h's persistent loop): the last two bodies
+    of an item stage the next item's Q fragments and first K / V tiles, the next statement skips its loads.  Every item must
+    match dense attention and the emulator must see no hazard (loads in flight across the seam, LDS ring reuse)."""
+    import numpy as np
+    nq, nkvs, qblks, bf16 = seam
+    rng = np.random.default_rng(nq + sum(nkvs))
+    items = [(rng.standard_normal((nq, 128)), rng.standard_normal((nkv, 128)), rng.standard_normal((nkv, 128)), qb)
+             for nkv, qb in zip(nkvs, qblks)]
+    outs, m = harness.run_items(items, False, bf16=bf16)
+    assert not m.errors, m.errors[:5]
+    for (q, k, v, qb), (o, lse) in zip(items, outs):
+        r0 = qb * 256
+        o_ref, lse_ref = harness.dense(q[r0:r0 + o.shape[0]], k, v, False, bf16=bf16, row0=r0, pre=bool(variant))
+        assert np.abs(o - o_ref).max() <= (4e-3 if bf16 else 1e-3)
+        assert np.abs(lse - lse_ref).max() <= 1e-4
+
+
 def test_emulator_flags_a_missing_wait():
     """The checker itself: drop the lgkmcnt wait in front of the QK^T phase and the emulator must object."""
     import fwd_d128_gen as gen
@@ -84,8 +113,9 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
     if not os.path.exists(mc):
         pytest.skip("llvm-mc not available")
-    subst = {0: "v0", 1: "v1", 2: "v[2:3]", 3: "v[4:5]", 4: "s[0:3]", 5: "s[4:7]", 6: "v6", 7: "v7", 8: "v8", 9: "v9", 10: "v10",
-             11: "v11", 12: "s8", 13: "s9", 14: "s10", 15: "s11", 16: "s12", 17: "s13", 18: "s14", 19: "s15", 20: "v12"}
+    subst = {0: "v0", 1: "v1", 2: "v2", 3: "v3", 4: "s[0:1]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
+             12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
+             23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]"}
     for bf16 in (False, True):
         text = "\n".join(gen.Gen(bf16, opt=opt).build().text_lines())
         text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))

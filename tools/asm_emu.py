@@ -524,8 +524,14 @@ class Machine:
         elif op == "global_load_dwordx4":
             dst = R(0)
             a = R(1)
-            lo, hi = self.regfile(w, a.kind)[a.idx].astype(np.uint64), self.regfile(w, a.kind)[a.idx + 1].astype(np.uint64)
-            addr = (lo | (hi << np.uint64(32))).astype(np.int64) + ins.mods.get("offset", 0)
+            sb = R(2)
+            if isinstance(sb, Sym):          # `off`: 64-bit address in a VGPR pair
+                lo, hi = self.regfile(w, a.kind)[a.idx].astype(np.uint64), self.regfile(w, a.kind)[a.idx + 1].astype(np.uint64)
+                addr = (lo | (hi << np.uint64(32))).astype(np.int64) + ins.mods.get("offset", 0)
+            else:                            # saddr form: 64-bit scalar base (numpy uint32[2]) + 32-bit VGPR offset
+                self.check_read(w, a.kind, a.idx, 1, "valu")
+                base = int(sb[0]) | (int(sb[1]) << 32)
+                addr = base + self.regfile(w, a.kind)[a.idx].astype(np.int64) + ins.mods.get("offset", 0)
             data = np.stack([self.gread(int(x), 16).view(np.uint32) for x in addr])       # [64, 4]
             self.mark_inflight(w, dst, 4, +1)
 
@@ -592,6 +598,16 @@ class Machine:
             if not progressed:
                 raise EmuError("deadlock")
         for w in self.waves:
-            if w.lgkm or w.vm:
+            if w.lgkm or (w.vm and not getattr(self, "allow_vm_in_flight", False)):
                 self.errors.append("wave %d ends with loads in flight" % w.wid)
         return self
+
+    def reenter(self, wave_args):
+        """The same workgroup runs the statement again with new operands (persistent workgroups: registers, LDS and the
+        loads still in flight carry over; compiler-owned registers v0..15 are rebound by the caller)."""
+        for w, a in zip(self.waves, wave_args):
+            w.args = a
+            w.pc = 0
+            w.done = False
+            w.at_barrier = False
+        self.epoch += 1

@@ -32,8 +32,9 @@ def from_bits(b, bf16):
     return asm_emu.bf16_to_f32(b) if bf16 else asm_emu.f16_to_f32(b)
 
 
-def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=256):
-    """The values fa2_fwd_d128.hip.h hands to the asm statement, for wave w of the workgroup owning Q block qblk."""
+def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=256, flags=0, nxt=None):
+    """The values fa2_fwd_d128.hip.h hands to the asm statement, for wave w of the workgroup working on Q block qblk.
+    nxt = (qblk, Nq, q_base, k_base, v_base, Nkv) of the workgroup's next item (flags bit 1) or None."""
     lane = np.arange(64)
     l31, hi = lane & 31, lane >> 5
     pp, g1 = lane & 15, (lane >> 4) & 1
@@ -48,70 +49,113 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         ntw = min(ntiles, (qw0 + 63) // 64 + 1)
     args = {}
     v = np.zeros((24, 64), dtype=np.uint32)
+
+    def q_offsets(qblk_, Nq_):
+        out = []
+        for qb in range(2):
+            qrow = qblk_ * 256 + 64 * w + 32 * qb + l31
+            qr = np.minimum(qrow, Nq_ - 1)
+            out.append((qr.astype(np.int64) * row_bytes + hi * 16).astype(np.uint32))
+        return out
+
+    v[2], v[3] = q_offsets(qblk, Nq)
     for qb in range(2):
         qrow = qw0 + 32 * qb + l31
-        qr = np.minimum(qrow, Nq - 1)
-        addr = q_base + qr.astype(np.int64) * row_bytes + hi * 16
-        v[2 + 2 * qb] = (addr & 0xffffffff).astype(np.uint32)
-        v[3 + 2 * qb] = (addr >> 32).astype(np.uint32)
         lim_c = qrow if causal else np.full(64, 0x3fffffff)
         lim = np.minimum(lim_c, Nkv - 1) - 64 * (ntw - 1) - 4 * hi
-        v[10 + qb] = lim.astype(np.int32).view(np.uint32)
+        v[11 + qb] = lim.astype(np.int32).view(np.uint32)
     row = 16 * w + (lane >> 4)
     slot = lane & 15
     gk = slot ^ (row & 15)
-    v[6] = (row * row_bytes + gk * 16).astype(np.uint32)
+    v[7] = (row * row_bytes + gk * 16).astype(np.uint32)
     gv = (((slot >> 2) ^ (row & 3)) << 2) | (slot & 3)
-    v[7] = (row * row_bytes + gv * 16).astype(np.uint32)
-    v[8] = (l31 * 256 + ((hi ^ (l31 & 15)) << 4)).astype(np.uint32)
-    v[9] = ((4 * hi + (pp >> 2)) * 256 + ((pp >> 2) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
-    v[12] = (w * 64 * gen.EPI_ROWB + l31 * gen.EPI_ROWB + hi * 16).astype(np.uint32)
-    args["vregs"] = v
+    v[8] = (row * row_bytes + gv * 16).astype(np.uint32)
+    v[9] = (l31 * 256 + ((hi ^ (l31 & 15)) << 4)).astype(np.uint32)
+    v[10] = ((4 * hi + (pp >> 2)) * 256 + ((pp >> 2) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
+    v[13] = (gen.EPI_BASE + w * 64 * gen.EPI_ROWB + l31 * gen.EPI_ROWB + hi * 16).astype(np.uint32)
+
+    def srd(base, nkv):
+        return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + 256, 0x00020000], dtype=np.uint32)
+
+    def pair(base):
+        return np.array([base & 0xffffffff, base >> 32], dtype=np.uint32)
+
     args[0], args[1] = Reg("v", 0), Reg("v", 1)
-    args[2], args[3] = Reg("v", 2, 2), Reg("v", 4, 2)
-    nbytes = ((Nkv - 1) * row_bytes + 256)
-    args[4] = np.array([k_base & 0xffffffff, k_base >> 32, nbytes, 0x00020000], dtype=np.uint32)
-    args[5] = np.array([v_base & 0xffffffff, v_base >> 32, nbytes, 0x00020000], dtype=np.uint32)
-    for n, r in ((6, 6), (7, 7), (8, 8), (9, 9), (10, 10), (11, 11), (20, 12)):
-        args[n] = Reg("v", r)
-    args[12] = int(np.float32(scale * LOG2E).view(np.uint32))
-    args[13], args[14] = ntw, ntiles
-    args[15] = args[16] = 64 * row_bytes
-    args[17] = args[18] = 4 * row_bytes - 1024
-    args[19] = w * 4096
+    args[2], args[3] = Reg("v", 2), Reg("v", 3)
+    args[4] = pair(q_base)
+    args[5], args[6] = srd(k_base, Nkv), srd(v_base, Nkv)
+    for n in range(7, 13):
+        args[n] = Reg("v", n)
+    args[13] = int(np.float32(scale * LOG2E).view(np.uint32))
+    args[14], args[15] = ntw, ntiles
+    args[16] = args[17] = 64 * row_bytes
+    args[18] = args[19] = 4 * row_bytes - 1024
+    args[20] = w * 4096
+    args[21] = Reg("v", 13)
+    args[22] = flags
+    args[23], args[24] = Reg("v", 14), Reg("v", 15)
+    if nxt is not None:
+        nqblk, nNq, nq_base, nk_base, nv_base, nNkv = nxt
+        v[14], v[15] = q_offsets(nqblk, nNq)
+        args[25], args[26], args[27] = pair(nq_base), srd(nk_base, nNkv), srd(nv_base, nNkv)
+    else:
+        args[25], args[26], args[27] = pair(q_base), args[5], args[6]
+    args["vregs"] = v
     return args
+
+
+def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
+    """One persistent workgroup works through `items` = [(q [Nq,128], k [Nkv,128], v [Nkv,128], qblk), ...]: the asm
+    statement runs once per item, registers / LDS / loads in flight carry over, and between two statements this harness
+    plays the HIP shell (reads the O tile out of the LDS image, rebinds v0..15).  Returns [(o, lse)], machine."""
+    scale = 128 ** -0.5 if scale is None else scale
+    pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)       # NaN guard bands around every matrix
+    bufs, bases = [], []
+    addr = 0x10000000
+    for (q, k, v, _) in items:
+        b3 = []
+        for t in (q, k, v):
+            arr = np.concatenate([pad, to_bits(t, bf16).ravel(), pad]).view(np.uint8)
+            bufs.append((addr, arr))
+            b3.append(addr + pad.size * 2)
+            addr += (arr.size + 0xffff) & ~0xffff
+        bases.append(b3)
+    m = None
+    outs = []
+    for it, (q, k, v, qblk) in enumerate(items):
+        Nq, Nkv = q.shape[0], k.shape[0]
+        nxt = None
+        if it + 1 < len(items):
+            nq_, nk_, _, nqblk = items[it + 1]
+            assert (nk_.shape[0] + 63) // 64 == (Nkv + 63) // 64, "items of one launch have the same number of KV tiles"
+            nxt = (nqblk, nq_.shape[0], bases[it + 1][0], bases[it + 1][1], bases[it + 1][2], nk_.shape[0])
+        flags = (1 if it > 0 else 0) | (2 if nxt is not None else 0)
+        wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt)
+              for w in range(4)]
+        if m is None:
+            m = asm_emu.Machine(program(bf16), wa, gen.LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
+        else:
+            m.reenter(wa)
+        m.allow_vm_in_flight = nxt is not None
+        for w, a in zip(m.waves, wa):
+            w.v[:24] = a["vregs"]
+        m.run()
+        rows = min(256, Nq - qblk * 256)
+        img = m.lds[gen.EPI_BASE:gen.EPI_BASE + 4 * 64 * gen.EPI_ROWB].reshape(256, gen.EPI_ROWB)[:, :256].copy().view(np.uint16)
+        o = from_bits(img, bf16)[:rows]
+        lse = np.empty(256, dtype=np.float32)
+        for w in range(4):
+            for qb in range(2):
+                lse[64 * w + 32 * qb:64 * w + 32 * qb + 32] = m.waves[w].v[qb][:32].view(np.float32)
+        outs.append((o, lse[:rows].copy()))
+    return outs, m
 
 
 def run_block(q, k, v, qblk, causal, scale=None, bf16=False, check_hazards=True):
     """q [Nq,128], k/v [Nkv,128] float arrays (rounded to the 16-bit type here).  Returns (o [rows,128] f32,
     lse [rows] f32, machine) for the rows of workgroup qblk that exist."""
-    Nq, Nkv = q.shape[0], k.shape[0]
-    scale = 128 ** -0.5 if scale is None else scale
-    qb_, kb_, vb_ = (to_bits(t, bf16) for t in (q, k, v))
-    pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)       # NaN guard bands around every matrix
-    bufs, bases = [], []
-    addr = 0x10000000
-    for b in (qb_, kb_, vb_):
-        arr = np.concatenate([pad, b.ravel(), pad]).view(np.uint8)
-        bufs.append((addr, arr))
-        bases.append(addr + pad.size * 2)
-        addr += (arr.size + 0xffff) & ~0xffff
-    wa = []
-    for w in range(4):
-        a = wave_args(w, qblk, Nq, Nkv, causal, scale, bases[0], bases[1], bases[2])
-        wa.append(a)
-    m = asm_emu.Machine(program(bf16), wa, gen.LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
-    for w, a in zip(m.waves, wa):
-        w.v[:24] = a["vregs"]
-    m.run()
-    rows = min(256, Nq - qblk * 256)
-    img = m.lds[:4 * 64 * gen.EPI_ROWB].reshape(256, gen.EPI_ROWB)[:, :256].copy().view(np.uint16)
-    o = from_bits(img, bf16)[:rows]
-    lse = np.empty(256, dtype=np.float32)
-    for w in range(4):
-        for qb in range(2):
-            lse[64 * w + 32 * qb:64 * w + 32 * qb + 32] = m.waves[w].v[qb][:32].view(np.float32)
-    return o, lse[:rows], m
+    outs, m = run_items([(q, k, v, qblk)], causal, scale=scale, bf16=bf16, check_hazards=check_hazards)
+    return outs[0][0], outs[0][1], m
 
 
 def dense(q, k, v, causal, scale=None, bf16=False, row0=0, pre=False):

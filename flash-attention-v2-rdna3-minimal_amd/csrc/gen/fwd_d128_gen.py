@@ -200,6 +200,12 @@ class Gen:
     # ------------------------------------------------------------------ MFMA lists
     def pv_mfmas(self, par, qb):
         out = []
+        if "chainpv" in self.opt:      # probe: the four k-steps of an accumulator back to back (C forwarded inside the pipe?)
+            for dt in range(4):
+                for ks in range(4):
+                    pfrag = SB(qb, par).sub(16 * (ks >> 1) + 8 * (ks & 1), 4)
+                    out.append(mk(self.mfma, OACC(qb, dt), self.vf(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
+            return out
         for ks in range(4):
             pfrag = SB(qb, par).sub(16 * (ks >> 1) + 8 * (ks & 1), 4)
             for dt in range(4):
@@ -213,9 +219,12 @@ class Gen:
             for qb in range(2):
                 for kvb in range(2):
                     out.append(mk(self.mfma, SB(qb, par).sub(16 * kvb, 16), KX, QX[qb], 0, tag="mfma"))
-        for ks in range(8):
-            for qb in range(2):
-                for kvb in range(2):
+        order = [(ks, qb, kvb) for ks in range(8) for qb in range(2) for kvb in range(2)]
+        if "chainqk" in self.opt:      # probe: pairs of k-steps of one accumulator back to back
+            order = [(2 * kp + j, qb, kvb) for kp in range(4) for qb in range(2) for kvb in range(2) for j in range(2)]
+        for (ks, qb, kvb) in order:
+            if True:
+                if True:
                     dst = SB(qb, par).sub(16 * kvb, 16)
                     c0 = CT[qb] if (self.ct and "ctc0" not in self.opt) else 0        # ctc0: timing probe (no reference in S)
                     out.append(mk(self.mfma, dst, self.kf(kvb, ks), self.qf(qb, ks), c0 if (ks == 0 and not self.pre) else dst, tag="mfma"))

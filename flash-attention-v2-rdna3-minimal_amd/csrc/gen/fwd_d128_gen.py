@@ -29,13 +29,21 @@ Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs (68 in the folded
   the two MFMA phases (all of PV(t) is in O, nothing of tile t+1 yet), so every value at the old reference is scaled once.
 Head / tail bodies are the same generator with streams switched off (and the tail masks switched on).
 
+Persistent workgroups.  The HIP shell runs the statement once per (head, q block) item of the workgroup's list.  Bodies
+ntwg-2 and ntwg-1 of an item stage the NEXT item's Q fragments and K(0), K(1), V(0) tiles (operands %22..%27; out-of-line
+code entered from the guarded staging groups), and the next statement skips its load phase (flag bit 0).
+
 Variants and developer options (Gen(..., opt=..., abl=..., syn=..., trace=...), `--opt` on the command line):
-    opt=pre      folded scale: Q * scale*log2e rounded once to the I/O dtype (pure_torch_ver.py:61), the running reference
-                 travels through a ninth k-step of QK^T as three 16-bit terms, no v_fma per score (fa2_fwd_d128_*_fold.inc)
-    abl=...      timing-only ablations of the fast bodies (streams left out; results are wrong)
+    opt=ct       folded scale (the fa2_fwd_d128_*_fold.inc bodies): Q * scale*log2e rounded once to the I/O dtype
+                 (pure_torch_ver.py:61); the running reference is the C operand of the first QK^T k-step (C tuples v[176:207],
+                 V^T k-steps 2-3 in a[224:255], K fragments in a 32-register pool with counted lgkmcnt waits: Gen.lds_waits)
+    opt=pre      the first form of the fold (usepre on the command line): the reference travels through a ninth k-step as three
+                 16-bit terms (68 MFMAs per body)
+    abl=...      timing-only ablations of the fast bodies (streams left out; results are wrong, cycle counts are not)
     syn=fma:5    timing probe: every gap of the fast bodies carries the same synthetic fillers (issue-cost measurements)
     trace=1..4   s_memtime sums (phases / barrier / whole block) returned through the LSE outputs
-    stagger=n    per-wave start skew (measured: no effect)
+    probes that measured no gain (profiles/r03_body_cycle_ablation.txt): stagger=, shift= (code placement), dmaw= (per-wave
+                 staging windows), vsplit=, w1=/w2= (scheduler weights), opt=vagpr / expsep / chainpv / chainqk / nofma / ctk64 / ctc0
 DESIGN.md section 3 has the measurements these options produced.
 """
 import os

@@ -571,6 +571,63 @@ def test_d128_asm_kernel_on_small_and_ragged_grids():
     assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
 
 
+PERSISTENT_SHAPES = [
+    # B, H, Nq, Nkv, BNHD: more items than CUs, so workgroups run several items and fetch across the item seam
+    (3, 11, 2304, 2304, False),     # 297 items, head count not a multiple of 8 (the plain item -> head mapping), 36 KV tiles
+    (5, 16, 1100, 1984, False),     # 400 items, ragged last q block (clamped rows), 31 KV tiles (ring parities flip at the seam)
+    (40, 8, 512, 64, False),        # 640 items of ONE KV tile: the staging body is a head body
+    (24, 8, 600, 100, True),        # 576 items of two tiles, ragged tail, BNHD strides
+    (2, 16, 4096, 4096, False),     # config 2 itself: two items per workgroup
+]
+
+
+@pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
+def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape, tmp_path):
+    """Non-causal D = 128 launches run persistent workgroups (grid = CUs; the last two bodies of an item fetch the next item's
+    Q fragments and first K / V tiles).  The arithmetic of an item does not depend on how it was scheduled, so the outputs must
+    be BIT-IDENTICAL to a child process that launches one workgroup per item (FA2_D128_PERSIST=0), and close to dense fp32."""
+    import os
+    import subprocess
+    import sys
+    B, H, Nq, Nkv, bnhd = shape
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rocwmma_fattn.FlashAttn import FlashAttentionFunction as F\n"
+        "B, H, Nq, Nkv, bnhd, out = %d, %d, %d, %d, %d, %r\n"
+        "g = torch.Generator(device='cpu').manual_seed(77)\n"
+        "q = torch.randn((B, H, Nq, 128), generator=g).half().cuda()\n"
+        "k = torch.randn((B, H, Nkv, 128), generator=g).half().cuda()\n"
+        "v = torch.randn((B, H, Nkv, 128), generator=g).half().cuda()\n"
+        "if bnhd:\n"
+        "    q, k, v = (t.transpose(1, 2).contiguous() for t in (q, k, v))\n"
+        "o = F.apply(q, k, v, None, False, None, bool(bnhd))\n"
+        "torch.cuda.synchronize()\n"
+        "np.save(out, o.cpu().view(torch.int16).numpy())\n"
+    ) % (os.path.join(root, "flash-attention-v2-rdna3-minimal_amd"), B, H, Nq, Nkv, int(bnhd), str(tmp_path / "o_%s.npy"))
+    outs = {}
+    for mode, env_extra in (("persist", {"FA2_FWD_ROWS": "256"}), ("single", {"FA2_FWD_ROWS": "256", "FA2_D128_PERSIST": "0"})):
+        res = subprocess.run([sys.executable, "-c", code.replace("o_%s.npy", "o_%s.npy" % mode)], capture_output=True, text=True,
+                             timeout=900, cwd=root, env=dict(os.environ, **env_extra))
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[mode] = np.load(tmp_path / ("o_%s.npy" % mode))
+    assert np.array_equal(outs["persist"], outs["single"])
+    g = torch.Generator(device="cpu").manual_seed(77)
+    q = torch.randn((B, H, Nq, 128), generator=g).half().to(_dev())
+    k = torch.randn((B, H, Nkv, 128), generator=g).half().to(_dev())
+    v = torch.randn((B, H, Nkv, 128), generator=g).half().to(_dev())
+    got = torch.from_numpy(outs["persist"]).view(torch.float16).to(_dev()).float()
+    if bnhd:
+        got = got.transpose(1, 2)
+    worst = 0.0
+    for b in range(0, B, max(1, B // 3)):
+        s = torch.matmul(q[b].float(), k[b].float().transpose(-1, -2)) * (128 ** -0.5)
+        truth = torch.matmul(torch.softmax(s, -1), v[b].float())
+        worst = max(worst, float((got[b] - truth).abs().max()))
+    assert worst <= 2e-3, worst
+
+
 def test_d128_fold_variant_in_a_child_process():
     """The opt-in folded-scale bodies of the D = 128 kernel (FA2_D128_FOLD=1: Q * scale*log2e rounded once to the I/O dtype, the
     running reference in the C operand of the first QK^T k-step).  The library reads the switch once per process, so the

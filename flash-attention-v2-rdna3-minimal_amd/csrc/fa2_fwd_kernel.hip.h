@@ -100,6 +100,11 @@ struct FwdParams {
     uint32_t k_bytes, v_bytes;           // addressable bytes of one head's K / V matrix
     int bh0, nbh;                        // this launch covers the flattened (batch*H + head) range [bh0, bh0 + nbh)
     int rows_hint;                       // host only: rows per workgroup the launcher must use (0 = its own heuristic)
+    // additive attention bias / boolean mask (BIAS kernels only; fa2_fwd_bias in include/fa2_gfx950.h): element (b,h,i,j) at
+    // bias + b*bs[0] + h*bs[1] + i*bs[2] + j in elements of the bias type, strides may be 0 (broadcast)
+    const void* bias;
+    int64_t bs[3];
+    int bias_kind;                       // 1: the I/O 16-bit dtype, 2: f32, 3: uint8 (non-zero = attend)
 };
 
 template <bool BF16>
@@ -210,7 +215,12 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // [128,256)): a 256-wide f32 O accumulator plus the Q fragments would not fit 256 VGPRs, so QK^T is
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 //
-template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB>
+// BIAS: scores = scale * Q K^T + bias[b, h, i, j] (or a boolean keep-mask) — the attention bias / mask argument the
+// reference only reserves (`mask` is accepted and ignored, FlashAttn.py:49, :74; README.md:45 lists it as to do).  Every tile
+// runs the generic step: the bias of tile+1 is fetched into registers at the top of the step (the loads fly under the
+// MFMAs), folded into the scores as s*c + bias*log2e after the masks, and the softmax then works in log2 units (c = 1).
+// A row whose every score is -inf (fully masked) produces O = 0 and lse = -inf.
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
@@ -314,7 +324,77 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
     }
-    const float c = p.c;
+    const float cs = p.c;                // factor of the raw Q.K^T product
+    const float c = BIAS ? 1.0f : p.c;   // factor still to be applied to a finished score (BIAS: already in log2 units)
+
+    // ---- attention bias (BIAS kernels): the 32 values of this lane's row in one KV tile, raw bits, in the register order
+    // of the two score accumulators (element 16*half + r <-> kv = kv0 + 32*half + (r&3) + 8(r>>2) + 4hi)
+    constexpr int NB = BIAS ? 32 : 1;
+    auto load_bias = [&](int tile, uint32_t (&raw)[QB][NB]) __attribute__((always_inline)) {
+        if constexpr (BIAS) {
+            const int kv0 = tile * kKvTile + 4 * hi;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
+                const int64_t row = b * p.bs[0] + h * p.bs[1] + (int64_t)qr * p.bs[2];
+                if (p.bias_kind == 1) {
+                    const uint16_t* bp = (const uint16_t*)p.bias + row;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+                        raw[qb][e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
+                    }
+                } else if (p.bias_kind == 2) {
+                    const uint32_t* bp = (const uint32_t*)p.bias + row;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+                        raw[qb][e] = kvi < p.Nkv ? bp[kvi] : 0u;
+                    }
+                } else {
+                    const uint8_t* bp = (const uint8_t*)p.bias + row;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+                        raw[qb][e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
+                    }
+                }
+            }
+        }
+    };
+    // s <- s * cs + bias * log2(e)   (boolean mask: s * cs where kept, -inf where not)
+    auto add_bias = [&](f32x16& s0, f32x16& s1, const uint32_t (&raw)[NB]) __attribute__((always_inline)) {
+        if constexpr (BIAS) {
+            constexpr float kLog2e = 1.4426950408889634f;
+            if (p.bias_kind == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] = raw[r] ? s0[r] * cs : -INFINITY;
+                    s1[r] = raw[16 + r] ? s1[r] * cs : -INFINITY;
+                }
+            } else if (p.bias_kind == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] = __builtin_fmaf(s0[r], cs, __uint_as_float(raw[r]) * kLog2e);
+                    s1[r] = __builtin_fmaf(s1[r], cs, __uint_as_float(raw[16 + r]) * kLog2e);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float b0, b1;
+                    if constexpr (BF16) {
+                        b0 = __uint_as_float(raw[r] << 16);
+                        b1 = __uint_as_float(raw[16 + r] << 16);
+                    } else {
+                        b0 = (float)__builtin_bit_cast(_Float16, (uint16_t)raw[r]);
+                        b1 = (float)__builtin_bit_cast(_Float16, (uint16_t)raw[16 + r]);
+                    }
+                    s0[r] = __builtin_fmaf(s0[r], cs, b0 * kLog2e);
+                    s1[r] = __builtin_fmaf(s1[r], cs, b1 * kLog2e);
+                }
+            }
+        }
+    };
 
     // Staging.  DMA form (head dims >= FA2_LDS_DMA_MIN_HD): buffer_load ... lds writes the tile image
     // directly — no staging VGPRs, no ds_write; wave-instruction i of this wave fills the 1 KiB of the
@@ -394,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
-    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], const uint32_t (&braw)[QB][NB]) __attribute__((always_inline)) {
         float mx[QB];
         bool grow = FA2_DEFER_THR < 0.f;
 #pragma unroll
@@ -421,6 +501,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
                     }
                 }
             }
+            add_bias(s0, s1, braw[qb]);
             float m = max3(s0[0], s1[0], s0[1]);
             m = max3(m, s1[1], s0[2]);
 #pragma unroll
@@ -434,7 +515,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const float m_new = __builtin_fmaxf(m_run[qb], mx[qb]);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+                float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+                if constexpr (BIAS) alpha = m_new == -INFINITY ? 1.0f : alpha;   // row fully masked so far: nothing accumulated
                 m_run[qb] = m_new;
                 l_run[qb] *= alpha;
 #pragma unroll
@@ -452,7 +534,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
         for (int qb = 0; qb < QB; ++qb) {
             f32x16& s0 = s[qb][0];
             f32x16& s1 = s[qb][1];
-            const float mc = m_run[qb] * c;
+            const float mc = (BIAS && m_run[qb] == -INFINITY) ? 0.f : m_run[qb] * c;   // fully masked so far: P = 2^(-inf - 0) = 0
             float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -510,6 +592,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #endif
         if (more2) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
         if (more1) load_v(tile + 1, PAR ^ 1);
+        uint32_t braw[QB][NB];
+        if (BIAS && next_w) load_bias(tile + 1, braw);
         if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
             u32x4 pf[QB][4];
@@ -519,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
         if (more2) write_k(PAR);
         if (more1) write_v(PAR ^ 1);
         __syncthreads();
-        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn);
+        if (next_w) finish_scores(tile + 1, std::integral_constant<bool, MODE != 1>{}, sn, braw);
     };
 
     // ---- prologue: K0, V0 -> buffers 0, K1 -> K buffer 1; scores of tile 0
@@ -530,9 +614,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     if (ntiles > 1) { load_k(1, 1); write_k(1); }
     __syncthreads();
     f32x16 sa[QB][2], sb[QB][2];
+    uint32_t braw0[QB][NB];
+    load_bias(0, braw0);
     qk(0, sa);
     __syncthreads();   // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us
-    finish_scores(0, std::true_type{}, sa);
+    finish_scores(0, std::true_type{}, sa, braw0);
 
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
@@ -542,6 +628,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
         const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
         n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
         n_fast = n_fast < 0 ? 0 : n_fast & ~1;
+        if (BIAS) n_fast = 0;                                              // the bias is applied by the generic step only
     }
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
@@ -572,7 +659,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
         __syncthreads();                                         // every wave is done reading the K / V buffers
         char* img = smem + wave * (32 * EROW);
         const float l_tot = half_swap_sum(l_run[0]);
-        const float inv_l = 1.0f / l_tot;
+        const float inv_l = (BIAS && !(l_tot > 0.f)) ? 0.f : 1.0f / l_tot;   // fully masked row: O = 0 (lse = -inf)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -604,7 +691,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float l_tot = half_swap_sum(l_run[qb]);
-        const float inv_l = 1.0f / l_tot;
+        const float inv_l = (BIAS && !(l_tot > 0.f)) ? 0.f : 1.0f / l_tot;
         if (qrow[qb] < p.Nq) {
             uint16_t* op = (uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qrow[qb] * p.os[2] + vcol0;
 #pragma unroll

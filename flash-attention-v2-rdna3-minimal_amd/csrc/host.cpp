@@ -89,7 +89,7 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
     return (int)main_heads;
 }
 
-template <int HD, bool BF16, bool CAUSAL, int NW, int QB>
+template <int HD, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
 int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
@@ -100,10 +100,17 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     p.nqblk = (p.Nq + NW * QB * 32 - 1) / (NW * QB * 32);
     if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
     const dim3 grid((unsigned)((int64_t)p.nbh * p.nqblk), HD / HDV);
-    constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, NW, QB>;
+    constexpr auto kern = fa2::fwd_kernel<HD, HDV, BF16, CAUSAL, NW, QB, BIAS>;
     if (int rc = set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+// Attention bias / boolean mask (fa2_fwd_bias): every head dim runs the generic HIP kernel as 4-wave, 128-row workgroups —
+// one wave per SIMD, so the 32 bias registers per tile come out of the 512-register budget instead of spilling.
+template <int HD, bool BF16>
+int launch_bias(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    return causal ? launch_shape<HD, BF16, true, 4, 1, true>(p, stream) : launch_shape<HD, BF16, false, 4, 1, true>(p, stream);
 }
 
 template <int HD, bool BF16, bool CAUSAL>
@@ -316,20 +323,28 @@ const char* fa2_error_string(int code) {
         case FA2_ERR_DTYPE: return "fa2: dtype must be FA2_DTYPE_F16 or FA2_DTYPE_BF16";
         case FA2_ERR_SCALE: return "fa2: scale must be finite";
         case FA2_ERR_GRID: return "fa2: B*H*ceil(Nq/256) exceeds the grid limit";
+        case FA2_ERR_BIAS: return "fa2: bias_kind must be FA2_BIAS_{NONE,IO_DTYPE,F32,BOOL} and bias strides >= 0";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.5 (D=128: hand-scheduled 4-wave 256x64 asm body; other head dims up to 512: 8-wave HIP kernels; mfma32x32x16, lds-dma; fwd+bwd)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.6 (D=128: hand-scheduled 4-wave 256x64 asm body; other head dims up to 512: 8-wave HIP kernels; mfma32x32x16, lds-dma; fwd+bwd; attention bias / mask)"; }
 
-int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
-            int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
-            const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
-            float scale, int causal, void* hip_stream) {
+static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+                    int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+                    const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+                    float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
     if (!q || !k || !v || !o || !lse || !q_strides || !k_strides || !v_strides || !o_strides || !lse_strides)
         return FA2_ERR_NULL_POINTER;
+    if (bias_kind != FA2_BIAS_NONE) {
+        if (bias_kind != FA2_BIAS_IO_DTYPE && bias_kind != FA2_BIAS_F32 && bias_kind != FA2_BIAS_BOOL) return FA2_ERR_BIAS;
+        if (!bias || !bias_strides) return FA2_ERR_NULL_POINTER;
+        if (bias_strides[0] < 0 || bias_strides[1] < 0 || bias_strides[2] < 0) return FA2_ERR_BIAS;
+        const uintptr_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1;
+        if (reinterpret_cast<uintptr_t>(bias) % esize) return FA2_ERR_ALIGNMENT;
+    }
     if (dtype != FA2_DTYPE_F16 && dtype != FA2_DTYPE_BF16) return FA2_ERR_DTYPE;
     if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
     const int HD = fa2_padded_head_dim(D);       // kernel head dim; columns [D, HD) are masked in-kernel
@@ -361,10 +376,23 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
     p.rows_hint = 0;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
+    p.bias = bias;
+    p.bias_kind = bias_kind;
+    for (int i = 0; i < 3; ++i) p.bs[i] = bias_kind != FA2_BIAS_NONE ? bias_strides[i] : 0;
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool bf16 = dtype == FA2_DTYPE_BF16;
+    if (bias_kind != FA2_BIAS_NONE) {
+        if ((int64_t)B * H * ((Nq + 127) / 128) > 0x7fffffffLL) return FA2_ERR_GRID;
+        switch (HD) {
+            case 64: return bf16 ? launch_bias<64, true>(p, causal != 0, stream) : launch_bias<64, false>(p, causal != 0, stream);
+            case 128: return bf16 ? launch_bias<128, true>(p, causal != 0, stream) : launch_bias<128, false>(p, causal != 0, stream);
+            case 256: return bf16 ? launch_bias<256, true>(p, causal != 0, stream) : launch_bias<256, false>(p, causal != 0, stream);
+            case 512: return bf16 ? launch_bias<512, true>(p, causal != 0, stream) : launch_bias<512, false>(p, causal != 0, stream);
+            default: return FA2_ERR_HEAD_DIM;
+        }
+    }
     switch (HD) {
         case 64: return bf16 ? launch<64, true>(p, causal != 0, stream) : launch<64, false>(p, causal != 0, stream);
         case 128: return bf16 ? launch<128, true>(p, causal != 0, stream) : launch<128, false>(p, causal != 0, stream);
@@ -372,6 +400,22 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
         case 512: return bf16 ? launch<512, true>(p, causal != 0, stream) : launch<512, false>(p, causal != 0, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
+}
+
+int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+            int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+            const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+            float scale, int causal, void* hip_stream) {
+    return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides, lse_strides,
+                    scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream);
+}
+
+int fa2_fwd_bias(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+                 int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+                 const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+                 float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
+    return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides, lse_strides,
+                    scale, causal, bias, bias_kind, bias_strides, hip_stream);
 }
 
 int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

@@ -22,7 +22,7 @@ import torch
 
 from . import _fa2_lib
 
-__all__ = ["FlashAttentionFunction", "flash_attn_wmma"]
+__all__ = ["FlashAttentionFunction", "flash_attn_wmma", "flash_attention"]
 
 
 class _FlashAttnWmma:
@@ -39,7 +39,14 @@ class _FlashAttnWmma:
         return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, causal, scale, permute_NH)
 
     @staticmethod
-    def forward_py(q, k, v, Br, Bc, causal, scale, permute_NH):
+    def forward_bias(q, k, v, bias, Br, Bc, causal, scale, permute_NH):
+        """forward() with an attention bias / mask (extension: the reference reserves `mask` but ignores it, FlashAttn.py:49, :74,
+        README.md:45).  `bias` broadcasts against [B, H, Nq, Nkv] like torch SDPA's attn_mask: bool = keep-mask, float = additive.
+        Same 6-tensor return as forward()."""
+        return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, causal, scale, permute_NH, bias=bias)
+
+    @staticmethod
+    def forward_py(q, k, v, Br, Bc, causal, scale, permute_NH, bias=None):
         """Returns [O_fwd, q_pad, k_pad, v_pad, O, L] like forward_fp16/forward_bf16 (kernel_fp16.cu:744-876).
         O and L keep the reference's shapes — rows padded to a multiple of Br with a zero tail, O_fwd a view into
         O (kernel_fp16.cu:761, :793-796, :865-875) — but nothing is COPIED to get there: the gfx950 kernels mask
@@ -108,12 +115,18 @@ class _FlashAttnWmma:
         dev = q.device.index
         args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
                 b, h, n, n_kv, d_kernel, s3(q_pad), s3(k_pad), s3(v_pad), s3(O),
-                _fa2_lib.strides2(h * (n + nq_pad), n + nq_pad), float(scale), 1 if causal else 0, _raw_stream(dev))
+                _fa2_lib.strides2(h * (n + nq_pad), n + nq_pad), float(scale), 1 if causal else 0)
+        fn = lib.fa2_fwd
+        if bias is not None:
+            bias_t, kind, bstr = _prepare_bias(bias, b, h, n, n_kv, q_pad.dtype, q.device)
+            args += (bias_t.data_ptr(), kind, _fa2_lib.strides3(*bstr))
+            fn = lib.fa2_fwd_bias
+        args += (_raw_stream(dev),)
         if dev != _current_device():
             with torch.cuda.device(dev):
-                rc = lib.fa2_fwd(*args)
+                rc = fn(*args)
         else:
-            rc = lib.fa2_fwd(*args)
+            rc = fn(*args)
         if rc:
             _fa2_lib.check(rc)
 
@@ -206,6 +219,39 @@ def _strides_ok(t):
     return s3 == 1 and not ((s0 | s1 | s2) & 7) and not (t.data_ptr() & 15)
 
 
+def _prepare_bias(bias, b, h, n, n_kv, io_dtype, device):
+    """Attention bias / mask -> (tensor kept alive by the caller, bias_kind, element strides (batch, head, row)) for fa2_fwd_bias.
+    Broadcasting follows torch.nn.functional.scaled_dot_product_attention: a 2-, 3- or 4-D tensor is aligned on the right
+    against [B, H, Nq, Nkv] and every dimension is 1 or full size; broadcast dimensions become stride 0 — nothing is expanded
+    in memory unless the Nkv dimension itself is broadcast or strided."""
+    if not torch.is_tensor(bias) or bias.dim() < 2 or bias.dim() > 4:
+        raise RuntimeError("fa2: the attention mask must be a 2-, 3- or 4-D tensor broadcastable to [B, H, Nq, Nkv]")
+    if bias.device != device:
+        raise RuntimeError("fa2: the attention mask must be on the device of q")
+    m = bias
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    for size, full in zip(m.shape, (b, h, n, n_kv)):
+        if size != 1 and size != full:
+            raise RuntimeError("fa2: attention mask of shape %s does not broadcast to %s" % (tuple(bias.shape), (b, h, n, n_kv)))
+    if m.dtype == torch.bool:
+        kind = _fa2_lib.FA2_BIAS_BOOL
+    elif m.dtype == torch.float32:
+        kind = _fa2_lib.FA2_BIAS_F32
+    else:
+        kind = _fa2_lib.FA2_BIAS_IO_DTYPE
+        if m.dtype != io_dtype:
+            m = m.to(io_dtype)
+    if m.size(3) != n_kv:
+        m = m.expand(m.size(0), m.size(1), m.size(2), n_kv).contiguous()
+    elif m.stride(3) != 1 and n_kv > 1:
+        m = m.contiguous()
+    if kind == _fa2_lib.FA2_BIAS_BOOL:
+        m = m.view(torch.uint8)
+    strides = tuple(m.stride(i) if m.size(i) > 1 else 0 for i in range(3))
+    return m, kind, strides
+
+
 def _kernel_ready(t):
     """kernel_fp16.cu:780-787 makes a tensor contiguous iff its last stride is not 1; the gfx950
     kernel additionally wants 16-byte aligned rows (strides multiple of 8 elements)."""
@@ -272,3 +318,21 @@ def _apply(q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, *
 
 
 FlashAttentionFunction.apply = staticmethod(_apply)
+
+
+def flash_attention(q, k, v, mask=None, causal=False, scale=None, BNHD_fmt=False):
+    """Forward attention that HONOURS `mask` — the extension the reference lists as to do (README.md:45; its
+    FlashAttentionFunction accepts the argument and ignores it, FlashAttn.py:49, :74, and `FlashAttentionFunction.apply` here
+    keeps doing exactly that so that existing call sites see no change).  `mask` follows
+    torch.nn.functional.scaled_dot_product_attention(attn_mask=...): broadcastable to [B, H, Nq, Nkv]; bool = True where
+    attention is allowed, float = added to the scaled scores.  mask=None is FlashAttentionFunction.apply.  Rows whose every
+    position is masked return zeros.  Forward only: inputs that require a gradient are refused when a mask is given."""
+    if mask is None:
+        return FlashAttentionFunction.apply(q, k, v, None, causal, scale, BNHD_fmt)
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        raise NotImplementedError("fa2: no backward through a masked / biased forward (the backward kernels recompute unbiased scores)")
+    D = q.shape[3]
+    if scale is None:
+        scale = D ** -0.5
+    Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67
+    return flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)[0]

@@ -19,6 +19,7 @@ _OVERRIDE = os.environ.get("FA2_GFX950_LIB")      # developer A/B: load this bui
 
 FA2_DTYPE_F16 = 0
 FA2_DTYPE_BF16 = 1
+FA2_BIAS_NONE, FA2_BIAS_IO_DTYPE, FA2_BIAS_F32, FA2_BIAS_BOOL = 0, 1, 2, 3     # bias_kind of fa2_fwd_bias
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _FWD_ARGTYPES = [
@@ -27,6 +28,8 @@ _FWD_ARGTYPES = [
     _i64p, _i64p, _i64p, _i64p, _i64p,                                                     # strides
     ctypes.c_float, ctypes.c_int, ctypes.c_void_p,                                         # scale causal stream
 ]
+
+_FWD_BIAS_ARGTYPES = [ctypes.c_int] + _FWD_ARGTYPES[:-1] + [ctypes.c_void_p, ctypes.c_int, _i64p, ctypes.c_void_p]  # ... bias kind strides stream
 
 _BWD_ARGTYPES = [ctypes.c_void_p] * 10 + [ctypes.c_int] * 5 + [_i64p] * 9 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
 
@@ -38,6 +41,7 @@ SYMBOLS = {
     "fa2_fwd_f16": (ctypes.c_int, _FWD_ARGTYPES),
     "fa2_fwd_bf16": (ctypes.c_int, _FWD_ARGTYPES),
     "fa2_fwd": (ctypes.c_int, [ctypes.c_int] + _FWD_ARGTYPES),
+    "fa2_fwd_bias": (ctypes.c_int, _FWD_BIAS_ARGTYPES),
     "fa2_supported_head_dims": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
     "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -11,12 +11,14 @@ operator with BNHD_fmt=True, the zero-copy layout of rocwmma_fattn/kernel_fp16.c
     out = attention_bnhd(q, k, v, heads)          # q [B, Nq, H*D], k/v [B, Nkv, H*D] -> [B, Nq, H*D]
     install_comfyui()                             # optional: patch comfy.ldm.modules.attention.optimized_attention
 
-Masks are not supported by the kernels (the reference ignores its `mask` argument too, FlashAttn.py:49/:74):
-a call with a mask falls through to the host's original attention function.
+Masks: the reference ignores its `mask` argument (FlashAttn.py:49/:74; README.md:45 lists it as to do), so its hooks have to
+send masked calls back to the host's own attention.  Here a mask goes to the kernels (`flash_attention`, C-ABI fa2_fwd_bias):
+bool = keep-mask, float = additive bias, in the shapes the SD hosts use — [Nq, Nkv], [B, Nq, Nkv] (batch first, as ComfyUI's
+attention functions read a 3-D mask) or [B, H | 1, Nq, Nkv].
 """
 import torch
 
-from .FlashAttn import FlashAttentionFunction
+from .FlashAttn import FlashAttentionFunction, flash_attention
 
 __all__ = ["attention_bnhd", "install_comfyui"]
 
@@ -25,19 +27,25 @@ _MAX_HEAD_DIM = 512      # the forward kernels reach 512 (SD VAE attention: one 
 
 def attention_bnhd(q, k, v, heads, mask=None, causal=False, scale=None, fallback=None):
     """q [B, Nq, heads*D], k, v [B, Nkv, heads*D] (any float dtype; non-half inputs run and return as bf16,
-    host.cpp:42-45) -> [B, Nq, heads*D].  `fallback(q, k, v, heads, mask)` is used when a mask is given or the
-    head dim exceeds the largest kernel; without a fallback those cases raise."""
+    host.cpp:42-45) -> [B, Nq, heads*D].  `mask`: None, or a bool keep-mask / additive float bias of shape [Nq, Nkv],
+    [B, Nq, Nkv] or [B, H | 1, Nq, Nkv].  `fallback(q, k, v, heads, mask)` is used when the head dim exceeds the largest
+    kernel; without a fallback that case raises."""
     b, nq, inner = q.shape
     d = inner // heads
-    if mask is not None or d > _MAX_HEAD_DIM or inner != heads * d:
+    if d > _MAX_HEAD_DIM or inner != heads * d:
         if fallback is None:
-            raise NotImplementedError("fa2 sd_hook: attention masks / head dims > %d need the host's own attention" % _MAX_HEAD_DIM)
+            raise NotImplementedError("fa2 sd_hook: head dims > %d need the host's own attention" % _MAX_HEAD_DIM)
         return fallback(q, k, v, heads, mask)
+    if mask is not None and mask.dim() == 3:
+        mask = mask.unsqueeze(1)                      # [B, Nq, Nkv] -> [B, 1, Nq, Nkv] (comfy.ldm.modules.attention reads it so)
     out_dtype = q.dtype
     q4 = q.reshape(b, nq, heads, d)
     k4 = k.reshape(b, k.shape[1], heads, d)
     v4 = v.reshape(b, v.shape[1], heads, d)
-    o = FlashAttentionFunction.apply(q4, k4, v4, None, causal, scale, True)      # BNHD_fmt=True
+    if mask is not None:
+        o = flash_attention(q4, k4, v4, mask, causal, scale, True)
+    else:
+        o = FlashAttentionFunction.apply(q4, k4, v4, None, causal, scale, True)      # BNHD_fmt=True
     o = o.reshape(b, nq, inner)
     return o if o.dtype == out_dtype or out_dtype not in (torch.float16, torch.bfloat16) else o.to(out_dtype)
 

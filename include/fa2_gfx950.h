@@ -64,6 +64,13 @@ extern "C" {
 #define FA2_ERR_DTYPE         -5
 #define FA2_ERR_SCALE         -6   /* scale is NaN/inf */
 #define FA2_ERR_GRID          -7   /* B*H*ceil(Nq/256) exceeds the 2^31-1 grid limit */
+#define FA2_ERR_BIAS          -8   /* unknown bias_kind or a negative bias stride */
+
+/* bias_kind codes for fa2_fwd_bias */
+#define FA2_BIAS_NONE     0   /* no bias: the call is fa2_fwd */
+#define FA2_BIAS_IO_DTYPE 1   /* additive bias in the I/O dtype (fp16 / bf16, as `dtype` says) */
+#define FA2_BIAS_F32      2   /* additive bias, f32 */
+#define FA2_BIAS_BOOL     3   /* keep-mask, one byte per element: non-zero = attend, zero = masked (score -> -inf) */
 
 /* Forward attention, fp16 I/O.  Replaces forward_fp16 (rocwmma_fattn/host.cpp:24-28). */
 int fa2_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -89,6 +96,29 @@ int fa2_fwd(int dtype,
             const int64_t v_strides[3], const int64_t o_strides[3],
             const int64_t lse_strides[2],
             float scale, int causal, void* hip_stream);
+
+/*
+ * Forward attention with an attention bias / mask: S = (Q K^T) * scale + bias[b, h, i, j] before the softmax (additive kinds), or
+ * masked to -inf where the boolean mask is zero — the semantics of torch's scaled_dot_product_attention(attn_mask=...).
+ * This is the `mask` argument the reference reserves but never implements: FlashAttentionFunction.forward accepts and
+ * ignores it (rocwmma_fattn/FlashAttn.py:49, :74), README.md:45 lists it as to do; SURVEY section 8 row f4.
+ *   bias         : element (b,h,i,j) at bias + b*bias_strides[0] + h*bias_strides[1] + i*bias_strides[2] + j, in ELEMENTS of the
+ *                  bias type (bias_kind); a stride of 0 broadcasts that dimension; the last (Nkv) dimension is contiguous.
+ *                  The pointer must be aligned to the element size; no other alignment is required (Nkv = 77 rows are fine).
+ *   causal       : may be combined with the bias (both masks apply).
+ *   fully masked rows (every score -inf) produce O = 0 and lse = -inf (torch's math path returns NaN there).
+ * Runs the compiler-scheduled HIP kernels as 4-wave, 128-row workgroups for every head dim (the hand-scheduled D = 128 body
+ * has no bias stream).  Forward only: there is no backward through a biased forward (fa2_bwd recomputes unbiased scores).
+ */
+int fa2_fwd_bias(int dtype,
+                 const void* q, const void* k, const void* v, void* o, float* lse,
+                 int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3],
+                 const int64_t v_strides[3], const int64_t o_strides[3],
+                 const int64_t lse_strides[2],
+                 float scale, int causal,
+                 const void* bias, int bias_kind, const int64_t bias_strides[3],
+                 void* hip_stream);
 
 /*
  * Backward attention: dQ, dK, dV from dO.  Replaces backward_fp16 / backward_bf16 (rocwmma_fattn/host.cpp:24-28,

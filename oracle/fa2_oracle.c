@@ -122,10 +122,11 @@ float fa2_oracle_bf16_to_f32(uint16_t h) { return bf16_to_f32(h); }
  * pure_torch_ver.py:24 defaults 64/256; the gfx950 kernel: 32 rows per wave / 64).
  * Returns 0, or -1 on bad arguments / allocation failure.
  */
-int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse,
-                   int B, int H, int Nq, int Nkv, int D,
-                   const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* ls,
-                   float scale, int causal, int Br, int Bc, int flags, int nthreads) {
+static int fwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse,
+                    int B, int H, int Nq, int Nkv, int D,
+                    const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* ls,
+                    float scale, int causal, int Br, int Bc, int flags, int nthreads,
+                    const float* bias, const int64_t* bs) {
     if (!q || !k || !v || !o || !lse || B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1 || Br < 1 || Bc < 1) return -1;
     if (dtype != FA2_ORACLE_DTYPE_F16 && dtype != FA2_ORACLE_DTYPE_BF16) return -1;
     const cvt_t cv = {dtype, (flags & FA2_ORACLE_BF16_TRUNC) != 0};
@@ -202,6 +203,8 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
 #pragma omp simd reduction(+ : acc)
                                 for (int d = 0; d < D; ++d) acc += qi[d] * kj[d];
                                 float s = acc * cs;
+                                /* attention bias (fa2_fwd_bias): natural-log units -> log2 domain, added to the scaled product */
+                                if (bias) s += bias[b * bs[0] + h * bs[1] + (int64_t)(r0 + i) * bs[2] + c0 + j] * 1.4426950408889634f;
                                 if (round_s) s = round16(cv, s);
                                 if (causal && c0 + j > r0 + i) s = -INFINITY; /* kernel_fp16.cu:403-410 */
                                 Si[j] = s;
@@ -237,7 +240,7 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
                     uint16_t* ob = o + b * os[0] + h * os[1];
                     float* lb = lse + b * ls[0] + h * ls[1];
                     for (int i = 0; i < rows; ++i) {
-                        const float inv = 1.0f / l[i];
+                        const float inv = l[i] > 0.f ? 1.0f / l[i] : 0.f; /* fully masked row (bias only): O = 0, L = -inf */
                         for (int d = 0; d < D; ++d) ob[(int64_t)(r0 + i) * os[2] + d] = store16(cv, O[(size_t)i * D + d] * inv);
                         lb[r0 + i] = m[i] + log2f(l[i]);
                     }
@@ -248,6 +251,29 @@ int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
     }
     free(kf_all); free(vf_all);
     return failed ? -1 : 0;
+}
+
+int fa2_oracle_fwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse,
+                   int B, int H, int Nq, int Nkv, int D,
+                   const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* ls,
+                   float scale, int causal, int Br, int Bc, int flags, int nthreads) {
+    return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, qs, ks, vs, os, ls, scale, causal, Br, Bc, flags, nthreads, NULL, NULL);
+}
+
+/*
+ * Forward with an additive attention bias (the checker of fa2_fwd_bias, include/fa2_gfx950.h): S = Q K^T * scale + bias, then the
+ * same recurrence.  The reference has no counterpart to pin this against — its `mask` argument is accepted and ignored
+ * (rocwmma_fattn/FlashAttn.py:49, :74; README.md:45 "to do") — so this entry is pinned on dense float64 attention only
+ * (tests/test_oracle.py).  bias: f32, element (b,h,i,j) at bias + b*bs[0] + h*bs[1] + i*bs[2] + j (strides may be 0); -inf masks a
+ * position; a fully masked row yields O = 0, L = -inf.
+ */
+int fa2_oracle_fwd_bias(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse,
+                        int B, int H, int Nq, int Nkv, int D,
+                        const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* ls,
+                        float scale, int causal, int Br, int Bc, int flags, int nthreads,
+                        const float* bias, const int64_t* bs) {
+    if (!bias || !bs) return -1;
+    return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, qs, ks, vs, os, ls, scale, causal, Br, Bc, flags, nthreads, bias, bs);
 }
 
 /*

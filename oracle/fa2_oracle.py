@@ -56,6 +56,8 @@ def _load():
         lib.fa2_oracle_fwd.restype = ctypes.c_int
         lib.fa2_oracle_fwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [i64p] * 5 + \
             [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.fa2_oracle_fwd_bias.restype = ctypes.c_int
+        lib.fa2_oracle_fwd_bias.argtypes = lib.fa2_oracle_fwd.argtypes + [ctypes.c_void_p, i64p]
         lib.fa2_oracle_bwd.restype = ctypes.c_int
         lib.fa2_oracle_bwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [i64p] * 9 + \
             [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -101,8 +103,9 @@ def f32_to_bits(x, dtype):
 
 # ---------------------------------------------------------------- C oracle
 
-def fwd_c(q_bits, k_bits, v_bits, dtype, causal=False, scale=None, Br=32, Bc=64, flags=0, nthreads=0):
+def fwd_c(q_bits, k_bits, v_bits, dtype, causal=False, scale=None, Br=32, Bc=64, flags=0, nthreads=0, bias=None):
     """q_bits/k_bits/v_bits: uint16 arrays [B,H,N,D] holding fp16 or bf16 bit patterns (C-contiguous).
+    bias: None, or a float array broadcastable to [B,H,Nq,Nkv] added to the scaled scores (-inf masks a position).
     Returns (o_bits uint16 [B,H,Nq,D], lse float32 [B,H,Nq] in the log2 domain)."""
     lib = _load()
     q = np.ascontiguousarray(q_bits, dtype=np.uint16)
@@ -119,9 +122,14 @@ def fwd_c(q_bits, k_bits, v_bits, dtype, causal=False, scale=None, Br=32, Bc=64,
     def s3(n):
         return (ctypes.c_int64 * 3)(H * n * D, n * D, D)
 
-    rc = lib.fa2_oracle_fwd(dtype, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, lse.ctypes.data,
-                            B, H, Nq, Nkv, D, s3(Nq), s3(Nkv), s3(Nkv), s3(Nq), (ctypes.c_int64 * 2)(H * Nq, Nq),
-                            float(scale), int(bool(causal)), int(Br), int(Bc), int(flags), int(nthreads))
+    args = (dtype, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, lse.ctypes.data,
+            B, H, Nq, Nkv, D, s3(Nq), s3(Nkv), s3(Nkv), s3(Nq), (ctypes.c_int64 * 2)(H * Nq, Nq),
+            float(scale), int(bool(causal)), int(Br), int(Bc), int(flags), int(nthreads))
+    if bias is None:
+        rc = lib.fa2_oracle_fwd(*args)
+    else:
+        bf = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, dtype=np.float32), (B, H, Nq, Nkv)))
+        rc = lib.fa2_oracle_fwd_bias(*args, bf.ctypes.data, (ctypes.c_int64 * 3)(H * Nq * Nkv, Nq * Nkv, Nkv))
     if rc != 0:
         raise RuntimeError("fa2_oracle_fwd failed (%d)" % rc)
     return o, lse
@@ -177,22 +185,28 @@ def bwd_numpy(q, k, v, do, causal=False, scale=None):
 
 # ---------------------------------------------------------------- numpy restatements
 
-def fwd_numpy(q, k, v, causal=False, scale=None):
-    """Dense float64 attention: softmax(Q K^T * scale [+ causal mask]) V and the log2-domain LSE
-    (= the quantity kernel_fp16.cu:541-542 stores).  q,k,v: float arrays [B,H,N,D]."""
+def fwd_numpy(q, k, v, causal=False, scale=None, bias=None):
+    """Dense float64 attention: softmax(Q K^T * scale [+ bias] [+ causal mask]) V and the log2-domain LSE
+    (= the quantity kernel_fp16.cu:541-542 stores).  q,k,v: float arrays [B,H,N,D]; bias broadcastable to [B,H,Nq,Nkv]
+    (-inf masks; fully masked rows return O = 0, LSE = -inf)."""
     q, k, v = (np.asarray(t, dtype=np.float64) for t in (q, k, v))
     D = q.shape[-1]
     if scale is None:
         scale = D ** -0.5
     s = np.einsum("bhid,bhjd->bhij", q, k) * (scale * LOG2E)
+    if bias is not None:
+        s = s + np.asarray(bias, dtype=np.float64) * LOG2E
     if causal:
         nq, nk = s.shape[-2:]
         s = np.where(np.triu(np.ones((nq, nk), dtype=bool), 1), -np.inf, s)  # column > row masked
     m = s.max(-1, keepdims=True)
-    p = np.exp2(s - m)
-    l = p.sum(-1, keepdims=True)
-    o = np.einsum("bhij,bhjd->bhid", p / l, v)
-    return o, (m + np.log2(l))[..., 0]
+    dead = ~np.isfinite(m)                                                   # fully masked rows (bias only)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = np.exp2(s - np.where(dead, 0.0, m))
+        l = p.sum(-1, keepdims=True)
+        o = np.einsum("bhij,bhjd->bhid", p / np.where(dead, 1.0, l), v)
+        lse = (m + np.log2(l))[..., 0]
+    return o, lse
 
 
 def fwd_numpy_tiled(q, k, v, causal=False, Br=64, Bc=256, dtype=np.float16):

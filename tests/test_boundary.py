@@ -94,6 +94,58 @@ def test_validation_codes_without_a_gpu():
         == c["FA2_ERR_HEAD_DIM"]
 
 
+def test_bias_entry_validation_codes_without_a_gpu():
+    """fa2_fwd_bias (the attention bias / mask extension) rejects bad bias arguments before any launch."""
+    lib = _fa2_lib.load()
+    c = _codes()
+    buf = ctypes.create_string_buffer(8192 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    s3 = _fa2_lib.strides3(2 * 16 * 64, 16 * 64, 64)
+    s2 = _fa2_lib.strides2(32, 16)
+    b3 = _fa2_lib.strides3(0, 0, 16)
+
+    def call(bias=p, kind=c["FA2_BIAS_F32"], bs=b3, q=p, D=64):
+        return lib.fa2_fwd_bias(0, q, p, p, p, p, 1, 2, 16, 16, D, s3, s3, s3, s3, s2, 0.125, 0, bias, kind, bs, None)
+
+    assert call(kind=9) == c["FA2_ERR_BIAS"]
+    assert call(bias=None) == c["FA2_ERR_NULL_POINTER"] and call(bs=None) == c["FA2_ERR_NULL_POINTER"]
+    assert call(bs=_fa2_lib.strides3(0, -16, 16)) == c["FA2_ERR_BIAS"]
+    assert call(bias=p + 2) == c["FA2_ERR_ALIGNMENT"]                                   # f32 bias on a 2-byte boundary
+    assert call(bias=p + 1, kind=c["FA2_BIAS_IO_DTYPE"]) == c["FA2_ERR_ALIGNMENT"]
+    assert call(q=None) == c["FA2_ERR_NULL_POINTER"] and call(D=44) == c["FA2_ERR_HEAD_DIM"]   # the fa2_fwd checks still apply
+    assert (c["FA2_BIAS_NONE"], c["FA2_BIAS_IO_DTYPE"], c["FA2_BIAS_F32"], c["FA2_BIAS_BOOL"]) == (
+        _fa2_lib.FA2_BIAS_NONE, _fa2_lib.FA2_BIAS_IO_DTYPE, _fa2_lib.FA2_BIAS_F32, _fa2_lib.FA2_BIAS_BOOL)
+
+
+def test_mask_preparation_is_broadcast_without_copies():
+    """Host logic of flash_attention(mask=...): right-aligned broadcasting as in torch SDPA, broadcast dimensions become
+    stride 0 (the tensor is not expanded in memory), bool -> one byte per element, foreign float dtypes -> the I/O dtype."""
+    from rocwmma_fattn.FlashAttn import _prepare_bias, flash_attention
+    B, H, Nq, Nkv = 2, 3, 10, 77
+    dev = torch.device("cpu")
+    m = torch.zeros((B, 1, Nq, Nkv), dtype=torch.bool)
+    t, kind, st = _prepare_bias(m, B, H, Nq, Nkv, torch.float16, dev)
+    assert kind == _fa2_lib.FA2_BIAS_BOOL and t.dtype == torch.uint8 and t.data_ptr() == m.data_ptr() and st == (Nq * Nkv, 0, Nkv)
+    m = torch.zeros((Nq, Nkv), dtype=torch.float32)
+    t, kind, st = _prepare_bias(m, B, H, Nq, Nkv, torch.bfloat16, dev)
+    assert kind == _fa2_lib.FA2_BIAS_F32 and t.data_ptr() == m.data_ptr() and st == (0, 0, Nkv)
+    m = torch.zeros((H, 1, Nkv), dtype=torch.float16)                                   # 3-D: [H, 1, Nkv] against [B, H, Nq, Nkv]
+    t, kind, st = _prepare_bias(m, B, H, Nq, Nkv, torch.float16, dev)
+    assert kind == _fa2_lib.FA2_BIAS_IO_DTYPE and t.data_ptr() == m.data_ptr() and st == (0, Nkv, 0)
+    t, kind, st = _prepare_bias(torch.zeros((B, H, Nq, Nkv), dtype=torch.float64), B, H, Nq, Nkv, torch.bfloat16, dev)
+    assert kind == _fa2_lib.FA2_BIAS_IO_DTYPE and t.dtype == torch.bfloat16 and st == (H * Nq * Nkv, Nq * Nkv, Nkv)
+    t, kind, st = _prepare_bias(torch.zeros((B, H, Nq, 1)), B, H, Nq, Nkv, torch.float16, dev)   # broadcast over Nkv: expanded
+    assert t.shape == (B, H, Nq, Nkv) and t.stride(3) == 1
+    t, kind, st = _prepare_bias(torch.zeros((B, H, Nq, 2 * Nkv))[..., ::2], B, H, Nq, Nkv, torch.float16, dev)
+    assert t.stride(3) == 1
+    for bad in (torch.zeros((B, H, Nq, Nkv + 1)), torch.zeros((5, Nq, Nkv)), torch.zeros(Nkv), torch.zeros((1, 1, 1, 1, Nkv))):
+        with pytest.raises(RuntimeError):
+            _prepare_bias(bad, B, H, Nq, Nkv, torch.float16, dev)
+    q = torch.rand(1, 2, 16, 64, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="ROCm device"):                              # no CPU path for the masked call either
+        flash_attention(q, q, q, torch.zeros(16, 16, dtype=torch.bool))
+
+
 def test_operator_surface_matches_reference():
     # reference: rocwmma_fattn/FlashAttn.py:45-49 forward(ctx, q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, **kwargs)
     sig = inspect.signature(FlashAttentionFunction.forward)

@@ -161,6 +161,37 @@ def test_edge_shapes_against_dense(shape, nkv):
     assert np.abs(lse - lse_true).max() <= LSE_TOL
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_bias_against_dense(dt, causal):
+    """The bias entry of the oracle (checker of fa2_fwd_bias; the reference ignores its `mask` argument, so there is no golden
+    vector to pin it on): additive values, -inf positions, broadcast shapes, a fully masked row, tiling invariance."""
+    rng = np.random.default_rng(20 + dt)
+    B, H, Nq, Nkv, D = 2, 3, 70, 77, 40
+    q = _rand_bits(rng, (B, H, Nq, D), dt, signed=True)
+    k, v = (_rand_bits(rng, (B, H, Nkv, D), dt, signed=True) for _ in range(2))
+    for bshape in ((B, H, Nq, Nkv), (B, 1, Nq, Nkv), (1, 1, 1, Nkv), (Nq, Nkv)):
+        bias = rng.standard_normal(bshape).astype(np.float32)
+        bias[..., 60:] = -np.inf
+        bias.reshape(-1, Nkv)[0] = -np.inf                     # one fully masked row (a whole batch for the [1,1,1,Nkv] shape)
+        if bshape == (1, 1, 1, Nkv):
+            bias = rng.standard_normal(bshape).astype(np.float32)
+            bias[..., 60:] = -np.inf
+        o, lse = fo.fwd_c(q, k, v, dt, causal, bias=bias)
+        o_true, lse_true = fo.fwd_numpy(_f32(q, dt), _f32(k, dt), _f32(v, dt), causal, bias=bias)
+        dead = np.isneginf(lse_true)
+        assert (np.isneginf(lse) == dead).all() and (_f32(o, dt)[dead] == 0).all() and (o_true[dead] == 0).all()
+        assert np.all(np.abs(_f32(o, dt) - o_true) <= ATOL[dt] + RTOL[dt] * np.abs(o_true))
+        assert np.abs(lse[~dead] - lse_true[~dead]).max() <= LSE_TOL
+        o2, lse2 = fo.fwd_c(q, k, v, dt, causal, Br=7, Bc=13, bias=bias)
+        assert np.all(np.abs(_f32(o2, dt) - _f32(o, dt)) <= ATOL[dt] + RTOL[dt] * np.abs(_f32(o, dt)))
+        assert np.abs(lse2[~dead] - lse[~dead]).max() <= 1e-4
+    zero = np.zeros((1, 1, Nq, Nkv), dtype=np.float32)         # a zero bias is the unbiased entry, bit for bit
+    o0, l0 = fo.fwd_c(q, k, v, dt, causal, bias=zero)
+    o1, l1 = fo.fwd_c(q, k, v, dt, causal)
+    assert np.array_equal(o0, o1) and np.array_equal(l0, l1)
+
+
 def test_causal_first_row_and_constant_v():
     rng = np.random.default_rng(4)
     q, k = (_rand_bits(rng, (1, 2, 70, 64), 0, signed=True) for _ in range(2))

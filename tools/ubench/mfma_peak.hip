@@ -98,6 +98,61 @@ static double run(const u32x4* d_ops, float* d_out, int n_cu, double settle_s, i
     return flops / per_launch_s / 1e12;
 }
 
+// Same loop with v_mfma_f32_16x16x32_f16 (half the FLOPs per instruction, 16 instead of 32 pipe cycles; per FLOP it reads twice the
+// A/B operand bytes and moves half the accumulator bytes of the 32x32x16 form): is the other MFMA shape cheaper in energy?
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void peak_kernel_16(const u32x4* __restrict__ operands, float* __restrict__ out, int iters) {
+    const int tid = threadIdx.x;
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = operands[(i * 2 + 0) * 512 + tid];
+        b[i] = operands[(i * 2 + 1) * 512 + tid];
+    }
+    f32x4 acc[8] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(i + r) & 3]), __builtin_bit_cast(f16x8, b[i & 3]), acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[blockIdx.x * THREADS + tid] = s;
+}
+
+template <int THREADS>
+static double run16(const u32x4* d_ops, float* d_out, int n_cu, double settle_s, int timed_launches, double* out_ms) {
+    const int waves_per_simd = THREADS / 256;
+    const int iters = 2 * kMfmaPerSimd / waves_per_simd / 32;   // same FLOPs per launch as run<>
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    float ms = 0.f;
+    do {
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((peak_kernel_16<THREADS>), dim3(n_cu), dim3(THREADS), 0, 0, d_ops, d_out, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } while (ms < settle_s * 1e3);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < timed_launches; ++i) hipLaunchKernelGGL((peak_kernel_16<THREADS>), dim3(n_cu), dim3(THREADS), 0, 0, d_ops, d_out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipGetLastError());
+    const double per_launch_s = ms * 1e-3 / timed_launches;
+    const double flops = 2.0 * 32 * 32 * 16 * (double)kMfmaPerSimd * 4 * n_cu;
+    *out_ms = per_launch_s * 1e3;
+    return flops / per_launch_s / 1e12;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -132,6 +187,9 @@ int main() {
     const double bf16_w1 = run<true, 256>(d_bf16, d_out, n_cu, settle, timed, &ms);  const double bf16_w1_ms = ms;
     const double u01_w2 = run<false, 512>(d_u01, d_out, n_cu, settle, timed, &ms);   const double u01_w2_ms = ms;
     const double u01_w1 = run<false, 256>(d_u01, d_out, n_cu, settle, timed, &ms);   const double u01_w1_ms = ms;
+    const double s16_w2 = run16<512>(d_u01, d_out, n_cu, settle, timed, &ms);        const double s16_w2_ms = ms;
+    const double s16_w1 = run16<256>(d_u01, d_out, n_cu, settle, timed, &ms);        const double s16_w1_ms = ms;
+    const double u01_again = run<false, 512>(d_u01, d_out, n_cu, settle, timed, &ms); const double u01_again_ms = ms;
     const double zero_w2 = run<false, 512>(d_zero, d_out, n_cu, settle, timed, &ms); const double zero_w2_ms = ms;
     // cold: 20 launches straight after >= 1 s of idle (what a short driver-run benchmark sees)
     CHECK(hipDeviceSynchronize());
@@ -150,6 +208,9 @@ int main() {
     printf(" \"bf16_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", bf16_w1, bf16_w1_ms, cyc / (bf16_w1_ms * 1e-3) / 1e9);
     printf(" \"f16_uniform01_2waves_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", u01_w2, u01_w2_ms, cyc / (u01_w2_ms * 1e-3) / 1e9);
     printf(" \"f16_uniform01_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", u01_w1, u01_w1_ms, cyc / (u01_w1_ms * 1e-3) / 1e9);
+    printf(" \"f16_uniform01_16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", s16_w2, s16_w2_ms);
+    printf(" \"f16_uniform01_16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", s16_w1, s16_w1_ms);
+    printf(" \"f16_uniform01_2waves_per_simd_repeat\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", u01_again, u01_again_ms);
     printf(" \"f16_zero_operands_2waves\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", zero_w2, zero_w2_ms, cyc / (zero_w2_ms * 1e-3) / 1e9);
     printf(" \"f16_cold_20_launches_after_idle\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", cold, cold_ms);
     printf(" \"sustained_tflops_f16_signed\": %.1f,\n", f16_w2 > f16_w1 ? f16_w2 : f16_w1);

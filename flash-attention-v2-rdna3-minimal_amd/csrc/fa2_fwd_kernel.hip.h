@@ -105,6 +105,7 @@ struct FwdParams {
     const void* bias;
     int64_t bs[3];
     int bias_kind;                       // 1: the I/O 16-bit dtype, 2: f32, 3: uint8 (non-zero = attend)
+    int bias_vec;                        // host: base pointer, strides and Nkv allow one aligned load per group of four kv
 };
 
 template <bool BF16>
@@ -327,8 +328,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     const float cs = p.c;                // factor of the raw Q.K^T product
     const float c = BIAS ? 1.0f : p.c;   // factor still to be applied to a finished score (BIAS: already in log2 units)
 
-    // ---- attention bias (BIAS kernels): the 32 values of this lane's row in one KV tile, raw bits, in the register order
-    // of the two score accumulators (element 16*half + r <-> kv = kv0 + 32*half + (r&3) + 8(r>>2) + 4hi)
+    // ---- attention bias (BIAS kernels): the 32 values of this lane's row in one KV tile, as loaded (raw words), in the register
+    // order of the two score accumulators: element i = 16*half + 4*g + e <-> kv = kv0 + 32*half + 8*g + 4*hi + e, i.e. eight groups
+    // G = 4*half + g of four consecutive kv.  Two load forms (wave-uniform p.bias_vec, chosen by the host):
+    //   scalar  one guarded load per element, raw[i] = the element (any alignment, any Nkv — e.g. 77-token cross-attention rows)
+    //   vector  one load per group — 8 / 16 / 4 bytes for the 16-bit / f32 / byte kinds — when the base pointer and every stride
+    //           are multiples of four elements and Nkv % 4 == 0: raw[2G..2G+1] / raw[4G..4G+3] / raw[G]
+    // The words are decoded where they are used (add_bias), so that the loads issued at the top of a step fly under its MFMAs.
     constexpr int NB = BIAS ? 32 : 1;
     auto load_bias = [&](int tile, uint32_t (&raw)[QB][NB]) __attribute__((always_inline)) {
         if constexpr (BIAS) {
@@ -337,7 +343,34 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
             for (int qb = 0; qb < QB; ++qb) {
                 const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
                 const int64_t row = b * p.bs[0] + h * p.bs[1] + (int64_t)qr * p.bs[2];
-                if (p.bias_kind == 1) {
+                if (p.bias_vec) {
+                    if (p.bias_kind == 1) {
+                        const uint16_t* bp = (const uint16_t*)p.bias + row;
+#pragma unroll
+                        for (int G = 0; G < 8; ++G) {
+                            const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
+                            const u32x2 w = kvi < p.Nkv ? *(const u32x2*)(bp + kvi) : (u32x2){0u, 0u};
+                            raw[qb][2 * G] = w[0];
+                            raw[qb][2 * G + 1] = w[1];
+                        }
+                    } else if (p.bias_kind == 2) {
+                        const uint32_t* bp = (const uint32_t*)p.bias + row;
+#pragma unroll
+                        for (int G = 0; G < 8; ++G) {
+                            const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
+                            const u32x4 w = kvi < p.Nkv ? *(const u32x4*)(bp + kvi) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) raw[qb][4 * G + e] = w[e];
+                        }
+                    } else {
+                        const uint8_t* bp = (const uint8_t*)p.bias + row;
+#pragma unroll
+                        for (int G = 0; G < 8; ++G) {
+                            const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
+                            raw[qb][G] = kvi < p.Nkv ? *(const uint32_t*)(bp + kvi) : 0u;
+                        }
+                    }
+                } else if (p.bias_kind == 1) {
                     const uint16_t* bp = (const uint16_t*)p.bias + row;
 #pragma unroll
                     for (int e = 0; e < 32; ++e) {
@@ -366,11 +399,19 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     auto add_bias = [&](f32x16& s0, f32x16& s1, const uint32_t (&raw)[NB]) __attribute__((always_inline)) {
         if constexpr (BIAS) {
             constexpr float kLog2e = 1.4426950408889634f;
+            auto io16 = [](uint32_t bits16) __attribute__((always_inline)) -> float {      // low 16 bits -> f32
+                if constexpr (BF16) return __uint_as_float(bits16 << 16);
+                else return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+            };
             if (p.bias_kind == 3) {
+                const bool vec = p.bias_vec != 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s0[r] = raw[r] ? s0[r] * cs : -INFINITY;
-                    s1[r] = raw[16 + r] ? s1[r] * cs : -INFINITY;
+                    // vector form: byte (r & 3) of the group word; scalar form: one word per element
+                    const uint32_t k0 = vec ? raw[r >> 2] & (0xffu << (8 * (r & 3))) : raw[r];
+                    const uint32_t k1 = vec ? raw[4 + (r >> 2)] & (0xffu << (8 * (r & 3))) : raw[16 + r];
+                    s0[r] = k0 ? s0[r] * cs : -INFINITY;
+                    s1[r] = k1 ? s1[r] * cs : -INFINITY;
                 }
             } else if (p.bias_kind == 2) {
 #pragma unroll
@@ -378,19 +419,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
                     s0[r] = __builtin_fmaf(s0[r], cs, __uint_as_float(raw[r]) * kLog2e);
                     s1[r] = __builtin_fmaf(s1[r], cs, __uint_as_float(raw[16 + r]) * kLog2e);
                 }
+            } else if (p.bias_vec) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {      // element r of half 0 = 16-bit half (r & 1) of word r >> 1; half 1: words 8..15
+                    const uint32_t w0 = raw[r >> 1], w1 = raw[8 + (r >> 1)];
+                    s0[r] = __builtin_fmaf(s0[r], cs, io16((r & 1) ? w0 >> 16 : w0 & 0xffffu) * kLog2e);
+                    s1[r] = __builtin_fmaf(s1[r], cs, io16((r & 1) ? w1 >> 16 : w1 & 0xffffu) * kLog2e);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float b0, b1;
-                    if constexpr (BF16) {
-                        b0 = __uint_as_float(raw[r] << 16);
-                        b1 = __uint_as_float(raw[16 + r] << 16);
-                    } else {
-                        b0 = (float)__builtin_bit_cast(_Float16, (uint16_t)raw[r]);
-                        b1 = (float)__builtin_bit_cast(_Float16, (uint16_t)raw[16 + r]);
-                    }
-                    s0[r] = __builtin_fmaf(s0[r], cs, b0 * kLog2e);
-                    s1[r] = __builtin_fmaf(s1[r], cs, b1 * kLog2e);
+                    s0[r] = __builtin_fmaf(s0[r], cs, io16(raw[r]) * kLog2e);
+                    s1[r] = __builtin_fmaf(s1[r], cs, io16(raw[16 + r]) * kLog2e);
                 }
             }
         }

@@ -81,6 +81,9 @@ int pick_rows(const fa2::FwdParams& p) {
 int tail_split_heads(const fa2::FwdParams& p, bool causal) {
     static const bool on = [] { const char* e = std::getenv("FA2_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
     if (!on || causal || forced_rows() != 0) return p.nbh;
+    // a second launch costs ~5 us: only sweeps of at least 16 KV tiles (a workgroup then runs >= ~15 us) can win it back.  SDXL's
+    // cross-attention (B2 H10 N4096 x Nkv 77, two tiles) measured 13.8 us split into two launches against 10.1 us for torch SDPA.
+    if (p.Nkv < 16 * fa2::kKvTile) return p.nbh;
     const int64_t cus = 256, nq = (p.Nq + 255) / 256, w = (int64_t)p.nbh * nq;
     if (w <= cus || nq > cus) return p.nbh;
     const int64_t main_heads = (w / cus) * cus / nq;           // whole heads that fit the full rounds
@@ -122,6 +125,8 @@ int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     if constexpr (HD > 256) {
         return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
     } else if constexpr (kNW == 8 && kQB == 1) {
+        // (512-row workgroups <8, 2> for short KV sweeps over long Q — SDXL cross-attention, 320 workgroups = 1.25 rounds — were
+        //  measured: 105 spilled VGPRs at D = 64, 20.1 us against 13.7 us: not kept)
         if (pick_rows(p) == 128) return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
         return launch_shape<HD, BF16, CAUSAL, kNW, kQB>(p, stream);
     } else {
@@ -379,6 +384,12 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     p.bias = bias;
     p.bias_kind = bias_kind;
     for (int i = 0; i < 3; ++i) p.bs[i] = bias_kind != FA2_BIAS_NONE ? bias_strides[i] : 0;
+    p.bias_vec = 0;
+    if (bias_kind != FA2_BIAS_NONE) {      // groups of four consecutive kv can be fetched with one aligned load
+        const uintptr_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1;
+        p.bias_vec = Nkv % 4 == 0 && reinterpret_cast<uintptr_t>(bias) % (4 * esize) == 0 && p.bs[0] % 4 == 0 && p.bs[1] % 4 == 0 &&
+                     p.bs[2] % 4 == 0;
+    }
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 
     hipStream_t stream = (hipStream_t)hip_stream;

@@ -288,7 +288,7 @@ class FlashAttentionFunction(torch.autograd.Function):
 
         o, q_bwd, k_bwd, v_bwd, o_bwd, L = ret
 
-        if q.requires_grad:
+        if ctx is not None and q.requires_grad:       # (ctx is None on the inference fast path below, e.g. under torch.no_grad())
             ctx.args = (causal, scale, mask, N, Nkv, D, BNHD_fmt)
             ctx.save_for_backward(q_bwd, k_bwd, v_bwd, o_bwd, L)
         return o

@@ -340,10 +340,14 @@ def test_sd_hook_bnhd_adapter_matches_sdpa():
         split = lambda t: t.reshape(t.shape[0], t.shape[1], heads, d).transpose(1, 2).float()  # noqa: E731
         ref = torch.nn.functional.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(b, nq, heads * d)
         assert float((o.float() - ref).abs().max()) <= ATOL[0] + RTOL[0] * float(ref.abs().max())
+    # head dims above the largest kernel go to the host's own attention (masks no longer do: tests/test_bias_gpu.py)
+    wide = torch.zeros((1, 16, 1024), device=_dev(), dtype=torch.float16)
     with pytest.raises(NotImplementedError):
-        attention_bnhd(q, k, v, heads, mask=torch.ones(1, device=_dev()))
+        attention_bnhd(wide, wide, wide, 1)
     sentinel = object()
-    assert attention_bnhd(q, k, v, heads, mask=torch.ones(1), fallback=lambda *a: sentinel) is sentinel
+    assert attention_bnhd(wide, wide, wide, 1, fallback=lambda *a: sentinel) is sentinel
+    with pytest.raises(RuntimeError, match="broadcast"):
+        attention_bnhd(q, k, v, heads, mask=torch.ones(3, device=_dev()).bool())
 
 
 def test_non_half_inputs_run_as_bf16_like_the_reference():

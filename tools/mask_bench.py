@@ -1,0 +1,58 @@
+"""Masked / biased attention (flash_attention(mask=...), C-ABI fa2_fwd_bias) against torch SDPA with attn_mask, on MI355X:
+the shapes where Stable-Diffusion front ends actually pass a mask (prompt padding in cross-attention) plus two dense-bias cases.
+Developer tool; prints one line per case (wall time per call through the Python operators, events around 100 calls)."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-v2-rdna3-minimal_amd"))
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attention  # noqa: E402
+
+CASES = [  # name, B, H, Nq, Nkv, D, dtype, mask kind, mask shape
+    ("sdxl-cross key-padding bool", 2, 10, 4096, 77, 64, torch.float16, "bool", (2, 1, 1, 77)),
+    ("sd15-cross key-padding bool", 2, 8, 4096, 77, 40, torch.float16, "bool", (2, 1, 1, 77)),
+    ("sdxl-cross additive f16", 2, 10, 4096, 77, 64, torch.float16, "io", (2, 1, 4096, 77)),
+    ("N1024 D64 dense bias f16", 2, 20, 1024, 1024, 64, torch.float16, "io", (1, 20, 1024, 1024)),
+    ("N4096 D64 dense bias f16 (shared)", 2, 10, 4096, 4096, 64, torch.float16, "io", (1, 1, 4096, 4096)),
+    ("N4096 D128 bool mask (shared)", 2, 16, 4096, 4096, 128, torch.float16, "bool", (4096, 4096)),
+    ("N4096 D128 bias bf16 per head", 1, 16, 4096, 4096, 128, torch.bfloat16, "io", (1, 16, 4096, 4096)),
+]
+
+
+def timeit(fn, iters=100):
+    for _ in range(10):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    print("%-36s %10s %10s %7s %12s %10s" % ("case", "fa2 mask", "sdpa mask", "x", "fa2 no mask", "max diff"))
+    with torch.no_grad():
+        for name, B, H, Nq, Nkv, D, dt, kind, mshape in CASES:
+            g = torch.Generator(device=dev).manual_seed(1)
+            q = torch.rand((B, H, Nq, D), generator=g, device=dev).to(dt)
+            k, v = (torch.rand((B, H, Nkv, D), generator=g, device=dev).to(dt) for _ in range(2))
+            if kind == "bool":
+                mask = torch.rand(mshape, generator=g, device=dev) < 0.8
+                mask[..., 0] = True
+            else:
+                mask = torch.randn(mshape, generator=g, device=dev).to(dt)
+            t_f = timeit(lambda: flash_attention(q, k, v, mask))
+            t_s = timeit(lambda: F.scaled_dot_product_attention(q, k, v, attn_mask=mask))
+            t_0 = timeit(lambda: FlashAttentionFunction.apply(q, k, v, None, False))
+            err = (flash_attention(q, k, v, mask).float() - F.scaled_dot_product_attention(q, k, v, attn_mask=mask).float()).abs().max().item()
+            print("%-36s %8.1fus %8.1fus %6.2fx %10.1fus %10.1e" % (name, t_f, t_s, t_s / t_f, t_0, err))
+
+
+if __name__ == "__main__":
+    main()

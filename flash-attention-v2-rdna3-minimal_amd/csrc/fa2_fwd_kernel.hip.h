@@ -217,9 +217,9 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // recomputed per half (1.5x the MFMA work of an unsplit kernel; D = 256 only occurs at tiny N in practice).
 //
 // BIAS: scores = scale * Q K^T + bias[b, h, i, j] (or a boolean keep-mask) — the attention bias / mask argument the
-// reference only reserves (`mask` is accepted and ignored, FlashAttn.py:49, :74; README.md:45 lists it as to do).  Every tile
-// runs the generic step: the bias of tile+1 is fetched into registers at the top of the step (the loads fly under the
-// MFMAs), folded into the scores as s*c + bias*log2e after the masks, and the softmax then works in log2 units (c = 1).
+// reference only reserves (`mask` is accepted and ignored, FlashAttn.py:49, :74; README.md:45 lists it as to do).  The bias of
+// tile+1 is fetched into registers at the top of a step (the loads fly under the MFMAs), folded into the scores as
+// s*c + bias*log2e after the causal / tail masks, and the softmax then works in log2 units (c = 1).
 // A row whose every score is -inf (fully masked) produces O = 0 and lse = -inf.
 template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdParams p) {
@@ -668,7 +668,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
         const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
         n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
         n_fast = n_fast < 0 ? 0 : n_fast & ~1;
-        if (BIAS) n_fast = 0;                                              // the bias is applied by the generic step only
     }
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};

@@ -153,6 +153,63 @@ static double run16(const u32x4* d_ops, float* d_out, int n_cu, double settle_s,
     return flops / per_launch_s / 1e12;
 }
 
+// Operand-sharing probe (32x32x16 f16, U[0,1) operands): does the order in which the MFMAs of a tile are issued matter for power?
+//   ORDER 0: consecutive MFMAs differ in A and in B (the loop of peak_kernel)
+//   ORDER 1: runs of four MFMAs share B (the attention kernel's P.V order: one P fragment against four V^T fragments)
+//   ORDER 2: runs of four MFMAs share A
+//   ORDER 3: all MFMAs use the same A and the same B
+template <int ORDER, int THREADS>
+__global__ __launch_bounds__(THREADS) void order_kernel(const u32x4* __restrict__ operands, float* __restrict__ out, int iters) {
+    const int tid = threadIdx.x;
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = operands[(i * 2 + 0) * 512 + tid];
+        b[i] = operands[(i * 2 + 1) * 512 + tid];
+    }
+    f32x16 acc[4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 aa = ORDER == 0 ? a[(i + r) & 3] : ORDER == 1 ? a[i] : ORDER == 2 ? a[r] : a[0];
+                const u32x4 bb = ORDER == 0 ? b[i] : ORDER == 1 ? b[r] : ORDER == 2 ? b[i] : b[0];
+                acc[i] = mfma<false>(aa, bb, acc[i]);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[blockIdx.x * THREADS + tid] = s;
+}
+
+template <int ORDER>
+static double run_order(const u32x4* d_ops, float* d_out, int n_cu, double settle_s, int timed_launches) {
+    const int iters = kMfmaPerSimd / 2 / 16;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    float ms = 0.f;
+    do {
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((order_kernel<ORDER, 512>), dim3(n_cu), dim3(512), 0, 0, d_ops, d_out, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } while (ms < settle_s * 1e3);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < timed_launches; ++i) hipLaunchKernelGGL((order_kernel<ORDER, 512>), dim3(n_cu), dim3(512), 0, 0, d_ops, d_out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipGetLastError());
+    const double per_launch_s = ms * 1e-3 / timed_launches;
+    return 2.0 * 32 * 32 * 16 * (double)kMfmaPerSimd * 4 * n_cu / per_launch_s / 1e12;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -190,6 +247,9 @@ int main() {
     const double s16_w2 = run16<512>(d_u01, d_out, n_cu, settle, timed, &ms);        const double s16_w2_ms = ms;
     const double s16_w1 = run16<256>(d_u01, d_out, n_cu, settle, timed, &ms);        const double s16_w1_ms = ms;
     const double u01_again = run<false, 512>(d_u01, d_out, n_cu, settle, timed, &ms); const double u01_again_ms = ms;
+    const double ord0 = run_order<0>(d_u01, d_out, n_cu, settle, timed), ord1 = run_order<1>(d_u01, d_out, n_cu, settle, timed);
+    const double ord2 = run_order<2>(d_u01, d_out, n_cu, settle, timed), ord3 = run_order<3>(d_u01, d_out, n_cu, settle, timed);
+    const double ord0b = run_order<0>(d_u01, d_out, n_cu, settle, timed);
     const double zero_w2 = run<false, 512>(d_zero, d_out, n_cu, settle, timed, &ms); const double zero_w2_ms = ms;
     // cold: 20 launches straight after >= 1 s of idle (what a short driver-run benchmark sees)
     CHECK(hipDeviceSynchronize());
@@ -211,6 +271,7 @@ int main() {
     printf(" \"f16_uniform01_16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", s16_w2, s16_w2_ms);
     printf(" \"f16_uniform01_16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", s16_w1, s16_w1_ms);
     printf(" \"f16_uniform01_2waves_per_simd_repeat\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", u01_again, u01_again_ms);
+    printf(" \"f16_uniform01_operand_order_tflops\": {\"a_and_b_change_every_mfma\": %.1f, \"b_shared_by_runs_of_4\": %.1f, \"a_shared_by_runs_of_4\": %.1f, \"same_a_and_b_always\": %.1f, \"a_and_b_change_repeat\": %.1f},\n", ord0, ord1, ord2, ord3, ord0b);
     printf(" \"f16_zero_operands_2waves\": {\"tflops\": %.1f, \"launch_ms\": %.5f, \"implied_clock_ghz\": %.3f},\n", zero_w2, zero_w2_ms, cyc / (zero_w2_ms * 1e-3) / 1e9);
     printf(" \"f16_cold_20_launches_after_idle\": {\"tflops\": %.1f, \"launch_ms\": %.5f},\n", cold, cold_ms);
     printf(" \"sustained_tflops_f16_signed\": %.1f,\n", f16_w2 > f16_w1 ? f16_w2 : f16_w1);

@@ -77,6 +77,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 
 constexpr int kQBlock = 256;      // rows per workgroup of the default kernel shapes (8 waves x 32 rows)
 constexpr int kKvTile = 64;       // KV rows per tile
@@ -221,6 +222,8 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // tile+1 is fetched into registers at the top of a step (the loads fly under the MFMAs), folded into the scores as
 // s*c + bias*log2e after the causal / tail masks, and the softmax then works in log2 units (c = 1).
 // A row whose every score is -inf (fully masked) produces O = 0 and lse = -inf.
+// (BIAS at D = 64 with two workgroups per CU — 256 registers per wave instead of the 434 the compiler spreads one over — spills
+//  112 VGPRs: not used)
 template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
@@ -334,24 +337,51 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     //   scalar  one guarded load per element, raw[i] = the element (any alignment, any Nkv — e.g. 77-token cross-attention rows)
     //   vector  one load per group — 8 / 16 / 4 bytes for the 16-bit / f32 / byte kinds — when the base pointer and every stride
     //           are multiples of four elements and Nkv % 4 == 0: raw[2G..2G+1] / raw[4G..4G+3] / raw[G]
+    //   tile    (p.bias_vec == 2; pointer, strides and Nkv multiples of 16 bytes, head dims up to 256) the wave fetches its 32 rows x
+    //           64 kv tile with COALESCED 16-byte loads (4 / 8 / 2 per lane; an instruction covers whole rows — with lane = Q row
+    //           the other forms touch 32 cache lines per instruction for a few useful bytes each), parks it in a wave-private LDS
+    //           image (rows of 272 bytes) when the scores are ready and reads its own row's groups back from there
     // The words are decoded where they are used (add_bias), so that the loads issued at the top of a step fly under its MFMAs.
-    constexpr int NB = BIAS ? 32 : 1;
-    auto load_bias = [&](int tile, uint32_t (&raw)[QB][NB]) __attribute__((always_inline)) {
+    // (the words travel as ONE 32-element vector value per wave tile: as an array, written on several control paths, they were
+    //  kept in scratch memory — 112 bytes per lane — instead of registers)
+    constexpr int kBiasRowB = 272;                           // up to 256 bytes of one row's 64 bias values (f32) + 16 bytes of padding
+    constexpr int kBiasLdsBase = 2 * TILEB + 2 * VTILEB;     // "tile" form: NW wave-private images of 32 rows above the K / V buffers
+    static_assert(!BIAS || QB == 1, "the bias kernels run one 32-row Q block per wave");
+    auto load_bias = [&](int tile, u32x32& raw) __attribute__((always_inline)) {
         if constexpr (BIAS) {
             const int kv0 = tile * kKvTile + 4 * hi;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
                 const int64_t row = b * p.bs[0] + h * p.bs[1] + (int64_t)qr * p.bs[2];
-                if (p.bias_vec) {
+                if (p.bias_vec == 2) {
+                    // a tile row is 64 elements = LPR lanes of 16 bytes; instruction i covers rows [i*RPI, +RPI) of the wave's 32
+                    // (RPI = 64 / LPR); its words land in raw[4i .. 4i+3]
+                    auto tile_rows = [&](auto es_t, auto lpr_log_t) __attribute__((always_inline)) {
+                        constexpr int ES = decltype(es_t)::value, LPRL = decltype(lpr_log_t)::value, RPI = 64 >> LPRL;
+                        const char* bh_base = (const char*)p.bias + (b * p.bs[0] + h * p.bs[1]) * ES;
+                        const int kvg = tile * kKvTile + (16 / ES) * (lane & ((1 << LPRL) - 1));      // first kv of this lane's granule
+#pragma unroll
+                        for (int i = 0; i < 32 / RPI; ++i) {
+                            const int rr = qw0 + 32 * qb + i * RPI + (lane >> LPRL);
+                            const int rc = rr < p.Nq ? rr : p.Nq - 1;
+                            const u32x4 w = kvg < p.Nkv ? *(const u32x4*)(bh_base + ((int64_t)rc * p.bs[2] + kvg) * ES) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) raw[4 * i + e] = w[e];
+                        }
+                    };
+                    if (p.bias_kind == 1) tile_rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+                    else if (p.bias_kind == 2) tile_rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+                    else tile_rows(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                } else if (p.bias_vec) {
                     if (p.bias_kind == 1) {
                         const uint16_t* bp = (const uint16_t*)p.bias + row;
 #pragma unroll
                         for (int G = 0; G < 8; ++G) {
                             const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
                             const u32x2 w = kvi < p.Nkv ? *(const u32x2*)(bp + kvi) : (u32x2){0u, 0u};
-                            raw[qb][2 * G] = w[0];
-                            raw[qb][2 * G + 1] = w[1];
+                            raw[2 * G] = w[0];
+                            raw[2 * G + 1] = w[1];
                         }
                     } else if (p.bias_kind == 2) {
                         const uint32_t* bp = (const uint32_t*)p.bias + row;
@@ -360,14 +390,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
                             const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
                             const u32x4 w = kvi < p.Nkv ? *(const u32x4*)(bp + kvi) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) raw[qb][4 * G + e] = w[e];
+                            for (int e = 0; e < 4; ++e) raw[4 * G + e] = w[e];
                         }
                     } else {
                         const uint8_t* bp = (const uint8_t*)p.bias + row;
 #pragma unroll
                         for (int G = 0; G < 8; ++G) {
                             const int kvi = kv0 + 32 * (G >> 2) + 8 * (G & 3);
-                            raw[qb][G] = kvi < p.Nkv ? *(const uint32_t*)(bp + kvi) : 0u;
+                            raw[G] = kvi < p.Nkv ? *(const uint32_t*)(bp + kvi) : 0u;
                         }
                     }
                 } else if (p.bias_kind == 1) {
@@ -375,64 +405,110 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #pragma unroll
                     for (int e = 0; e < 32; ++e) {
                         const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
-                        raw[qb][e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
+                        raw[e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
                     }
                 } else if (p.bias_kind == 2) {
                     const uint32_t* bp = (const uint32_t*)p.bias + row;
 #pragma unroll
                     for (int e = 0; e < 32; ++e) {
                         const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
-                        raw[qb][e] = kvi < p.Nkv ? bp[kvi] : 0u;
+                        raw[e] = kvi < p.Nkv ? bp[kvi] : 0u;
                     }
                 } else {
                     const uint8_t* bp = (const uint8_t*)p.bias + row;
 #pragma unroll
                     for (int e = 0; e < 32; ++e) {
                         const int kvi = kv0 + 32 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
-                        raw[qb][e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
+                        raw[e] = kvi < p.Nkv ? (uint32_t)bp[kvi] : 0u;
                     }
                 }
             }
         }
     };
-    // s <- s * cs + bias * log2(e)   (boolean mask: s * cs where kept, -inf where not)
-    auto add_bias = [&](f32x16& s0, f32x16& s1, const uint32_t (&raw)[NB]) __attribute__((always_inline)) {
+    // s <- s * cs + bias * log2(e)   (boolean mask: s * cs where kept, -inf where not).  One fully separate code path per bias
+    // kind (compile-time KIND inside, wave-uniform dispatch outside): shared temporaries across the kinds ended up in scratch.
+    auto add_bias = [&](f32x16& s0, f32x16& s1, const u32x32& raw) __attribute__((always_inline)) {
         if constexpr (BIAS) {
-            constexpr float kLog2e = 1.4426950408889634f;
-            auto io16 = [](uint32_t bits16) __attribute__((always_inline)) -> float {      // low 16 bits -> f32
-                if constexpr (BF16) return __uint_as_float(bits16 << 16);
-                else return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+            auto one_kind = [&](auto kind_t) __attribute__((always_inline)) {
+                constexpr int KIND = decltype(kind_t)::value;
+                constexpr float kLog2e = 1.4426950408889634f;
+                constexpr int ES = KIND == 1 ? 2 : KIND == 2 ? 4 : 1;          // bytes per element
+                constexpr int LPRL = KIND == 1 ? 3 : KIND == 2 ? 4 : 2;        // log2(lanes of 16 bytes per tile row)
+                constexpr int RPI = 64 >> LPRL;                                // rows per load instruction
+                constexpr int WPG = ES;                                        // words per group of four elements
+                auto io16 = [](uint32_t bits16) __attribute__((always_inline)) -> float {      // low 16 bits -> f32
+                    if constexpr (BF16) return __uint_as_float(bits16 << 16);
+                    else return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+                };
+                // element r (0..15) of half hf from the grouped word layout (group G = 4*hf + (r >> 2), element e = r & 3)
+                auto decode = [&](const u32x32& wd, int hf, int r) __attribute__((always_inline)) -> float {
+                    const int G = 4 * hf + (r >> 2), e = r & 3;
+                    if constexpr (KIND == 2) return __uint_as_float(wd[4 * G + e]) * kLog2e;
+                    else if constexpr (KIND == 1) {
+                        const uint32_t w = wd[2 * G + (e >> 1)];
+                        return io16((e & 1) ? w >> 16 : w & 0xffffu) * kLog2e;
+                    } else return (wd[G] & (0xffu << (8 * e))) ? 0.f : -INFINITY;
+                };
+                auto fold = [&](float s, float bv) __attribute__((always_inline)) -> float {
+                    if constexpr (KIND == 3) return bv == 0.f ? s * cs : -INFINITY;
+                    else return __builtin_fmaf(s, cs, bv);
+                };
+                if (p.bias_vec == 2) {
+                    // wave-private image above the K / V buffers: park the coalesced tile, read this lane's row back (the LDS
+                    // operations of one wave execute in order, so neither a barrier nor a second buffer is needed)
+                    char* bimg = smem + kBiasLdsBase + wave * (32 * kBiasRowB);
+#pragma unroll
+                    for (int i = 0; i < 32 / RPI; ++i)
+                        *(u32x4*)(bimg + (RPI * i + (lane >> LPRL)) * kBiasRowB + 16 * (lane & ((1 << LPRL) - 1))) =
+                            (u32x4){raw[4 * i], raw[4 * i + 1], raw[4 * i + 2], raw[4 * i + 3]};
+                    u32x32 wd;
+#pragma unroll
+                    for (int G = 0; G < 8; ++G) {
+                        const char* src = bimg + l31 * kBiasRowB + (32 * (G >> 2) + 8 * (G & 3) + 4 * hi) * ES;
+                        if constexpr (KIND == 1) {
+                            const u32x2 w = *(const u32x2*)src;
+                            wd[2 * G] = w[0];
+                            wd[2 * G + 1] = w[1];
+                        } else if constexpr (KIND == 2) {
+                            const u32x4 w = *(const u32x4*)src;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) wd[4 * G + e] = w[e];
+                        } else {
+                            wd[G] = *(const uint32_t*)src;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s0[r] = fold(s0[r], decode(wd, 0, r));
+                        s1[r] = fold(s1[r], decode(wd, 1, r));
+                    }
+                } else if (p.bias_vec) {
+                    u32x32 wd;
+                    wd = raw;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s0[r] = fold(s0[r], decode(wd, 0, r));
+                        s1[r] = fold(s1[r], decode(wd, 1, r));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {        // scalar form: one word per element
+                        if constexpr (KIND == 3) {
+                            s0[r] = raw[r] ? s0[r] * cs : -INFINITY;
+                            s1[r] = raw[16 + r] ? s1[r] * cs : -INFINITY;
+                        } else if constexpr (KIND == 2) {
+                            s0[r] = __builtin_fmaf(s0[r], cs, __uint_as_float(raw[r]) * kLog2e);
+                            s1[r] = __builtin_fmaf(s1[r], cs, __uint_as_float(raw[16 + r]) * kLog2e);
+                        } else {
+                            s0[r] = __builtin_fmaf(s0[r], cs, io16(raw[r]) * kLog2e);
+                            s1[r] = __builtin_fmaf(s1[r], cs, io16(raw[16 + r]) * kLog2e);
+                        }
+                    }
+                }
             };
-            if (p.bias_kind == 3) {
-                const bool vec = p.bias_vec != 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // vector form: byte (r & 3) of the group word; scalar form: one word per element
-                    const uint32_t k0 = vec ? raw[r >> 2] & (0xffu << (8 * (r & 3))) : raw[r];
-                    const uint32_t k1 = vec ? raw[4 + (r >> 2)] & (0xffu << (8 * (r & 3))) : raw[16 + r];
-                    s0[r] = k0 ? s0[r] * cs : -INFINITY;
-                    s1[r] = k1 ? s1[r] * cs : -INFINITY;
-                }
-            } else if (p.bias_kind == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s0[r] = __builtin_fmaf(s0[r], cs, __uint_as_float(raw[r]) * kLog2e);
-                    s1[r] = __builtin_fmaf(s1[r], cs, __uint_as_float(raw[16 + r]) * kLog2e);
-                }
-            } else if (p.bias_vec) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {      // element r of half 0 = 16-bit half (r & 1) of word r >> 1; half 1: words 8..15
-                    const uint32_t w0 = raw[r >> 1], w1 = raw[8 + (r >> 1)];
-                    s0[r] = __builtin_fmaf(s0[r], cs, io16((r & 1) ? w0 >> 16 : w0 & 0xffffu) * kLog2e);
-                    s1[r] = __builtin_fmaf(s1[r], cs, io16((r & 1) ? w1 >> 16 : w1 & 0xffffu) * kLog2e);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s0[r] = __builtin_fmaf(s0[r], cs, io16(raw[r]) * kLog2e);
-                    s1[r] = __builtin_fmaf(s1[r], cs, io16(raw[16 + r]) * kLog2e);
-                }
-            }
+            if (p.bias_kind == 1) one_kind(std::integral_constant<int, 1>{});
+            else if (p.bias_kind == 2) one_kind(std::integral_constant<int, 2>{});
+            else one_kind(std::integral_constant<int, 3>{});
         }
     };
 
@@ -514,7 +590,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     // that did not grow have alpha == 1.  Runs BEFORE the tile's P is formed and AFTER the previous
     // tile's P.V has been accumulated, so everything at the old reference is scaled exactly once.
     // (reference: kernel_fp16.cu:396-451)
-    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], const uint32_t (&braw)[QB][NB]) __attribute__((always_inline)) {
+    auto finish_scores = [&](int tile, auto masked, f32x16 (&s)[QB][2], const u32x32& braw) __attribute__((always_inline)) {
         float mx[QB];
         bool grow = FA2_DEFER_THR < 0.f;
 #pragma unroll
@@ -541,7 +617,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
                     }
                 }
             }
-            add_bias(s0, s1, braw[qb]);
+            add_bias(s0, s1, braw);
             float m = max3(s0[0], s1[0], s0[1]);
             m = max3(m, s1[1], s0[2]);
 #pragma unroll
@@ -632,7 +708,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
 #endif
         if (more2) load_k(tile + 2, PAR);  // global loads fly under the MFMA work below
         if (more1) load_v(tile + 1, PAR ^ 1);
-        uint32_t braw[QB][NB];
+        u32x32 braw;
         if (BIAS && next_w) load_bias(tile + 1, braw);
         if (next_w) qk(PAR ^ 1, sn);
         if (cur_w) {
@@ -654,7 +730,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdPar
     if (ntiles > 1) { load_k(1, 1); write_k(1); }
     __syncthreads();
     f32x16 sa[QB][2], sb[QB][2];
-    uint32_t braw0[QB][NB];
+    u32x32 braw0;
     load_bias(0, braw0);
     qk(0, sa);
     __syncthreads();   // step(0) stages K2 into K buffer 0: every wave's tile-0 fragment reads must be behind us

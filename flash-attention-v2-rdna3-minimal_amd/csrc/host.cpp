@@ -97,7 +97,9 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
     constexpr int lds_epi = FA2_EPI_LDS && QB == 1 ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
-    constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
+    // bias kernels: + NW wave-private 32-row images of the "tile" bias form where they fit (not at D = 512: 160 KiB of K / V buffers)
+    constexpr int lds_bias = BIAS && lds_kv + NW * 32 * 272 <= 160 * 1024 ? NW * 32 * 272 : 0;
+    constexpr int lds = lds_kv + lds_bias > lds_epi ? lds_kv + lds_bias : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + NW * QB * 32 - 1) / (NW * QB * 32);
@@ -390,6 +392,12 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         const uintptr_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1;
         p.bias_vec = Nkv % 4 == 0 && reinterpret_cast<uintptr_t>(bias) % (4 * esize) == 0 && p.bs[0] % 4 == 0 && p.bs[1] % 4 == 0 &&
                      p.bs[2] % 4 == 0;
+        // 2: a per-row bias whose geometry allows whole 16-byte granules: coalesced tile loads through LDS (a row-broadcast bias —
+        // bs[2] == 0, e.g. a key-padding mask — is one cache line for the whole wave already)
+        const int64_t gran = 16 / (int64_t)esize;
+        if (p.bias_vec && HD <= 256 && Nkv % gran == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 && p.bs[0] % gran == 0 &&
+            p.bs[1] % gran == 0 && p.bs[2] % gran == 0 && p.bs[2] != 0)
+            p.bias_vec = 2;
     }
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 

@@ -226,12 +226,19 @@ def test_sd_hook_with_masks_matches_sdpa():
     assert (out.float() - sdpa(add4)).abs().max().item() <= 2e-3
 
 
-def test_bias_memory_past_the_row_is_never_read():
-    """Rows of Nkv = 77 elements inside a NaN-poisoned buffer: the guarded per-element loads must not touch the neighbours' tail."""
-    B, H, Nq, Nkv, D = 1, 2, 64, 77, 64
-    q, k, v = _inputs(B, H, Nq, Nkv, D, 0, seed=17)
-    buf = torch.full((B, H, Nq, 128), float("nan"), device=_dev())
-    buf[..., :Nkv] = torch.randn((B, H, Nq, Nkv), device=_dev())
-    bias = buf[..., :Nkv]                                                   # row pitch 128, last dim contiguous: passed as is
+@pytest.mark.parametrize("nkv,dtype", [(77, torch.float32), (76, torch.float32), (72, torch.float16), (76, torch.float16), (76, torch.bool), (80, torch.bool)])
+def test_bias_memory_past_the_row_is_never_read(nkv, dtype):
+    """Rows of Nkv elements inside a NaN- (bool: True-) poisoned buffer of pitch 128: none of the three load forms — guarded
+    per-element loads (77), coalesced 16-byte tile loads (72, fp16), one load per group of four (76) — may use the neighbours' tail."""
+    B, H, Nq, D = 1, 2, 200, 64
+    q, k, v = _inputs(B, H, Nq, nkv, D, 0, seed=17)
+    if dtype == torch.bool:
+        buf = torch.ones((B, H, Nq, 128), dtype=torch.bool, device=_dev())
+        buf[..., :nkv] = torch.rand((B, H, Nq, nkv), device=_dev()) < 0.7
+        buf[..., 0] = True
+    else:
+        buf = torch.full((B, H, Nq, 128), float("nan"), device=_dev(), dtype=dtype)
+        buf[..., :nkv] = torch.randn((B, H, Nq, nkv), device=_dev()).to(dtype)
+    bias = buf[..., :nkv]                                                   # row pitch 128, last dim contiguous: passed as is
     o, lse = _cabi_forward_bias(q, k, v, bias, causal=False)
     _check(o, lse, q, k, v, bias, 0, False)

@@ -25,7 +25,7 @@ STAMP_PATH = LIB_PATH + ".stamp"
 SOURCES = ["host.cpp"]
 FRONTEND_SRC = "frontend.cpp"                      # optional compiled front end of the operator (host-only C++, g++)
 FRONTEND_PATH = os.path.join(PKG_DIR, "rocwmma_fattn", "_fa2_frontend.so")
-HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
+HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_kernel16.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
            os.path.join("gen", "isa.py"), os.path.join("gen", "fwd_d128_gen.py")]
 GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_f16_fold.inc", "fa2_fwd_d128_bf16_fold.inc",
              "fa2_fwd_d128_clobbers.inc"]   # written by gen/fwd_d128_gen.py

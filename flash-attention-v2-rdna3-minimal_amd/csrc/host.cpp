@@ -11,6 +11,7 @@
 // launch is asynchronous on the caller's stream, and failures are returned, not printf'ed
 // (reference: kernel_fp16.cu:854-863).
 #include "fa2_fwd_kernel.hip.h"
+#include "fa2_fwd_kernel16.hip.h"
 #include "fa2_fwd_d128.hip.h"
 #include "fa2_bwd_kernel.hip.h"
 
@@ -119,6 +120,35 @@ int launch_bias(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     return causal ? launch_shape<HD, BF16, true, 4, 1, true>(p, stream) : launch_shape<HD, BF16, false, 4, 1, true>(p, stream);
 }
 
+// The 8-wave kernel on v_mfma_f32_16x16x32 (fa2_fwd_kernel16.hip.h), head dims 64 and 128, 256-row workgroups.
+// FA2_MFMA16=1|0 in the environment (read once) overrides the build-time default.
+#ifndef FA2_MFMA16
+#define FA2_MFMA16 0
+#endif
+bool use_mfma16() {
+    static const bool on = [] {
+        const char* e = std::getenv("FA2_MFMA16");
+        if (e && e[0] == '1') return true;
+        if (e && e[0] == '0') return false;
+        return FA2_MFMA16 != 0;
+    }();
+    return on;
+}
+
+template <int HD, bool BF16, bool CAUSAL>
+int launch_shape16(const fa2::FwdParams& p0, hipStream_t stream) {
+    constexpr int lds_kv = 4 * fa2::Geo<HD, 8>::TILEB;
+    constexpr int lds_epi = 8 * 32 * (HD * 2 + 16);
+    constexpr int lds = lds_kv > lds_epi ? lds_kv : lds_epi;
+    fa2::FwdParams p = p0;
+    p.nqblk = (p.Nq + 255) / 256;
+    if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
+    constexpr auto kern = fa2::fwd_kernel16<HD, BF16, CAUSAL>;
+    if (int rc = set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(512), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <int HD, bool BF16, bool CAUSAL>
 int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     // D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
@@ -131,6 +161,9 @@ int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
         // (512-row workgroups <8, 2> for short KV sweeps over long Q — SDXL cross-attention, 320 workgroups = 1.25 rounds — were
         //  measured: 105 spilled VGPRs at D = 64, 20.1 us against 13.7 us: not kept)
         if (pick_rows(p) == 128) return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
+        if constexpr (HD <= 128) {
+            if (use_mfma16()) return launch_shape16<HD, BF16, CAUSAL>(p, stream);
+        }
         return launch_shape<HD, BF16, CAUSAL, kNW, kQB>(p, stream);
     } else {
         return launch_shape<HD, BF16, CAUSAL, kNW, kQB>(p, stream);

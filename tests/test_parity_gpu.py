@@ -653,6 +653,23 @@ def test_d128_fold_variant_in_a_child_process():
     assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
 
 
+def test_mfma16_variant_in_a_kid_process():
+    """The opt-in 8-wave kernel on v_mfma_f32_16x16x32 (csrc/fa2_fwd_kernel16.hip.h, FA2_MFMA16=1; head dims <= 128, 256-row
+    workgroups): a different register layout of S, P and O, a different V image swizzle and two-step row reductions, so the
+    parity cases run again in a child process (the library reads the switch once).  FA2_FWD_D128=hip takes the hand-scheduled
+    kernel out of the way so that head dim 128 reaches it too; FA2_FWD_ROWS=256 keeps small grids on the 8-wave shape."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, FA2_FWD_ROWS="256", FA2_MFMA16="1", FA2_FWD_D128="hip")
+    sel = "golden or seeded or ragged_tail or scale or large_logits or precision_shape or head_dims_masked or bnhd_layout"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
+                          "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
+
+
 def test_bnhd_d128_zero_copy():
     """[B, N, H, D] storage at head dim 128 (row stride H*D): the hand-scheduled kernel takes the same strides."""
     g = torch.Generator(device="cpu").manual_seed(16)

@@ -519,4 +519,218 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dK AND dV in one sweep at head dims 65..128, where one wave cannot hold both accumulators: wave PAIRS.
+// A workgroup owns 128 KV rows; waves g and g + 4 (same SIMD) share the 32 KV rows of group g:
+//   wave g     ("P side")   S = Q K^T (K rows as B fragments), P = 2^(S c - L), dV^T += dO^T P
+//   wave g + 4 ("dS side")  dP = dO V^T (V rows as B fragments), dS = P (dP - D), dK^T += Q^T dS
+// P crosses from the first to the second wave once per tile through a 4-KiB LDS slot per pair, as the very 16-bit B
+// fragments the dV product consumes (same lane, same registers: S^T and dP^T have the same layout) — so S and P are formed once
+// for both products: 4 GEMMs per (kv, q) pair instead of the 5 of the two separate passes, 7 instead of 8 for the whole backward.
+// Each tile has two phases separated by a barrier: {S, exp | dP} and {dV | dS, dK}; the transcendental / VALU stretch of one wave
+// of a pair runs beside the MFMAs of the other.  Stage: Q row | dO row | Q tr | dO tr | L | D, two stages (129 KiB) + 16 KiB of slots.
+template <int HD, bool BF16, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p) {
+    constexpr int NW = 8;
+    using L_ = BwdLane<HD, NW>;
+    constexpr int kRows = 128;
+    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NT = 4, STAGEB = NT * TILEB + 512, XCHB = 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    const lds_char_ptr smem = (lds_char_ptr)smem_generic;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave & 3;
+    const bool ds_side = wave >= 4;
+    const lds_char_ptr xch = smem + 2 * STAGEB + grp * XCHB + lane * 16;
+
+    const int nbh = p.B * p.H, bid = blockIdx.x;
+    int bh, kblk;
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;
+        if (CAUSAL) { bh = (bid & 7) + 8 * (slot % hpx); kblk = slot / hpx; }
+        else { bh = (bid & 7) + 8 * (slot / p.nblk); kblk = slot % p.nblk; }
+    } else if (CAUSAL) { bh = bid % nbh; kblk = bid / nbh; }
+    else { bh = bid / p.nblk; kblk = bid % p.nblk; }
+    const int b = bh / p.H, h = bh % p.H;
+    const int kv0 = kblk * kRows, kvw0 = kv0 + 32 * grp, kvrow = kvw0 + l31;
+    const int kr = kvrow < p.Nkv ? kvrow : p.Nkv - 1;
+
+    L_ ln;
+    ln.init(tid, lane, p.D);
+    u32x4 bf[KS];            // the pair's own rows as B fragments: K on the P side, V on the dS side
+    {
+        const uint16_t* rp = ds_side ? (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1] + (int64_t)kr * p.vs[2]
+                                     : (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1] + (int64_t)kr * p.ks[2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bf[ks] = 16 * ks + 8 * hi < p.D ? *(const u32x4*)(rp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    const uint16_t* qbase = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1];
+    const uint16_t* gbase = (const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1];
+    const auto qrs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
+    const auto grs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, p.do_bytes, 0x00020000);
+    const auto lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + b * p.ls[0] + h * p.ls[1]), 0, p.l_bytes, 0x00020000);
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + b * p.ls[0] + h * p.ls[1]), 0, p.l_bytes, 0x00020000);
+    const uint32_t q_rowb = (uint32_t)p.qs[2] * 2u, g_rowb = (uint32_t)p.dos[2] * 2u;
+
+    const int ntiles = (p.Nq + kKvTile - 1) / kKvTile;
+    const int tile0 = CAUSAL ? kv0 / kKvTile : 0;
+    const int first_plain = CAUSAL ? (kvw0 + 31 + kKvTile - 1) / kKvTile : 0;
+
+    auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
+        const lds_char_ptr base = smem + stage * STAGEB;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
+            const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
+            const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
+            dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
+            dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                       // dO row-form
+            dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);                   // Q tr-form
+            dma16_to_lds3(grs, dst + 3 * TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
+        }
+        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+        if (wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+    };
+
+    f32x16 acc[DT];          // dV^T (P side) or dK^T / scale (dS side)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const float c = p.c;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_cptr;
+    typedef __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+
+    auto accumulate = [&](lds_char_ptr tT, const u32x4 (&xf)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const lds_char_ptr va = tT + ln.vr_off[dt] + 16 * ks * ROWB;
+                const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
+                const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], acc[dt]);
+            }
+    };
+
+    if (tile0 < ntiles) stage_load(tile0, 0);
+    __syncthreads();
+    for (int tile = tile0; tile < ntiles; ++tile) {
+        const int st = (tile - tile0) & 1;
+        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+        // (a pair whose rows all lie above the tile's q range — the first tile of groups 2, 3 under a causal mask — runs the tile
+        //  like any other: every P is masked to zero, so it contributes nothing)
+        const bool masked = CAUSAL && tile < first_plain;
+        const lds_char_ptr qR = smem + st * STAGEB;
+        const lds_char_ptr lt = qR + NT * TILEB;
+        const int q0t = tile * kKvTile;
+        if (!ds_side) {
+            u32x4 xf[4];
+            {
+                f32x16 s0, s1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {                     // S[q, kv] = Q K^T  (lane = kv)
+                    s0 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks]), bf[ks], s0);
+                    s1 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks] + 32 * ROWB), bf[ks], s1);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 L0 = *(lds_f32x4_cptr)(lt + (8 * g4 + 4 * hi) * 4);
+                    const f32x4 L1 = *(lds_f32x4_cptr)(lt + (32 + 8 * g4 + 4 * hi) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
+                        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
+                    }
+                }
+                if (CAUSAL && masked) {                               // pairs with kv > q contribute nothing (wave-uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kvrow > qi) s0[r] = 0.f;
+                        if (kvrow > qi + 32) s1[r] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
+                    xf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
+                    xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
+                    xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(lds_u32x4_ptr)(xch + 1024 * i) = xf[i];
+            }
+            __syncthreads();                                          // P is in the pair's slot
+            accumulate(qR + 3 * TILEB, xf);                // dV^T += dO^T P
+        } else {
+            f32x16 d0, d1;
+            {
+                const lds_char_ptr gR = qR + TILEB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {                     // dP[q, kv] = dO V^T
+                    d0 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks]), bf[ks], d0);
+                    d1 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks] + 32 * ROWB), bf[ks], d1);
+                }
+            }
+            __syncthreads();
+            {
+                u32x4 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *(lds_u32x4_ptr)(xch + 1024 * i);
+                float pv[32];                                          // P as the dV product sees it (16-bit), in register order
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            pv[8 * j + 2 * i] = __uint_as_float(xf[j][i] << 16);
+                            pv[8 * j + 2 * i + 1] = __uint_as_float(xf[j][i] & 0xffff0000u);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x8 hv = __builtin_bit_cast(f16x8, xf[j]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pv[8 * j + e] = (float)hv[e];
+                    }
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 D0 = *(lds_f32x4_cptr)(lt + 256 + (8 * g4 + 4 * hi) * 4);
+                    const f32x4 D1 = *(lds_f32x4_cptr)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        d0[r] = pv[r] * (d0[r] - D0[e]);               // dS / scale; `scale` is applied once, to the finished dK
+                        d1[r] = pv[16 + r] * (d1[r] - D1[e]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xf[0][i] = pack2<BF16>(d0[2 * i], d0[2 * i + 1]);
+                    xf[1][i] = pack2<BF16>(d0[8 + 2 * i], d0[8 + 2 * i + 1]);
+                    xf[2][i] = pack2<BF16>(d1[2 * i], d1[2 * i + 1]);
+                    xf[3][i] = pack2<BF16>(d1[8 + 2 * i], d1[8 + 2 * i + 1]);
+                }
+                accumulate(qR + 2 * TILEB, xf);                        // dK^T += Q^T dS
+            }
+        }
+        __syncthreads();
+    }
+    if (kvrow < p.Nkv) {
+        uint16_t* op = ds_side ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
+                               : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
+        store_acc_t<BF16, DT>(acc, op, hi, ds_side ? p.scale : 1.0f, p.D);
+    }
+}
+
 }  // namespace fa2

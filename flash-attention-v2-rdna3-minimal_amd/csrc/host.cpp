@@ -275,6 +275,30 @@ int launch_range(const fa2::FwdParams& p, bool causal, hipStream_t stream) {
 #define FA2_BWD_FUSE_MAX_HD 64
 #endif
 
+// Backward at head dims 65..128: dK and dV as ONE sweep of wave pairs (7 GEMM-equivalents for the whole backward) instead of two
+// separate sweeps (8).  FA2_BWD_PAIR=0|1 in the environment (read once) overrides the build-time default (A/B measurements).
+#ifndef FA2_BWD_PAIR
+#define FA2_BWD_PAIR 1
+#endif
+bool use_bwd_pair() {
+    static const bool on = [] {
+        const char* e = std::getenv("FA2_BWD_PAIR");
+        if (e && e[0] == '1') return true;
+        if (e && e[0] == '0') return false;
+        return FA2_BWD_PAIR != 0;
+    }();
+    return on;
+}
+
+template <int HD, bool BF16, bool CAUSAL>
+int launch_bwd_pair(const fa2::BwdParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * (4 * fa2::Geo<HD, 8>::TILEB + 512) + 4 * 4096;
+    constexpr auto kern = fa2::bwd_dkv_pair_kernel<HD, BF16, CAUSAL>;
+    if (int rc = set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <int HD, bool BF16, bool CAUSAL>
 int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
@@ -288,6 +312,14 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
         p.nblk = (p.Nq + kRows - 1) / kRows;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
+    }
+    if constexpr (HD == 128 && NW == 8) {
+        // D in 65..128: dK and dV in one sweep by wave pairs (bwd_dkv_pair_kernel): 128 KV rows per workgroup, S and P formed once
+        if (use_bwd_pair()) {
+            p.nblk = (p.Nkv + 127) / 128;
+            if ((int64_t)p.B * p.H * p.nblk > 0x7fffffffLL) return FA2_ERR_GRID;
+            return launch_bwd_pair<HD, BF16, CAUSAL>(p, stream);
+        }
     }
     p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows
     if constexpr (HD <= FA2_BWD_FUSE_MAX_HD && NW == 8) {

@@ -168,3 +168,41 @@ def test_backward_above_256_is_refused_not_wrong():
     o = FlashAttentionFunction.apply(q, k, v, None, False)
     with pytest.raises(RuntimeError, match="head dim"):
         o.backward(torch.ones_like(o))
+
+
+PAIR_SHAPES = [(1, 2, 129, 127, 128), (2, 3, 200, 333, 96), (1, 8, 640, 640, 128), (1, 1, 64, 700, 72), (2, 2, 513, 255, 120)]
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES)
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_wave_pair_dkdv_pass_against_oracle(shape, dt, causal):
+    """Head dims 65..128 run dK and dV as ONE sweep of wave pairs (bwd_dkv_pair_kernel: 128 KV rows per workgroup, P crosses from
+    the dV wave to the dK wave through LDS as the 16-bit fragments the dV product consumes).  Shapes chosen for it: KV rows that are
+    not multiples of 128 or 32, one- and many-block sweeps, Nq shorter and longer than Nkv under the causal mask (pairs whose
+    rows lie entirely above the first tile's q range), head dims with a masked column tail."""
+    B, H, Nq, Nkv, D = shape
+    g = torch.Generator(device="cpu").manual_seed(hash(shape) % 1000 + 7 * dt)
+    mk = lambda n: torch.randn((B, H, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(Nq), mk(Nkv), mk(Nkv), mk(Nq)
+    o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+    _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+    o2, lse2, grads2 = _cabi_fwd_bwd(q, k, v, do, causal)
+    for a, b in zip(grads, grads2):
+        assert torch.equal(a, b), "the pair pass is not deterministic"
+
+
+def test_separate_dk_dv_passes_in_a_child_process():
+    """FA2_BWD_PAIR=0 selects the two separate KV-owned sweeps (dV, then dK) at head dims 65..128 — the A/B baseline of the pair
+    pass and the path of a build with -DFA2_BWD_PAIR=0.  The library reads the switch once, so the backward parity cases run again
+    in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, FA2_BWD_PAIR="0")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_backward_gpu.py"), "-m", "gpu", "-q", "-x",
+                          "-k", "golden or seeded or wave_pair or head_dims or deterministic"], capture_output=True, text=True,
+                         timeout=1200, cwd=root, env=env)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]

@@ -239,8 +239,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
     if (CAUSAL) { const int nc = (qw0 + 1) / kKvTile; n_plain = nc < n_plain ? nc : n_plain; }
     n_plain = n_plain < ntiles_w ? n_plain : ntiles_w;
 
-    auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_t)::value;
+    // ONE tile body: two bodies (masked / plain) joined by a branch made the register allocator copy the 64 accumulator registers
+    // at the join in every iteration (64 v_mov per tile in the ISA); the mask is a wave-uniform block instead.
+    auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {
         {
             const lds_char_ptr kR = smem + st * STAGEB;
             const lds_char_ptr vR = kR + TILEB;
@@ -259,11 +260,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
             // P^T = 2^(S^T c - L); masked entries -> 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -Lq));
-                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -Lq));
-                s0[r] = MASKED && kvi > lim ? 0.f : p0;
-                s1[r] = MASKED && kvi + 32 > lim ? 0.f : p1;
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -Lq));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -Lq));
+            }
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kvi > lim) s0[r] = 0.f;
+                    if (kvi + 32 > lim) s1[r] = 0.f;
+                }
             }
             f32x16 d0, d1;
 #pragma unroll
@@ -304,8 +310,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
     for (int tile = 0; tile < ntiles; ++tile) {
         const int st = DBUF ? tile & 1 : 0;
         if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
-        if (DBUF && tile < n_plain) tile_body(tile, st, std::false_type{});
-        else if (tile < ntiles_w) tile_body(tile, st, std::true_type{});       // (NW = 4: one body keeps the code and the registers down)
+        if (!CAUSAL || tile < ntiles_w) tile_body(tile, st, tile >= n_plain);   // (causal: a wave past its diagonal only keeps the barriers)
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
@@ -403,8 +408,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     // Q tiles from first_plain on lie entirely at or below this wave's KV rows' diagonal (q >= kv for every pair)
     const int first_plain = CAUSAL ? (kvw0 + 31 + kKvTile - 1) / kKvTile : 0;
 
-    auto tile_body = [&](int tile, int st, auto masked_t) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_t)::value;
+    auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {       // one body: see bwd_dq_kernel
         {
             const lds_char_ptr qR = smem + st * STAGEB;
             const lds_char_ptr lt = qR + NT * TILEB;
@@ -429,33 +433,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
             }
             const int q0t = tile * kKvTile;
             // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
                 const f32x4 L0 = *(const __attribute__((address_space(3))) f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
                 const f32x4 L1 = *(const __attribute__((address_space(3))) f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
-                f32x4 D0, D1;
-                if constexpr (WANT_DK) {
-                    D0 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (8 * g4 + 4 * hi) * 4);
-                    D1 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
-                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const int qi = q0t + e + 8 * g4 + 4 * hi;
-                    float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
-                    float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
-                    if constexpr (MASKED) {           // causal: pairs with kv > q contribute nothing
-                        if (kvrow > qi) p0 = 0.f;
-                        if (kvrow > qi + 32) p1 = 0.f;
+                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
+                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
+                }
+            }
+            if (CAUSAL && masked) {               // causal: pairs with kv > q contribute nothing (wave-uniform branch)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kvrow > qi) s0[r] = 0.f;
+                    if (kvrow > qi + 32) s1[r] = 0.f;
+                }
+            }
+            if constexpr (WANT_DK) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 D0 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (8 * g4 + 4 * hi) * 4);
+                    const f32x4 D1 = *(const __attribute__((address_space(3))) f32x4*)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        if constexpr (BOTH) { d0[r] = s0[r] * (d0[r] - D0[e]); d1[r] = s1[r] * (d1[r] - D1[e]); }   // dS / scale, P kept
+                        else {                        // dS / scale; `scale` is applied once, to the finished dK
+                            s0[r] = s0[r] * (d0[r] - D0[e]);
+                            s1[r] = s1[r] * (d1[r] - D1[e]);
+                        }
                     }
-                    if constexpr (BOTH) { d0[r] = p0 * (d0[r] - D0[e]); d1[r] = p1 * (d1[r] - D1[e]); }   // dS / scale, P kept
-                    else if constexpr (WANT_DK) {     // dS / scale; `scale` is applied once, to the finished dK
-                        p0 = p0 * (d0[r] - D0[e]);
-                        p1 = p1 * (d1[r] - D1[e]);
-                    }
-                    s0[r] = p0;
-                    s1[r] = p1;
                 }
             }
             u32x4 xf[4];   // P (dV) or dS (dK) as B fragments: contraction index = q
@@ -503,8 +514,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     for (int tile = tile0; tile < ntiles; ++tile) {
         const int st = DBUF ? (tile - tile0) & 1 : 0;
         if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
-        if (DBUF && tile >= first_plain) tile_body(tile, st, std::false_type{});
-        else if (tile >= tile0_w) tile_body(tile, st, std::integral_constant<bool, CAUSAL>{});
+        if (!CAUSAL || tile >= tile0_w) tile_body(tile, st, CAUSAL && tile < first_plain);
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
@@ -616,115 +626,117 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
             }
     };
 
+    // One tile loop PER ROLE (the role branch outside the loop): with both roles inside one loop the allocator copied the 64
+    // accumulator registers at the join in every iteration.  Both loops hold the same two barriers per tile.
+    // (A pair whose rows all lie above a tile's q range — the first tile of groups 2, 3 under a causal mask — runs the tile like
+    //  any other: every P is masked to zero, so it contributes nothing.)
     if (tile0 < ntiles) stage_load(tile0, 0);
     __syncthreads();
-    for (int tile = tile0; tile < ntiles; ++tile) {
-        const int st = (tile - tile0) & 1;
-        if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
-        // (a pair whose rows all lie above the tile's q range — the first tile of groups 2, 3 under a causal mask — runs the tile
-        //  like any other: every P is masked to zero, so it contributes nothing)
-        const bool masked = CAUSAL && tile < first_plain;
-        const lds_char_ptr qR = smem + st * STAGEB;
-        const lds_char_ptr lt = qR + NT * TILEB;
-        const int q0t = tile * kKvTile;
-        if (!ds_side) {
-            u32x4 xf[4];
-            {
-                f32x16 s0, s1;
+    if (!ds_side) {
+        for (int tile = tile0; tile < ntiles; ++tile) {
+            const int st = (tile - tile0) & 1;
+            if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+            const lds_char_ptr qR = smem + st * STAGEB;
+            const lds_char_ptr lt = qR + NT * TILEB;
+            f32x16 s0, s1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {                     // S[q, kv] = Q K^T  (lane = kv)
-                    s0 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks]), bf[ks], s0);
-                    s1 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks] + 32 * ROWB), bf[ks], s1);
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 L0 = *(lds_f32x4_cptr)(lt + (8 * g4 + 4 * hi) * 4);
-                    const f32x4 L1 = *(lds_f32x4_cptr)(lt + (32 + 8 * g4 + 4 * hi) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g4 + e;
-                        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
-                        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
-                    }
-                }
-                if (CAUSAL && masked) {                               // pairs with kv > q contribute nothing (wave-uniform branch)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (kvrow > qi) s0[r] = 0.f;
-                        if (kvrow > qi + 32) s1[r] = 0.f;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
-                    xf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
-                    xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
-                    xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *(lds_u32x4_ptr)(xch + 1024 * i) = xf[i];
+            for (int ks = 0; ks < KS; ++ks) {                         // S[q, kv] = Q K^T  (lane = kv)
+                s0 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks]), bf[ks], s0);
+                s1 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks] + 32 * ROWB), bf[ks], s1);
             }
-            __syncthreads();                                          // P is in the pair's slot
-            accumulate(qR + 3 * TILEB, xf);                // dV^T += dO^T P
-        } else {
-            f32x16 d0, d1;
-            {
-                const lds_char_ptr gR = qR + TILEB;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 L0 = *(lds_f32x4_cptr)(lt + (8 * g4 + 4 * hi) * 4);
+                const f32x4 L1 = *(lds_f32x4_cptr)(lt + (32 + 8 * g4 + 4 * hi) * 4);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {                     // dP[q, kv] = dO V^T
-                    d0 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks]), bf[ks], d0);
-                    d1 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks] + 32 * ROWB), bf[ks], d1);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
+                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
                 }
+            }
+            if (CAUSAL && tile < first_plain) {                       // pairs with kv > q contribute nothing (wave-uniform branch)
+                const int q0t = tile * kKvTile;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kvrow > qi) s0[r] = 0.f;
+                    if (kvrow > qi + 32) s1[r] = 0.f;
+                }
+            }
+            u32x4 xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
+                xf[1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
+                xf[2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
+                xf[3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(lds_u32x4_ptr)(xch + 1024 * i) = xf[i];
+            __syncthreads();                                          // P is in the pair's slot
+            accumulate(qR + 3 * TILEB, xf);                           // dV^T += dO^T P
+            __syncthreads();
+        }
+    } else {
+        for (int tile = tile0; tile < ntiles; ++tile) {
+            const int st = (tile - tile0) & 1;
+            if (tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
+            const lds_char_ptr qR = smem + st * STAGEB;
+            const lds_char_ptr lt = qR + NT * TILEB;
+            const lds_char_ptr gR = qR + TILEB;
+            f32x16 d0, d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                         // dP[q, kv] = dO V^T
+                d0 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks]), bf[ks], d0);
+                d1 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks] + 32 * ROWB), bf[ks], d1);
             }
             __syncthreads();
-            {
-                u32x4 xf[4];
+            u32x4 xf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = *(lds_u32x4_ptr)(xch + 1024 * i);
-                float pv[32];                                          // P as the dV product sees it (16-bit), in register order
-                if constexpr (BF16) {
+            for (int i = 0; i < 4; ++i) xf[i] = *(lds_u32x4_ptr)(xch + 1024 * i);
+            float pv[32];                                              // P as the dV product sees it (16-bit), in register order
+            if constexpr (BF16) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            pv[8 * j + 2 * i] = __uint_as_float(xf[j][i] << 16);
-                            pv[8 * j + 2 * i + 1] = __uint_as_float(xf[j][i] & 0xffff0000u);
-                        }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f16x8 hv = __builtin_bit_cast(f16x8, xf[j]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pv[8 * j + e] = (float)hv[e];
+                    for (int i = 0; i < 4; ++i) {
+                        pv[8 * j + 2 * i] = __uint_as_float(xf[j][i] << 16);
+                        pv[8 * j + 2 * i + 1] = __uint_as_float(xf[j][i] & 0xffff0000u);
                     }
-                }
+            } else {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 D0 = *(lds_f32x4_cptr)(lt + 256 + (8 * g4 + 4 * hi) * 4);
-                    const f32x4 D1 = *(lds_f32x4_cptr)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+                for (int j = 0; j < 4; ++j) {
+                    const f16x8 hv = __builtin_bit_cast(f16x8, xf[j]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g4 + e;
-                        d0[r] = pv[r] * (d0[r] - D0[e]);               // dS / scale; `scale` is applied once, to the finished dK
-                        d1[r] = pv[16 + r] * (d1[r] - D1[e]);
-                    }
+                    for (int e = 0; e < 8; ++e) pv[8 * j + e] = (float)hv[e];
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xf[0][i] = pack2<BF16>(d0[2 * i], d0[2 * i + 1]);
-                    xf[1][i] = pack2<BF16>(d0[8 + 2 * i], d0[8 + 2 * i + 1]);
-                    xf[2][i] = pack2<BF16>(d1[2 * i], d1[2 * i + 1]);
-                    xf[3][i] = pack2<BF16>(d1[8 + 2 * i], d1[8 + 2 * i + 1]);
-                }
-                accumulate(qR + 2 * TILEB, xf);                        // dK^T += Q^T dS
             }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 D0 = *(lds_f32x4_cptr)(lt + 256 + (8 * g4 + 4 * hi) * 4);
+                const f32x4 D1 = *(lds_f32x4_cptr)(lt + 256 + (32 + 8 * g4 + 4 * hi) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    d0[r] = pv[r] * (d0[r] - D0[e]);                   // dS / scale; `scale` is applied once, to the finished dK
+                    d1[r] = pv[16 + r] * (d1[r] - D1[e]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[0][i] = pack2<BF16>(d0[2 * i], d0[2 * i + 1]);
+                xf[1][i] = pack2<BF16>(d0[8 + 2 * i], d0[8 + 2 * i + 1]);
+                xf[2][i] = pack2<BF16>(d1[2 * i], d1[2 * i + 1]);
+                xf[3][i] = pack2<BF16>(d1[8 + 2 * i], d1[8 + 2 * i + 1]);
+            }
+            accumulate(qR + 2 * TILEB, xf);                            // dK^T += Q^T dS
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (kvrow < p.Nkv) {
         uint16_t* op = ds_side ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]

@@ -32,7 +32,7 @@ print(" ".join("%%8.1f" %% x for x in r))
 
 def main():
     print("%-22s %8s %8s %8s %8s %8s %8s   (us per backward)" % ("setting", "c2", "c3", "c4", "B8", "N1024", "D80"))
-    settings = [("separate passes", {"FA2_BWD_PAIR": "0"})] + [("pair var %d" % v, {"FA2_BWD_PAIR": "1", "FA2_BWD_PAIR_VAR": str(v)}) for v in (0, 2, 8)]
+    settings = [("separate passes", {"FA2_BWD_PAIR": "0"})] + [("wave-pair dK+dV pass", {"FA2_BWD_PAIR": "1"})]
     for rep in range(2):
         for name, env in settings:
             e = dict(os.environ); e.update(env)

@@ -214,16 +214,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams
     if (CAUSAL) { const int nt_w = (qw0 + 31) / kKvTile + 1; ntiles_w = nt_w < ntiles ? nt_w : ntiles; }
     asm volatile("" : "+s"(ntiles_w));   // opaque: stops the non-causal build from peeling the tail tile into a register-hungry shape
 
+    // per-lane source offsets of the staging loads within a tile (loop-invariant); the tile's own byte offset rides in soffset
+    // (kept for the 8-wave kernels only: the 4-wave ones have 8 passes per tile and no registers to spare)
+    constexpr int NKEEP = NW == 8 ? NPASS : 1;
+    uint32_t kr_src[NKEEP], vr_src[NKEEP], kt_src[NKEEP];
+    if constexpr (NW == 8) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            kr_src[i] = (uint32_t)ln.rowi[i] * k_rowb + ln.r_src[i];
+            vr_src[i] = (uint32_t)ln.rowi[i] * v_rowb + ln.r_src[i];
+            kt_src[i] = (uint32_t)ln.rowi[i] * k_rowb + ln.t_src[i];
+        }
+    }
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
         const lds_char_ptr base = smem + stage * STAGEB;
+        const uint32_t ksoff = (uint32_t)tile * kKvTile * k_rowb, vsoff = (uint32_t)tile * kKvTile * v_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
-            const uint32_t krow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * k_rowb;
-            const uint32_t vrow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * v_rowb;
-            dma16_to_lds3(krs, dst, krow + ln.r_src[i], 0);
-            dma16_to_lds3(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
-            dma16_to_lds3(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+            if constexpr (NW == 8) {
+                dma16_to_lds3(krs, dst, FA2_TILE_OFF(kr_src[i], ksoff));
+                dma16_to_lds3(vrs, dst + TILEB, FA2_TILE_OFF(vr_src[i], vsoff));
+                dma16_to_lds3(krs, dst + 2 * TILEB, FA2_TILE_OFF(kt_src[i], ksoff));
+            } else {
+                const uint32_t krow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * k_rowb;
+                const uint32_t vrow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * v_rowb;
+                dma16_to_lds3(krs, dst, krow + ln.r_src[i], 0);
+                dma16_to_lds3(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
+                dma16_to_lds3(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+            }
         }
     };
 
@@ -378,24 +397,49 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     const int tile0 = CAUSAL ? kv0 / kKvTile : 0;
     const int tile0_w = CAUSAL ? kvw0 / kKvTile : 0;     // this wave's first useful tile
 
+    // per-lane source offsets of the staging loads within a tile (loop-invariant); the tile's own byte offset rides in soffset
+    // (kept for the 8-wave kernels only: the 4-wave ones have 8 passes per tile and no registers to spare)
+    constexpr int NKEEP = NW == 8 ? NPASS : 1;
+    uint32_t qr_src[NKEEP], qt_src[NKEEP], gr_src[NKEEP], gt_src[NKEEP];
+    if constexpr (NW == 8) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            qr_src[i] = (uint32_t)ln.rowi[i] * q_rowb + ln.r_src[i];
+            qt_src[i] = (uint32_t)ln.rowi[i] * q_rowb + ln.t_src[i];
+            gr_src[i] = (uint32_t)ln.rowi[i] * g_rowb + ln.r_src[i];
+            gt_src[i] = (uint32_t)ln.rowi[i] * g_rowb + ln.t_src[i];
+        }
+    }
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
         const lds_char_ptr base = smem + stage * STAGEB;
+        const uint32_t qsoff = (uint32_t)tile * kKvTile * q_rowb, gsoff = (uint32_t)tile * kKvTile * g_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
-            const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
-            const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
-            dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
-            if constexpr (WANT_DK) {
-                dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                   // dO row-form
-                dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);               // Q tr-form
-                if constexpr (BOTH) dma16_to_lds3(grs, dst + 3 * TILEB, grow_b + ln.t_src[i], 0);   // dO tr-form
+            if constexpr (NW == 8) {
+                dma16_to_lds3(qrs, dst, FA2_TILE_OFF(qr_src[i], qsoff));                               // Q row-form
+                if constexpr (WANT_DK) {
+                    dma16_to_lds3(grs, dst + TILEB, FA2_TILE_OFF(gr_src[i], gsoff));                   // dO row-form
+                    dma16_to_lds3(qrs, dst + 2 * TILEB, FA2_TILE_OFF(qt_src[i], qsoff));               // Q tr-form
+                    if constexpr (BOTH) dma16_to_lds3(grs, dst + 3 * TILEB, FA2_TILE_OFF(gt_src[i], gsoff));   // dO tr-form
+                } else {
+                    dma16_to_lds3(grs, dst + TILEB, FA2_TILE_OFF(gt_src[i], gsoff));                   // dO tr-form
+                }
             } else {
-                dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
+                const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
+                const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
+                dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);
+                if constexpr (WANT_DK) {
+                    dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);
+                    dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);
+                } else {
+                    dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);
+                }
             }
         }
-        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
-        if (WANT_DK && wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+        const uint32_t lsoff = (uint32_t)tile * kKvTile * 4u;
+        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
+        if (WANT_DK && wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
     };
 
     f32x16 acc[DT], accv[BOTH ? DT : 1];
@@ -588,20 +632,29 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
     const int tile0 = CAUSAL ? kv0 / kKvTile : 0;
     const int first_plain = CAUSAL ? (kvw0 + 31 + kKvTile - 1) / kKvTile : 0;
 
+    // per-lane source offsets of the staging loads within a tile (loop-invariant); the tile's own byte offset rides in soffset
+    uint32_t qr_src[NPASS], qt_src[NPASS], gr_src[NPASS], gt_src[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        qr_src[i] = (uint32_t)ln.rowi[i] * q_rowb + ln.r_src[i];
+        qt_src[i] = (uint32_t)ln.rowi[i] * q_rowb + ln.t_src[i];
+        gr_src[i] = (uint32_t)ln.rowi[i] * g_rowb + ln.r_src[i];
+        gt_src[i] = (uint32_t)ln.rowi[i] * g_rowb + ln.t_src[i];
+    }
     auto stage_load = [&](int tile, int stage) __attribute__((always_inline)) {
         const lds_char_ptr base = smem + stage * STAGEB;
+        const uint32_t qsoff = (uint32_t)tile * kKvTile * q_rowb, gsoff = (uint32_t)tile * kKvTile * g_rowb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const lds_char_ptr dst = base + (wave * 64 + NW * 64 * i) * 16;
-            const uint32_t qrow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * q_rowb;
-            const uint32_t grow_b = (uint32_t)(tile * kKvTile + ln.rowi[i]) * g_rowb;
-            dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);                               // Q row-form
-            dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);                       // dO row-form
-            dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);                   // Q tr-form
-            dma16_to_lds3(grs, dst + 3 * TILEB, grow_b + ln.t_src[i], 0);                   // dO tr-form
+            dma16_to_lds3(qrs, dst, FA2_TILE_OFF(qr_src[i], qsoff));                        // Q row-form
+            dma16_to_lds3(grs, dst + TILEB, FA2_TILE_OFF(gr_src[i], gsoff));                // dO row-form
+            dma16_to_lds3(qrs, dst + 2 * TILEB, FA2_TILE_OFF(qt_src[i], qsoff));            // Q tr-form
+            dma16_to_lds3(grs, dst + 3 * TILEB, FA2_TILE_OFF(gt_src[i], gsoff));            // dO tr-form
         }
-        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
-        if (wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, (uint32_t)(tile * kKvTile + lane) * 4u, 0);
+        const uint32_t lsoff = (uint32_t)tile * kKvTile * 4u;
+        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
+        if (wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
     };
 
     f32x16 acc[DT];          // dV^T (P side) or dK^T / scale (dS side)

@@ -128,7 +128,8 @@ int fa2_fwd_bias(int dtype,
  *   dq/dk/dv : outputs, caller-owned, every element written (no zero-init needed)
  *   delta_ws : caller-owned f32 workspace addressed like lse (lse_strides), >= Nq floats per (b,h):
  *              receives D_i = rowsum(dO_i * O_i) (the reference's `Di`, kernel_fp16.cu:605-631)
- * Three launches on `hip_stream` (dQ — which also fills delta_ws —, dV, dK; D <= 64: dK and dV are one fused launch); deterministic: every output element has one owner — the
+ * Two launches on `hip_stream` at D <= 128 (dQ — which also fills delta_ws —, then dK and dV in one sweep: one fused pass at D <= 64, wave pairs at D <= 128),
+ * three above (dQ, dV, dK); deterministic: every output element has one owner — the
  * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
  * Gradients are those of O = softmax(scale * Q K^T [+ causal mask]) V, i.e. what torch autograd returns.
  * Head dims: multiples of 8 up to 256 (the forward reaches 512; above 256 the backward returns FA2_ERR_HEAD_DIM).  D > 128 runs

@@ -573,6 +573,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     }
 }
 
+// Mid-tile barrier of the pair pass: only the LDS hand-over of P has to be complete — unlike __syncthreads() it does not wait for the
+// next tile's staging loads in flight (vmcnt), which have the whole tile to land (the end-of-tile __syncthreads() drains them).
+__device__ __forceinline__ void pair_mid_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // dK AND dV in one sweep at head dims 65..128, where one wave cannot hold both accumulators: wave PAIRS.
 // A workgroup owns 128 KV rows; waves g and g + 4 (same SIMD) share the 32 KV rows of group g:
@@ -694,11 +702,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
             f32x16 s0, s1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+            __builtin_amdgcn_s_setprio(3);            // the S products ahead of the partner wave's dP products: the exp stretch then runs beside those
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {                         // S[q, kv] = Q K^T  (lane = kv)
                 s0 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks]), bf[ks], s0);
                 s1 = mfma16<BF16>(lds_load128(qR + ln.kr_off[ks] + 32 * ROWB), bf[ks], s1);
             }
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 L0 = *(lds_f32x4_cptr)(lt + (8 * g4 + 4 * hi) * 4);
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) *(lds_u32x4_ptr)(xch + 1024 * i) = xf[i];
-            __syncthreads();                                          // P is in the pair's slot
+            pair_mid_barrier();                                       // P is in the pair's slot
             accumulate(qR + 3 * TILEB, xf);                           // dV^T += dO^T P
             __syncthreads();
         }
@@ -748,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
                 d0 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks]), bf[ks], d0);
                 d1 = mfma16<BF16>(lds_load128(gR + ln.kr_off[ks] + 32 * ROWB), bf[ks], d1);
             }
-            __syncthreads();
+            pair_mid_barrier();
             u32x4 xf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *(lds_u32x4_ptr)(xch + 1024 * i);

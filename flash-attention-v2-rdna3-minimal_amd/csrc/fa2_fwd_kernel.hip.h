@@ -224,8 +224,15 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // A row whose every score is -inf (fully masked) produces O = 0 and lse = -inf.
 // (BIAS at D = 64 with two workgroups per CU — 256 registers per wave instead of the 434 the compiler spreads one over — spills
 //  112 VGPRs: not used)
+// Register budget: 4-wave workgroups get the 512-register budget of one wave per SIMD only where they need it (bias registers, head dims
+// above 128, two q blocks per wave); the plain 128-row kernels of head dims <= 128 fit 256 registers, and with the smaller budget the
+// compiler keeps the accumulators out of the AGPRs (under the 512 budget it parked them there and wrapped every rescale in
+// v_accvgpr_read / write: 11-13 register moves per MFMA in the ISA) and two workgroups can share a CU.
+template <int HD, int NW, int QB, bool BIAS>
+constexpr int fwd_min_waves_per_simd() { return (NW == 4 && !BIAS && QB == 1 && HD <= 128) ? 2 : (NW + 3) / 4; }
+
 template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
-__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>())) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
     using GV_ = Geo<HDV, NW>;  // V tile image

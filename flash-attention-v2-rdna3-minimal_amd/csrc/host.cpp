@@ -66,10 +66,21 @@ int forced_rows() {
 // number of busy CUs at the price of staging every K/V tile for half as many rows.  Measured (tools/rows_probe.py, MI355X):
 // 64 workgroups -> 128 of 128 rows: B1 H16 N1024 D128 25.1 -> 20.5 us, B1 H8 N2048 D128 44.1 -> 35.3, B2 H8 N1024 D80 24.0 -> 19.9;
 // at 160 workgroups (SDXL 32x32 self-attention) and above the big shape wins (19.9 vs 23.9 us), 64-row workgroups never do.
-int pick_rows(const fa2::FwdParams& p) {
+// Between one and one and a half rounds of 256-row workgroups at head dims <= 64 (non-causal), 128-row workgroups all the way — two per CU since
+// they fit the 256-register budget (fwd_min_waves_per_simd) — beat both the plain grid and the tail split (tools/rows_probe.py, r05m: SDXL 64x64
+// self-attention B2 H10 N4096 D64, 320 workgroups: 130.8 plain / 121.2 tail split / 117.4 us; B1 H24 N3072 D64, 288: 97.0 / 90.9 / 84.5 us); at exactly one
+// round (B2 H8 N4096: 66 vs 73 us) and below (160 workgroups: 20.0 vs 22.6 us) the 8-wave shape stays ahead.
+bool short_second_round(const fa2::FwdParams& p, bool causal) {
+    if (causal || p.D > 64) return false;
+    const int64_t w = (int64_t)p.nbh * ((p.Nq + 255) / 256);
+    return w > 256 && w <= 384;
+}
+
+int pick_rows(const fa2::FwdParams& p, bool causal = true) {
     const int f = forced_rows();
     if (f == 128 || f == 256) return f;
     if (p.rows_hint == 128 || p.rows_hint == 256) return p.rows_hint;
+    if (short_second_round(p, causal)) return 128;
     return (int64_t)p.nbh * ((p.Nq + 255) / 256) <= 96 ? 128 : 256;
 }
 
@@ -82,6 +93,7 @@ int pick_rows(const fa2::FwdParams& p) {
 int tail_split_heads(const fa2::FwdParams& p, bool causal) {
     static const bool on = [] { const char* e = std::getenv("FA2_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
     if (!on || causal || forced_rows() != 0) return p.nbh;
+    if (short_second_round(p, causal)) return p.nbh;            // 128-row workgroups for the whole grid instead (pick_rows)
     // a second launch costs ~5 us: only sweeps of at least 16 KV tiles (a workgroup then runs >= ~15 us) can win it back.  SDXL's
     // cross-attention (B2 H10 N4096 x Nkv 77, two tiles) measured 13.8 us split into two launches against 10.1 us for torch SDPA.
     if (p.Nkv < 16 * fa2::kKvTile) return p.nbh;
@@ -160,7 +172,7 @@ int launch_t(const fa2::FwdParams& p, hipStream_t stream) {
     } else if constexpr (kNW == 8 && kQB == 1) {
         // (512-row workgroups <8, 2> for short KV sweeps over long Q — SDXL cross-attention, 320 workgroups = 1.25 rounds — were
         //  measured: 105 spilled VGPRs at D = 64, 20.1 us against 13.7 us: not kept)
-        if (pick_rows(p) == 128) return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
+        if (pick_rows(p, CAUSAL) == 128) return launch_shape<HD, BF16, CAUSAL, 4, 1>(p, stream);
         if constexpr (HD <= 128) {
             if (use_mfma16()) return launch_shape16<HD, BF16, CAUSAL>(p, stream);
         }

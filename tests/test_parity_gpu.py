@@ -540,11 +540,12 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
         assert "roofline" in rec and rec["check"]["max_abs_err_vs_dense_fp32"] <= rec["check"]["tol"]
 
 
-@pytest.mark.parametrize("shape", [(2, 10, 4096, 64), (1, 24, 4096, 128), (3, 7, 2816, 128), (1, 20, 3500, 80)])
+@pytest.mark.parametrize("shape", [(2, 10, 4096, 64), (2, 17, 4096, 64), (1, 24, 4096, 128), (3, 7, 2816, 128), (1, 20, 3500, 80)])
 def test_tail_split_launches_cover_every_head(shape):
     """Grids whose last round of 256-row workgroups would be at most half full are issued as two launches (whole heads: the
-    full rounds as they are, the remaining heads as 128-row workgroups — host.cpp tail_split_heads).  Every head must come
-    out right, in particular the ones of the second launch."""
+    full rounds as they are, the remaining heads as 128-row workgroups — host.cpp tail_split_heads; B2 H17 N4096 D64 = 544
+    workgroups is such a grid), and between one and one and a half rounds at head dims <= 64 the whole grid runs as 128-row
+    workgroups (short_second_round: B2 H10 N4096 D64 = 320).  Every head must come out right, in particular the ones of the second launch."""
     B, H, N, D = shape
     g = torch.Generator(device="cpu").manual_seed(41 + H)
     q, k, v = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(3))

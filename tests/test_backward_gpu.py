@@ -161,6 +161,26 @@ def test_full_size_config2_backward_sampled_heads():
         assert torch.equal(a, b[:, 3:11])
 
 
+def test_full_size_config3_backward_sampled_heads():
+    """BASELINE config 3 shape (bf16, causal) through the backward: one head against the same-contract oracle, everything
+    finite, and the causal structure itself — dK / dV of the last KV row depend on the last Q row only, so they equal the
+    closed form (P = 1 on the diagonal of the last row: dV[last] = dO[last] * P, with P the last row's softmax weight)."""
+    g = torch.Generator(device=_dev()).manual_seed(6)
+    q, k, v, do = (torch.randn((2, 16, 4096, 128), generator=g, device=_dev(), dtype=torch.float32).bfloat16() for _ in range(4))
+    o, lse, grads = _cabi_fwd_bwd(q, k, v, do, True)
+    for t in grads:
+        assert torch.isfinite(t.float()).all()
+    sl = (slice(0, 1), slice(9, 10))
+    _check_vs_oracle(q[sl], k[sl], v[sl], do[sl], o[sl], lse[sl], [t[sl] for t in grads], 1, True)
+    # first Q row attends to the first KV row only: P = 1, dP - D = 0 up to f32 summation order -> dQ[0] vanishes
+    assert float(grads[0][:, :, 0].float().abs().max()) <= 1e-3
+    # last KV row is seen by the last Q row only: dV[last] = p * dO[last] with p = 2^(s*c - lse)
+    s_last = (q[:, :, -1].float() * k[:, :, -1].float()).sum(-1) * (128 ** -0.5)
+    p_last = torch.exp2(s_last * 1.4426950408889634 - lse[:, :, -1])
+    want = p_last[..., None] * do[:, :, -1].float()
+    assert float((grads[2][:, :, -1].float() - want).abs().max()) <= 1.6e-2 * max(1.0, float(want.abs().max()))
+
+
 def test_backward_above_256_is_refused_not_wrong():
     """The forward reaches D = 512; the backward kernels stop at 256 and say so (FA2_ERR_HEAD_DIM) instead of computing
     something else.  (The reference's LoRA-training use, README.md:151-154, is on SD1.5/SDXL UNet attention: D <= 160.)"""

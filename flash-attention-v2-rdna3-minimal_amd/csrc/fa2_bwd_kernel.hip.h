@@ -146,10 +146,10 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // 512-register budget, 128 rows per workgroup, ONE LDS stage (three 32-KiB images do not fit twice) — a correct, simple
 // path for the rare large head dim (SD1.5's D = 160), not a tuned one.
 template <int HD, bool BF16, bool CAUSAL, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dq_kernel(const BwdParams p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_dq_kernel(const BwdParams p) {
     using L_ = BwdLane<HD, NW>;
     constexpr int kRows = NW * 32;            // rows per workgroup (p.nblk = ceil(N / kRows))
-    constexpr bool DBUF = NW == 8;
+    constexpr bool DBUF = NW == 8 || HD <= 128;   // (NW = 4 at head dims <= 128: the small-grid shape, 128 Q rows per workgroup, 256 registers, two stages)
     constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
     constexpr int STAGEB = 3 * TILEB;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];

@@ -317,7 +317,24 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
     constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
     int rc;
-    {   // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass
+    // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass.
+    // Grids that would cover at most half of the CUs with 256-row workgroups (B*H*ceil(Nq/256) <= 128: SD-size training shapes) run
+    // as 128-row, 4-wave workgroups instead — twice as many, one wave per SIMD each.  FA2_BWD_DQ_ROWS=256|128 in the environment pins the shape.
+    bool dq_small = false;
+    if constexpr (NW == 8) {
+        static const int forced = [] { const char* e = std::getenv("FA2_BWD_DQ_ROWS"); return e ? std::atoi(e) : 0; }();
+        dq_small = forced == 128 || (forced != 256 && (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= 128);
+    }
+    if (dq_small) {
+        if constexpr (NW == 8) {
+            constexpr int lds = 2 * 3 * fa2::Geo<HD, 4>::TILEB;
+            constexpr auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, 4>;
+            if ((rc = set_lds<kern>(lds))) return rc;
+            p.nblk = (p.Nq + 127) / 128;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+    } else {
         constexpr int lds = kStages * 3 * TILEB;
         constexpr auto kern = fa2::bwd_dq_kernel<HD, BF16, CAUSAL, NW>;
         if ((rc = set_lds<kern>(lds))) return rc;

@@ -226,3 +226,19 @@ def test_separate_dk_dv_passes_in_a_child_process():
                          timeout=1200, cwd=root, env=env)
     assert res.returncode == 0, res.stdout[-3000:]
     assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
+
+
+def test_256_row_dq_workgroups_in_a_child_process():
+    """Small grids (B*H*ceil(Nq/256) <= 128) run dQ as 128-row, 4-wave workgroups, so most parity cases above no longer reach the
+    8-wave dQ kernel.  FA2_BWD_DQ_ROWS=256 pins the 256-row shape (read once per process): the backward parity cases run again
+    in a child process through it; FA2_BWD_DQ_ROWS=128 likewise forces the small shape onto the full-size cases."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    for rows, sel in (("256", "golden or seeded or wave_pair or head_dims or deterministic"), ("128", "full_size or autograd")):
+        env = dict(os.environ, FA2_BWD_DQ_ROWS=rows)
+        res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_backward_gpu.py"), "-m", "gpu", "-q", "-x",
+                              "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+        assert res.returncode == 0, res.stdout[-3000:]
+        assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]

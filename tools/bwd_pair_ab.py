@@ -26,13 +26,14 @@ def run(B, H, N, D, dtype, causal):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 30 * 1e3
 r = [run(2, 16, 4096, 128, torch.float16, False), run(2, 16, 4096, 128, torch.bfloat16, True), run(1, 32, 8192, 128, torch.float16, True),
-     run(8, 16, 4096, 128, torch.float16, False), run(2, 16, 1024, 128, torch.float16, False), run(2, 8, 4096, 80, torch.float16, False)]
+     run(8, 16, 4096, 128, torch.float16, False), run(2, 16, 1024, 128, torch.float16, False), run(2, 8, 4096, 80, torch.float16, False),
+     run(2, 8, 1024, 80, torch.float16, False), run(1, 8, 2048, 128, torch.float16, True)]
 print(" ".join("%%8.1f" %% x for x in r))
 ''' % ROOT
 
 def main():
-    print("%-22s %8s %8s %8s %8s %8s %8s   (us per backward)" % ("setting", "c2", "c3", "c4", "B8", "N1024", "D80"))
-    settings = [("separate passes", {"FA2_BWD_PAIR": "0"})] + [("wave-pair dK+dV pass", {"FA2_BWD_PAIR": "1"})]
+    print("%-22s %8s %8s %8s %8s %8s %8s %8s %8s   (us per backward)" % ("setting", "c2", "c3", "c4", "B8", "N1024", "D80", "sd15_32", "N2k_c"))
+    settings = [("separate passes", {"FA2_BWD_PAIR": "0"})] + [("wave-pair dK+dV pass", {"FA2_BWD_PAIR": "1"}), ("  + dQ pinned 256-row", {"FA2_BWD_PAIR": "1", "FA2_BWD_DQ_ROWS": "256"})]
     for rep in range(2):
         for name, env in settings:
             e = dict(os.environ); e.update(env)

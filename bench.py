@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (dry run of the multi-rank path on one GPU)")
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group, barriers, reductions and --collectives even with ONE rank (executes the RCCL path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,15 +175,18 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     host_sync = args.backend == "gloo"     # gloo: barriers / reductions on CPU tensors
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if host_sync:
                 dist.barrier()
             else:
@@ -189,7 +194,7 @@ def main():
 
     def max_over_ranks(vals):
         t = torch.tensor(vals, dtype=torch.float64, device="cpu" if host_sync else device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
@@ -264,22 +269,29 @@ def main():
 
     # ---- edge transfers (SURVEY §8e timing rule): reported separately, never part of `value`
     coll = None
-    if args.collectives and world > 1 and not host_sync:
+    if args.collectives and use_dist:
         shape = (B_global, H, N, D)
-        full = [torch.rand(shape, device=device, dtype=torch.float32).to(dtype) for _ in range(3)] if rank == 0 else [None] * 3
+        # gloo (the dry runs) moves CPU tensors: the slabs are staged through host memory there; RCCL moves device tensors
+        cdev = torch.device("cpu") if host_sync else device
+        full = [torch.rand(shape, device=device, dtype=torch.float32).to(dtype).to(cdev) for _ in range(3)] if rank == 0 else [None] * 3
         for _ in range(2):            # first pass = warm-up (communicator setup)
             torch.cuda.synchronize(); barrier(); t0c = time.perf_counter()
-            slabs = [scatter_batch(t, shape, dtype, device, src=0) for t in full]
+            slabs = [scatter_batch(t, shape, dtype, cdev, src=0, always_collective=True).to(device) for t in full]
             torch.cuda.synchronize(); barrier(); t_sc = time.perf_counter() - t0c
             o_loc = attn(*slabs, None, causal)
             torch.cuda.synchronize(); barrier(); t0c = time.perf_counter()
-            o_full = gather_batch(o_loc, B_global)
+            o_full = gather_batch(o_loc.to(cdev), B_global, always_collective=True)
             torch.cuda.synchronize(); barrier(); t_ga = time.perf_counter() - t0c
+        lo_c, hi_c = shard_bounds(B_global, world, rank)
+        assert torch.equal(o_full[lo_c:hi_c].to(device), o_loc), "gathered output differs from the local slab"
+        if rank == 0:
+            assert all(torch.equal(sl, t[lo_c:hi_c].to(device)) for sl, t in zip(slabs, full)), "scattered slab differs from the root's slice"
         t_sc, t_ga = max_over_ranks([t_sc, t_ga])
         nbytes = B_global * H * N * D * 2
         coll = {"scatter_qkv_ms": round(t_sc * 1e3, 3), "gather_o_ms": round(t_ga * 1e3, 3),
-                "scatter_bytes": 3 * nbytes, "gather_bytes": nbytes,
-                "note": "root-held [B_global,H,N,D] tensors: dist.scatter x3, all_gather_into_tensor x1 over RCCL; not part of value"}
+                "scatter_bytes": 3 * nbytes, "gather_bytes": nbytes, "backend": args.backend, "world": world,
+                "note": "root-held [B_global,H,N,D] tensors: dist.scatter x3, all_gather_into_tensor x1 (%s); not part of value"
+                        % ("host-staged over gloo" if host_sync else "device tensors over RCCL")}
         del full, slabs, o_full
 
     # ---- informational backward (reference harness style, bench_with_sdpa.py:78-88), outside the timed region
@@ -342,6 +354,8 @@ def main():
         }
         if steady is not None:
             line["steady"] = steady
+        if args.force_dist and world == 1:
+            line["dist"] = {"backend": args.backend, "world": 1, "note": "process group, barriers and reductions executed with one rank (--force-dist)"}
         if args.backend != "nccl" or args.same_device:
             line["dry_run"] = "backend=%s same_device=%s: control-flow check of the multi-rank path, not a scaling measurement" % (
                 args.backend, args.same_device)
@@ -352,7 +366,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_port"] = cpu_baseline(B * H, N, D, causal, dtype, 1234 + cfg_idx)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

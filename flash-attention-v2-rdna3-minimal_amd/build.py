@@ -1,4 +1,4 @@
-"""Ahead-of-time build of the gfx950 FlashAttention-2 forward library (libfa2_gfx950.so).
+"""Ahead-of-time build of the gfx950 FlashAttention-2 library (libfa2_gfx950.so).
 
 The reference JIT-builds its extension at import time with the arch pinned to gfx1100
 (rocwmma_fattn/FlashAttn.py:16-41).  Here the library is a plain C-ABI shared object compiled once,
@@ -6,13 +6,21 @@ in-tree, with `hipcc --offload-arch=gfx950`; hipcc cross-compiles without a GPU,
 runs in CI containers and on the MI355X box.
 
     python flash-attention-v2-rdna3-minimal_amd/build.py [--force] [--verbose]
+
+The build is hermetic: the generated asm bodies are produced with no options (timing-probe options of the
+generators need --probe and a separate output directory, tools/kbench.py), the stamp covers the sources,
+the flags AND the generated files, the whole build runs under a file lock (ranks of a multi-process launch
+that all find the library stale build it once), and every output is written to a temporary name and renamed.
 """
 import argparse
+import concurrent.futures
+import fcntl
 import hashlib
 import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 PKG_DIR = os.path.dirname(os.path.realpath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
@@ -21,14 +29,23 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_NAME = "libfa2_gfx950.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 STAMP_PATH = LIB_PATH + ".stamp"
+LOCK_PATH = LIB_PATH + ".lock"
 
-SOURCES = ["host.cpp"]
+# translation units: (object name, source, extra flags) — compiled in parallel, linked into one shared object
+UNITS = [
+    ("host", "host.cpp", []),
+    ("fwd_hip_f16", "fwd_hip.cpp", ["-DFA2_TU_BF16=0"]),
+    ("fwd_hip_bf16", "fwd_hip.cpp", ["-DFA2_TU_BF16=1"]),
+    ("fwd_asm", "fwd_asm.cpp", []),
+    ("bwd_hip_f16", "bwd_hip.cpp", ["-DFA2_TU_BF16=0"]),
+    ("bwd_hip_bf16", "bwd_hip.cpp", ["-DFA2_TU_BF16=1"]),
+    ("bwd_asm", "bwd_asm.cpp", []),
+]
 FRONTEND_SRC = "frontend.cpp"                      # optional compiled front end of the operator (host-only C++, g++)
 FRONTEND_PATH = os.path.join(PKG_DIR, "rocwmma_fattn", "_fa2_frontend.so")
-HEADERS = ["fa2_fwd_kernel.hip.h", "fa2_fwd_kernel16.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", os.path.join(INCLUDE, "fa2_gfx950.h"),
-           os.path.join("gen", "isa.py"), os.path.join("gen", "fwd_d128_gen.py")]
-GENERATED = ["fa2_fwd_d128_f16.inc", "fa2_fwd_d128_bf16.inc", "fa2_fwd_d128_f16_fold.inc", "fa2_fwd_d128_bf16_fold.inc",
-             "fa2_fwd_d128_clobbers.inc"]   # written by gen/fwd_d128_gen.py
+GENERATORS = [os.path.join("gen", "fwd_d128_gen.py"), os.path.join("gen", "bwd_d128_gen.py")]
+HEADERS = ["fa2_launch.h", "fa2_fwd_kernel.hip.h", "fa2_fwd_d128.hip.h", "fa2_bwd_kernel.hip.h", "fa2_bwd_d128.hip.h",
+           os.path.join(INCLUDE, "fa2_gfx950.h"), os.path.join("gen", "isa.py"), os.path.join("gen", "sched.py")] + GENERATORS
 
 HIPCC_FLAGS = [
     "-x", "hip",
@@ -36,9 +53,9 @@ HIPCC_FLAGS = [
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
+    "-fvisibility-inlines-hidden",
     "-fno-honor-nans",          # no canonicalising v_max before fmaxf on MFMA outputs; +-inf still honoured
-] + os.environ.get("FA2_EXTRA_HIPCC_FLAGS", "").split()    # e.g. "-DFA2_PRESCALE_MAX_HD=64" (kernel knobs, see the headers)
+]
 
 
 def _hipcc():
@@ -48,26 +65,95 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); the gfx950 library cannot be built")
 
 
+def _existing(names):
+    out = []
+    for name in names:
+        path = name if os.path.isabs(name) else os.path.join(CSRC, name)
+        if os.path.exists(path):
+            out.append(path)
+    return out
+
+
 def _source_digest():
     h = hashlib.sha256()
     h.update(" ".join(HIPCC_FLAGS).encode())
-    for name in SOURCES + HEADERS + [FRONTEND_SRC]:
-        path = name if os.path.isabs(name) else os.path.join(CSRC, name)
+    for (obj, src, flags) in UNITS:
+        h.update(("%s %s %s" % (obj, src, " ".join(flags))).encode())
+    for path in _existing(sorted(set(u[1] for u in UNITS)) + HEADERS + [FRONTEND_SRC]):
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
 
 
-def generate():
-    """Run the asm generator: the hand-scheduled D = 128 forward body is emitted as .inc files next to the kernels."""
-    res = subprocess.run([sys.executable, os.path.join(CSRC, "gen", "fwd_d128_gen.py")], capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("fwd_d128_gen.py failed:\n%s\n%s" % (res.stdout, res.stderr))
+def _dir_digest(d):
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith(".inc"):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def generate(out_dir=None, opts=None, probe=False):
+    """Run the asm generators: the hand-scheduled bodies are emitted as .inc files (default: next to the kernels; every file is
+    written under a temporary name and renamed).  `opts` = {generator file name: option string} (developer variants only)."""
+    out_dir = out_dir or CSRC
+    for g in GENERATORS:
+        path = os.path.join(CSRC, g)
+        if not os.path.exists(path):
+            continue
+        cmd = [sys.executable, path, "--out", out_dir]
+        o = (opts or {}).get(os.path.basename(g))
+        if o:
+            cmd += ["--opt", o]
+        if probe:
+            cmd.append("--probe")
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("%s failed:\n%s\n%s" % (g, res.stdout, res.stderr))
+    return out_dir
+
+
+def compile_library(out_path, extra_flags=(), inc_dir=None, verbose=False, jobs=None):
+    """hipcc every translation unit (in parallel) and link them into `out_path`.  inc_dir: where the generated .inc files are
+    (default csrc/).  Returns the concatenated compiler output (resource usage remarks with verbose=True)."""
+    units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[1]))]
+    tmpdir = tempfile.mkdtemp(prefix="fa2_build_")
+    log = []
+    try:
+        def one(u):
+            obj, src, flags = u
+            cmd = [_hipcc()] + HIPCC_FLAGS + list(flags) + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC]
+            if inc_dir:
+                cmd += ["-I", inc_dir, "-DFA2_D128_INC_DIR=%s" % inc_dir]
+            if verbose:
+                cmd.append("-Rpass-analysis=kernel-resource-usage")
+            cmd += ["-c", os.path.join(CSRC, src), "-o", os.path.join(tmpdir, obj + ".o")]
+            res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+            return obj, res
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as ex:
+            for obj, res in ex.map(one, units):
+                log.append(res.stdout + res.stderr)
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc failed on %s (%d):\n%s\n%s" % (obj, res.returncode, res.stdout[-4000:], res.stderr[-8000:]))
+        tmp = out_path + ".tmp.%d" % os.getpid()
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(tmpdir, u[0] + ".o") for u in units] + ["-o", tmp]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("link failed (%d):\n%s\n%s" % (res.returncode, res.stdout, res.stderr))
+        os.replace(tmp, out_path)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return "\n".join(log)
 
 
 def build_frontend(verbose=False):
     """rocwmma_fattn/_fa2_frontend.so: the forward of the reference's pybind module in C++ over the C-ABI (csrc/frontend.cpp).
-    Optional — the Python implementation in FlashAttn.py is used when it is absent — so a failure here is reported, not raised."""
+    Optional — the Python implementation in FlashAttn.py is used when it is absent — so a failure here is reported, not raised,
+    and an existing module is left alone (peers may have it loaded)."""
     try:
         import sysconfig
         import torch
@@ -91,41 +177,48 @@ def build_frontend(verbose=False):
         os.replace(tmp, FRONTEND_PATH)
         return FRONTEND_PATH
     except Exception as e:   # noqa: BLE001 - optional component
-        if os.path.exists(FRONTEND_PATH):
-            os.remove(FRONTEND_PATH)
         print("fa2 build: compiled front end not built (%s); the Python front end will be used" % str(e)[:500], file=sys.stderr)
         return None
 
 
+def _read_stamp():
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().split()
+    except OSError:
+        return []
+
+
 def is_current():
-    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+    """The library exists, was built from these sources and flags, and the generated bodies next to the kernels are the ones
+    it was built from."""
+    if not os.path.exists(LIB_PATH):
         return False
-    with open(STAMP_PATH) as f:
-        return f.read().strip() == _source_digest()
+    st = _read_stamp()
+    return len(st) >= 2 and st[0] == _source_digest() and st[1] == _dir_digest(CSRC)
 
 
 def build(force=False, verbose=False):
     """Compile libfa2_gfx950.so in-tree unless it is already up to date.  Returns its path."""
-    digest = _source_digest()
     if not force and is_current():
         return LIB_PATH
-    generate()
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd += ["-o", tmp]
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, cwd=CSRC, capture_output=not verbose, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed (%d):\n%s\n%s" % (res.returncode, res.stdout or "", res.stderr or ""))
-    os.replace(tmp, LIB_PATH)
-    build_frontend(verbose)
-    with open(STAMP_PATH, "w") as f:
-        f.write(digest + "\n")
+    with open(LOCK_PATH, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)          # one builder at a time; the others wait and then find the library current
+        try:
+            if not force and is_current():
+                return LIB_PATH
+            digest = _source_digest()
+            generate()
+            log = compile_library(LIB_PATH, verbose=verbose)
+            if verbose:
+                print(log, file=sys.stderr)
+            ok = build_frontend(verbose) is not None
+            tmp = STAMP_PATH + ".tmp.%d" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write("%s %s %s\n" % (digest, _dir_digest(CSRC), "frontend" if ok else "no-frontend"))
+            os.replace(tmp, STAMP_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -1,0 +1,111 @@
+// bwd_hip.cpp — instantiations and launchers of the compiler-scheduled backward kernels (fa2_bwd_kernel.hip.h) for ONE dtype:
+// build.py compiles this file twice, -DFA2_TU_BF16=0 and =1.  Reference counterpart: backward_fp16 / backward_bf16
+// (kernel_fp16.cu:878-1028).
+#include "fa2_launch.h"
+
+#include "fa2_gfx950.h"
+
+#ifndef FA2_TU_BF16
+#error "compile with -DFA2_TU_BF16=0 or 1"
+#endif
+
+namespace {
+
+constexpr bool kBF16 = FA2_TU_BF16 != 0;
+
+template <int HD, bool CAUSAL>
+int launch_bwd_pair(const fa2::BwdParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * (4 * fa2::Geo<HD, 8>::TILEB + 512) + 4 * 4096;
+    constexpr auto kern = fa2::bwd_dkv_pair_kernel<HD, kBF16, CAUSAL>;
+    if (int rc = fa2::set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <int HD, bool CAUSAL>
+int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
+    constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
+    constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
+    int rc;
+    // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass.
+    // Grids that would cover at most half of the CUs with 256-row workgroups (SD-size training shapes) run as 128-row,
+    // 4-wave workgroups instead — twice as many, one wave per SIMD each.
+    bool dq_small = false;
+    if constexpr (NW == 8) {
+        const int forced = fa2::options().rows.load(std::memory_order_relaxed);      // option "rows" pins this shape too
+        dq_small = forced == 128 || (forced != 256 && (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= fa2::device_cus() / 2);
+    }
+    if (dq_small) {
+        if constexpr (NW == 8) {
+            constexpr int lds = 2 * 3 * fa2::Geo<HD, 4>::TILEB;
+            constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, 4>;
+            if ((rc = fa2::set_lds<kern>(lds))) return rc;
+            p.nblk = (p.Nq + 127) / 128;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+    } else {
+        constexpr int lds = kStages * 3 * TILEB;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        p.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    if constexpr (HD == 128) {
+        // D in 65..128: dK and dV in one sweep by wave pairs (bwd_dkv_pair_kernel): 128 KV rows per workgroup, S and P formed once
+        p.nblk = (p.Nkv + 127) / 128;
+        if ((int64_t)p.B * p.H * p.nblk > 0x7fffffffLL) return FA2_ERR_GRID;
+        return launch_bwd_pair<HD, CAUSAL>(p, stream);
+    } else if constexpr (HD <= 64) {
+        // D <= 64: both accumulators fit one wave, one sweep forms S and P once for dK and dV
+        p.nblk = (p.Nkv + kRows - 1) / kRows;
+        constexpr int lds = kStages * (4 * TILEB + 512);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        return (int)hipGetLastError();
+    } else {
+        p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows, two sweeps
+        {
+            constexpr int lds = kStages * (2 * TILEB + 512);
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW>;
+            if ((rc = fa2::set_lds<kern>(lds))) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        {
+            constexpr int lds = kStages * (3 * TILEB + 512);
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW>;
+            if ((rc = fa2::set_lds<kern>(lds))) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        return 0;
+    }
+}
+
+template <int HD>
+int launch_bwd(const fa2::BwdParams& p, bool causal, hipStream_t stream) {
+    return causal ? launch_bwd_t<HD, true>(p, stream) : launch_bwd_t<HD, false>(p, stream);
+}
+
+}  // namespace
+
+namespace fa2 {
+
+#if FA2_TU_BF16
+int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+#else
+int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+#endif
+    switch (HD) {
+        case 64: return launch_bwd<64>(p, causal, stream);
+        case 128: return launch_bwd<128>(p, causal, stream);
+        case 256: return launch_bwd<256>(p, causal, stream);
+        default: return FA2_ERR_HEAD_DIM;
+    }
+}
+
+}  // namespace fa2

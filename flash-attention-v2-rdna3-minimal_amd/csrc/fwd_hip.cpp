@@ -1,0 +1,74 @@
+// fwd_hip.cpp — instantiations and launchers of the compiler-scheduled forward kernels (fa2_fwd_kernel.hip.h) for ONE dtype:
+// build.py compiles this file twice, -DFA2_TU_BF16=0 and =1, in parallel with the other translation units.
+// Reference counterpart: the template dispatch at the end of forward_fp16 / forward_bf16 (kernel_fp16.cu:841-851).
+#include "fa2_launch.h"
+
+#include "fa2_gfx950.h"
+
+#ifndef FA2_TU_BF16
+#error "compile with -DFA2_TU_BF16=0 or 1"
+#endif
+
+namespace {
+
+constexpr bool kBF16 = FA2_TU_BF16 != 0;
+
+template <int HD, bool CAUSAL, int NW, bool BIAS = false>
+int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
+    constexpr int HDV = HD > 128 ? 128 : HD;
+    constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
+    constexpr int lds_epi = FA2_EPI_LDS ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
+    // bias kernels: + NW wave-private 32-row images of the "tile" bias form where they fit (not at D = 512: 160 KiB of K / V buffers)
+    constexpr int lds_bias = BIAS && lds_kv + NW * 32 * 272 <= 160 * 1024 ? NW * 32 * 272 : 0;
+    constexpr int lds = lds_kv + lds_bias > lds_epi ? lds_kv + lds_bias : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    fa2::FwdParams p = p0;
+    p.nqblk = (p.Nq + NW * 32 - 1) / (NW * 32);
+    if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
+    const dim3 grid((unsigned)((int64_t)p.nbh * p.nqblk), HD / HDV);
+    constexpr auto kern = fa2::fwd_kernel<HD, HDV, kBF16, CAUSAL, NW, 1, BIAS>;
+    if (int rc = fa2::set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+// D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
+// D = 512 (the reference's D > 384 path, FlashAttn.py:65-67; the SD VAE attention block): 4-wave workgroups of 128 Q
+// rows, one wave per SIMD — the 128 registers of Q fragments per wave need the 512-register budget — and all 160 KiB
+// of LDS (two 64 KiB K tiles + two 16 KiB V tiles).  A correct path for a rare shape, not a tuned one.
+// Attention bias / boolean mask: every head dim runs as 4-wave, 128-row workgroups — one wave per SIMD, so the 32 bias
+// registers per tile come out of the 512-register budget instead of spilling (the 8-wave shape at D = 64 spills 62-67 VGPRs).
+template <int HD, bool CAUSAL>
+int launch_t(const fa2::FwdParams& p, int rows, bool bias, hipStream_t stream) {
+    if (bias) return launch_shape<HD, CAUSAL, 4, true>(p, stream);
+    if constexpr (HD > 256) {
+        return launch_shape<HD, CAUSAL, 4>(p, stream);
+    } else {
+        return rows == 128 ? launch_shape<HD, CAUSAL, 4>(p, stream) : launch_shape<HD, CAUSAL, 8>(p, stream);
+    }
+}
+
+template <int HD>
+int launch_hd(const fa2::FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
+    return causal ? launch_t<HD, true>(p, rows, bias, stream) : launch_t<HD, false>(p, rows, bias, stream);
+}
+
+}  // namespace
+
+namespace fa2 {
+
+#if FA2_TU_BF16
+int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
+#else
+int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
+#endif
+    switch (HD) {
+        case 64: return launch_hd<64>(p, causal, rows, bias, stream);
+        case 128: return launch_hd<128>(p, causal, rows, bias, stream);
+        case 256: return launch_hd<256>(p, causal, rows, bias, stream);
+        case 512: return launch_hd<512>(p, causal, rows, bias, stream);
+        default: return FA2_ERR_HEAD_DIM;
+    }
+}
+
+}  // namespace fa2

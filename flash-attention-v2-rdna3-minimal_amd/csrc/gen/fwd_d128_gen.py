@@ -17,7 +17,7 @@ Shape of the computation (one workgroup = 4 waves = 256 Q rows, ONE wave per SIM
     both products are "swapped" (S^T = K Q^T, O^T = V^T P^T) exactly as in fa2_fwd_kernel.hip.h, so a lane owns one
     Q row of each block and the softmax is lane-local plus one v_permlane32_swap.
 
-Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs (68 in the folded-scale variant):
+Software pipeline.  Body B(t), t = -2 .. ntiles-1, is 64 MFMAs:
     MFMA  0..31  PV(t)        O[qb] += V(t)^T P(t)^T          (qb 0 then qb 1, four O accumulators per k-step)
     MFMA 32..63  QK(t+2)      S(t+2)[qb] = K(t+2) Q[qb]^T      (the four 32x32 S accumulators take turns)
   and between them ("gaps") the single-issue work, spread by the water-filling scheduler (Gen.place) so that the
@@ -34,11 +34,9 @@ ntwg-2 and ntwg-1 of an item stage the NEXT item's Q fragments and K(0), K(1), V
 code entered from the guarded staging groups), and the next statement skips its load phase (flag bit 0).
 
 Variants and developer options (Gen(..., opt=..., abl=..., syn=..., trace=...), `--opt` on the command line):
-    opt=ct       folded scale (the fa2_fwd_d128_*_fold.inc bodies): Q * scale*log2e rounded once to the I/O dtype
+    opt=ct       folded scale (not shipped since 0.7; kept as a correct, emulator-tested variant): Q * scale*log2e rounded once to the I/O dtype
                  (pure_torch_ver.py:61); the running reference is the C operand of the first QK^T k-step (C tuples v[176:207],
                  V^T k-steps 2-3 in a[224:255], K fragments in a 32-register pool with counted lgkmcnt waits: Gen.lds_waits)
-    opt=pre      the first form of the fold (usepre on the command line): the reference travels through a ninth k-step as three
-                 16-bit terms (68 MFMAs per body)
     abl=...      timing-only ablations of the fast bodies (streams left out; results are wrong, cycle counts are not)
     syn=fma:5    timing probe: every gap of the fast bodies carries the same synthetic fillers (issue-cost measurements)
     trace=1..4   s_memtime sums (phases / barrier / whole block) returned through the LSE outputs
@@ -99,9 +97,7 @@ LB = [LSUM[0][1], LSUM[1][1]]
 FSC = [V(232), V(233)]                             # pending O rescale factor
 MC = [V(234), V(235)]                              # reference max in log2 units (m * c)
 TMP = [V(236 + i) for i in range(8)]               # scratch: row-max chains, rescale block, epilogue
-KX = V(244, 4)                                     # folded-scale kernels: the K side of the extra k-step (ones / zeros)
-QX = [V(248, 4), V(252, 4)]                        # ... and the Q side: -(reference max) split into three 16-bit terms
-EP_LT, EP_T, EP_INV = FSC[0], FSC[1], KX[0]        # epilogue scratch (the softmax state above is dead by then)
+EP_LT, EP_T, EP_INV = FSC[0], FSC[1], V(244)       # epilogue scratch (the softmax state above is dead by then)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
 S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
@@ -186,17 +182,15 @@ class Gen:
         if "w1" in self.cfg and "w2" in self.cfg:     # scheduler weights: w1=trans:lds, w2=dma:salu
             set_weights(self.cfg["w1"][0], self.cfg["w1"][1], self.cfg["w2"][0], self.cfg["w2"][1])
         self.opt = set(self.cfg["opt"])
-        self.pre = "pre" in self.opt      # folded scale: Q is multiplied by c and rounded once, -m rides in an extra k-step
-        self.ct = "ct" in self.opt        # folded scale, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
-        assert not (self.pre and self.ct)
-        self.fold = self.pre or self.ct   # what the two share: prescaled Q, S leaves the MFMA as (score - reference)
+        self.ct = "ct" in self.opt        # folded scale: Q * c rounded once, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
+        self.fold = self.ct               # prescaled Q, S leaves the MFMA as (score - reference)
         self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else KF      # ctk64: timing probe (K and V^T fragments collide)
         self.vf = VF_CT if self.ct else VF
         self.qf = QF
         if "vagpr" in self.opt:
             self.vf = VF_ACC
             self.qf = QF_SPLIT if self.ct else QF_ARCH
-        self.nqk = 36 if self.pre else 32
+        self.nqk = 32
         self.ng = 32 + self.nqk           # MFMAs (= gaps) per body
         self.bf16 = bf16
         self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
@@ -223,10 +217,6 @@ class Gen:
     def qk_mfmas(self, par):
         """S(t+2) for both q blocks; the four 32x32 accumulators take turns (a dependent MFMA is four issues away)."""
         out = []
-        if self.pre:       # S starts as -m: A = ones (kv rows), B = the three 16-bit terms of -m of this lane's q row
-            for qb in range(2):
-                for kvb in range(2):
-                    out.append(mk(self.mfma, SB(qb, par).sub(16 * kvb, 16), KX, QX[qb], 0, tag="mfma"))
         order = [(ks, qb, kvb) for ks in range(8) for qb in range(2) for kvb in range(2)]
         if "chainqk" in self.opt:      # probe: pairs of k-steps of one accumulator back to back
             order = [(2 * kp + j, qb, kvb) for kp in range(4) for qb in range(2) for kvb in range(2) for j in range(2)]
@@ -235,7 +225,7 @@ class Gen:
                 if True:
                     dst = SB(qb, par).sub(16 * kvb, 16)
                     c0 = CT[qb] if (self.ct and "ctc0" not in self.opt) else 0        # ctc0: timing probe (no reference in S)
-                    out.append(mk(self.mfma, dst, self.kf(kvb, ks), self.qf(qb, ks), c0 if (ks == 0 and not self.pre) else dst, tag="mfma"))
+                    out.append(mk(self.mfma, dst, self.kf(kvb, ks), self.qf(qb, ks), c0 if ks == 0 else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
@@ -275,25 +265,6 @@ class Gen:
                 out += F + E + Ad + C
         return out
 
-    def split16(self, r, src, terms, tmp):
-        """`src` (f32, left unchanged) -> three 16-bit terms whose exact sum is the value the kernel uses as the reference:
-        terms[i] receive the f32 value of term i, tmp[i] its bits in the low half.  Appends to r."""
-        rem = src
-        for i in range(3):
-            if self.bf16:                                     # truncation: bits = upper half
-                r.append(mk("v_and_b32", terms[i], 0xffff0000, rem))
-                r.append(mk("v_lshrrev_b32", tmp[i], 16, terms[i]))
-            else:
-                r.append(mk("v_cvt_f16_f32", tmp[i], rem))
-                r.append(mk("s_nop", 0))
-                r.append(mk("v_cvt_f32_f16", terms[i], tmp[i]))
-                r.append(mk("v_and_b32", tmp[i], 0xffff, tmp[i]))
-            if i < 2:
-                r.append(mk("s_nop", 0))
-                nxt = terms[i + 1]
-                r.append(mk("v_sub_f32", nxt, rem, terms[i]))
-                rem = nxt
-
     def stream_max(self, qb, par, masked, first=False):
         """mask (tail bodies) -> row max of the 32 scores of this lane -> half-wave exchange -> rescale decision."""
         b = SB(qb, par)
@@ -328,7 +299,7 @@ class Gen:
             else:
                 out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_lt_f32", VCC, THR, mxa, tag="valu"),
                             mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
-            self.rare.append((self.rare_m_ct if self.ct else self.rare_m_pre)(lab, qb, b, mxa, mxb, t, t2, first))
+            self.rare.append(self.rare_m_ct(lab, qb, b, mxa, mxb, t, t2, first))
             return out
         out.append(mk("v_fma_f32", t2, mxa, A_C, Neg(MC[qb]), tag="valu"))
         out.append([mk("v_cmp_lt_f32", VCC, THR, t2, tag="valu"), mk("s_cbranch_vccnz", Label(lab), tag="branch"),
@@ -352,46 +323,6 @@ class Gen:
         r.append(mk("s_branch", Label(lab + "_ret")))
         self.rare.append(r)
         return out
-
-    def rare_m_pre(self, lab, qb, b, mxa, mxb, t, t2, first):
-        """Folded-scale kernels, out of line: the reference of q block qb moves by d = max(row max, 0) (tile 0: = row max).
-        The new reference is re-split into three 16-bit terms (QX, fed to the next QK^T through the extra k-step), the
-        scores of THIS tile — formed against the old reference — are shifted by the exact difference, the row sums are
-        scaled now and the O rescale is left pending."""
-        r = [Ins("label", (Label(lab),))]
-        if not first:
-            r.append(mk("v_max_f32", mxa, 0, mxa))                      # rows that did not grow keep their reference
-            r.append(mk("s_nop", 0))
-        r.append(mk("v_add_f32", mxb, MC[qb], mxa))                     # wanted new reference
-        r.append(mk("s_nop", 0))
-        terms, bits = [t, t2, mxa], [QX[qb][2], QX[qb][3], QX[qb][1]]   # (QX[qb][2:4] are rebuilt as zeros below)
-        self.split16(r, mxb, terms, bits)
-        r.append(mk("s_nop", 0))
-        r.append(mk("v_add_f32", mxb, terms[0], terms[1]))              # the reference actually representable: t0 + t1 + t2
-        r.append(mk("s_nop", 0))
-        r.append(mk("v_add_f32", mxb, mxb, terms[2]))
-        r.append(mk("s_nop", 0))
-        r.append(mk("v_sub_f32", t, mxb, MC[qb]))                       # exact shift d of the reference
-        r.append(mk("v_mov_b32", MC[qb], mxb))
-        r.append(mk("s_nop", 0))
-        for e in range(32):
-            r.append(mk("v_sub_f32", b[e], b[e], t))                    # this tile's scores, now against the new reference
-        r.append(mk("v_exp_f32", t2, Neg(t)))                           # factor for everything accumulated at the old one
-        # QX = { -(t0, t1), -(t2, 0), 0, 0 } as packed 16-bit pairs
-        r.append(mk("v_lshl_or_b32", QX[qb][0], bits[1], 16, bits[0]))
-        r.append(mk("v_xor_b32", QX[qb][1], 0x8000, bits[2]))
-        r.append(mk("s_nop", 0))
-        r.append(mk("v_xor_b32", QX[qb][0], 0x80008000, QX[qb][0]))
-        r.append(mk("v_mov_b32", QX[qb][2], 0))
-        r.append(mk("v_mov_b32", QX[qb][3], 0))
-        if not first:
-            r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
-        r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
-        r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
-        r.append(mk("v_mov_b32", FSC[qb], t2))
-        r.append(mk("s_nop", 1))
-        r.append(mk("s_branch", Label(lab + "_ret")))
-        return r
 
     def rare_m_ct(self, lab, qb, b, mxa, mxb, t, t2, first):
         """"ct" kernels, out of line: the reference of q block qb moves by d = max(row max, 0) (tile 0: = row max).  The C tuple
@@ -867,17 +798,6 @@ class Gen:
                 for i in range(16):
                     p.emit("v_mov_b32", CT[qb][i], 0)              # C tuples: the reference starts at 0
         if self.fold:
-            # extra k-step operands: K side = 1.0 in the eight k-slots of the lower lane half (the upper half's slots are 0),
-            # Q side = the (negated) reference, 0 for now
-            one2 = 0x3f803f80 if self.bf16 else 0x3c003c00
-            if self.pre:
-                p.emit("v_and_b32", TMP[0], 16, A_EPI)             # the epilogue address carries hi * 16
-                p.emit("v_mov_b32", TMP[1], one2)
-                p.emit("v_cmp_eq_u32", VCC, 0, TMP[0])
-                for i in range(4):
-                    p.emit("v_cndmask_b32", KX[i], 0, TMP[1], VCC)
-                    p.emit("v_mov_b32", QX[0][i], 0)
-                    p.emit("v_mov_b32", QX[1][i], 0)
             if self.ct and early:
                 # the 16 Q loads were issued first: K(0), V(0) and K(1) (12 or 8 pieces behind them) keep flying during the prescale
                 p.emit("s_cmp_lt_i32", A_NTWG, 2)
@@ -1099,31 +1019,43 @@ def parse_opts(text):
     return cfg
 
 
+# Options that emit bodies which are WRONG BY DESIGN (timing probes) or that only exist for measurements: the product build
+# never passes them (build.py calls main() with no options), tools/kbench.py does, with --probe and its own output directory.
+PROBE_KEYS = ("abl", "syn", "vsplit", "stagger", "shift", "dmaw", "w1", "w2", "trace")
+PROBE_OPTS = ("ctk64", "ctc0", "nofma", "noadd", "vagpr", "expsep", "chainpv", "chainqk")
+
+
+def is_probe(cfg):
+    return any(k in cfg for k in PROBE_KEYS) or any(o in PROBE_OPTS for o in cfg.get("opt", ()))
+
+
+def write_atomic(path, text):
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
-    ap.add_argument("--opt", default=os.environ.get("FA2_D128_GEN_OPT", ""), help="schedule tunables / options / ablations, see parse_opts")
+    ap.add_argument("--opt", default="", help="schedule tunables / options, see parse_opts")
+    ap.add_argument("--probe", action="store_true", help="allow timing-probe options (bodies with wrong results; never for the product build)")
     a = ap.parse_args()
     out_dir = a.out
     os.makedirs(out_dir, exist_ok=True)
     cfg = parse_opts(a.opt)
-    for fold in (False, True):
-        for bf16 in (False, True):
-            c2 = dict(cfg)
-            # the *_fold.inc bodies: "ct" (reference rides in the C operand) unless opt=usepre asks for the extra-k-step form
-            fopt = "pre" if "usepre" in cfg.get("opt", ()) else "ct"
-            c2["opt"] = tuple(x for x in cfg.get("opt", ()) if x not in ("pre", "ct", "usepre")) + ((fopt,) if fold else ())
-            g = Gen(bf16, **c2)
-            prog = g.build()
-            path = os.path.join(out_dir, "fa2_fwd_d128_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))
-            with open(path, "w") as f:
-                f.write("// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)))
-                f.write(render_inline(prog))
-            print(path, len(prog.ins), "instructions")
-    with open(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"), "w") as f:
-        f.write("// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.\n")
-        f.write(clobber_list() + "\n")
+    if is_probe(cfg) and not a.probe:
+        sys.exit("fwd_d128_gen.py: %r contains timing-probe options; they need --probe and must not go into the product build" % a.opt)
+    for bf16 in (False, True):
+        g = Gen(bf16, **cfg)
+        prog = g.build()
+        path = os.path.join(out_dir, "fa2_fwd_d128_%s.inc" % ("bf16" if bf16 else "f16"))
+        write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))
+        print(path, len(prog.ins), "instructions")
+    write_atomic(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"),
+                 "// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.\n" + clobber_list() + "\n")
 
 
 if __name__ == "__main__":

@@ -46,6 +46,8 @@ SYMBOLS = {
     "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
     "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "fa2_fwd_prescales_q": (ctypes.c_int, [ctypes.c_int, ctypes.c_float]),
+    "fa2_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "fa2_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "fa2_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "fa2_version": (ctypes.c_char_p, []),
 }
@@ -91,6 +93,31 @@ def error_string(code):
 def check(code):
     if code != 0:
         raise RuntimeError("fa2 call failed (%d): %s" % (code, error_string(code)))
+
+
+class options:
+    """with _fa2_lib.options(rows=256, persist=0): ... — set tuning switches of the library (fa2_set_option) and restore
+    them on exit.  Process-wide: for A/B measurements and tests, not for concurrent use."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.saved = {}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.kw.items():
+            old = lib.fa2_get_option(k.encode())
+            if old < 0:
+                raise ValueError("fa2: unknown option %r" % k)
+            self.saved[k] = old
+            check(lib.fa2_set_option(k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.saved.items():
+            lib.fa2_set_option(k.encode(), v)
+        return False
 
 
 def strides3(a, b, c):

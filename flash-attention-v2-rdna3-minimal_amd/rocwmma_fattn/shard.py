@@ -38,14 +38,15 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
-def scatter_batch(t_full, shape, dtype, device, src=0, group=None):
+def scatter_batch(t_full, shape, dtype, device, src=0, group=None, always_collective=False):
     """Root `src` holds t_full [B, ...]; every rank receives its contiguous batch slab.
-    Non-root ranks pass t_full=None.  Slabs may be uneven (B % world != 0)."""
+    Non-root ranks pass t_full=None.  Slabs may be uneven (B % world != 0).  A group of one rank copies locally unless
+    `always_collective` asks for the collective call anyway (bench.py --force-dist: runs RCCL on a 1-GPU box)."""
     world, rank = _world(group)
     B = shape[0]
     lo, hi = shard_bounds(B, world, rank)
     out = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
-    if world == 1:
+    if world == 1 and not always_collective:
         out.copy_(t_full)
         return out
     if B % world == 0:
@@ -69,10 +70,10 @@ def scatter_batch(t_full, shape, dtype, device, src=0, group=None):
     return out
 
 
-def gather_batch(t_local, total_batch, group=None):
+def gather_batch(t_local, total_batch, group=None, always_collective=False):
     """Inverse of the partition: every rank ends with the full [B, ...] tensor."""
     world, rank = _world(group)
-    if world == 1:
+    if world == 1 and not always_collective:
         return t_local
     full = torch.empty((total_batch,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
     if total_batch % world == 0:

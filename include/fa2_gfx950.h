@@ -126,8 +126,9 @@ int fa2_fwd_bias(int dtype,
  *   o, lse   : the forward's outputs (lse in log2 units, as fa2_fwd writes it)
  *   dout     : [B,H,Nq,D] upstream gradient, same dtype as q
  *   dq/dk/dv : outputs, caller-owned, every element written (no zero-init needed)
- *   delta_ws : caller-owned f32 workspace addressed like lse (lse_strides), >= Nq floats per (b,h):
- *              receives D_i = rowsum(dO_i * O_i) (the reference's `Di`, kernel_fp16.cu:605-631)
+ *   delta_ws : caller-owned f32 workspace addressed like lse (lse_strides), >= Nq floats per (b,h): scratch of the call
+ *              (it carries D_i = rowsum(dO_i * O_i), the reference's `Di`, kernel_fp16.cu:605-631 — or its negative,
+ *              depending on the kernel family — from the dQ pass to the dK/dV pass)
  * Two launches on `hip_stream` at D <= 128 (dQ — which also fills delta_ws —, then dK and dV in one sweep: one fused pass at D <= 64, wave pairs at D <= 128),
  * three above (dQ, dV, dK); deterministic: every output element has one owner — the
  * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
@@ -172,11 +173,27 @@ int fa2_padded_head_dim(int D);
  * the counterparts of the reference's Br / Bc, FlashAttn.py:56-67). */
 int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
 
-/* Where the softmax scale is applied (numerical contract, informational).  Returns 0: every forward kernel scales the
- * f32 Q.K^T product, as the reference kernel does (kernel_fp16.cu:164), never Q itself (the reference oracle's
- * `scale * q_frags`, pure_torch_ver.py:61, costs LSE accuracy in proportion to the logits; a build option that did so
- * at D = 64 was removed).  Kept so that callers written against 0.4 keep linking.  -1: D not supported. */
+/* Where the softmax scale is applied (numerical contract, informational).  Returns 0 for every supported head dim: every
+ * kernel scales the f32 Q.K^T product, as the reference kernel does (kernel_fp16.cu:164), never Q itself (the reference
+ * oracle's `scale * q_frags`, pure_torch_ver.py:61, costs LSE accuracy in proportion to the logits; the opt-in folded-scale
+ * bodies of version 0.6, for which this returned 1, were removed in 0.7).  Kept so that callers written against earlier
+ * versions keep linking.  -1: D not supported. */
 int fa2_fwd_prescales_q(int D, float scale);
+
+/*
+ * Process-wide tuning switches.  They choose between kernels that satisfy the same contract (results agree to rounding,
+ * not necessarily bit for bit) and exist for A/B measurements and for the test-suite; the defaults are the measured best.
+ * Initial values come from the environment variable named below, read once when the library is loaded.
+ *   "rows"  FA2_ROWS   0 (default: heuristic on the grid size) | 128 | 256 — Q rows per forward (and dQ-pass) workgroup
+ *   "asm"       FA2_ASM        bit 0: hand-scheduled forward bodies (head dims 64 and 128), bit 1: hand-scheduled backward
+ *                              bodies (head dim 128); default 3.  0 = compiler-scheduled HIP kernels everywhere
+ *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
+ * These three (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.
+ * fa2_set_option returns FA2_OK, or FA2_ERR_BAD_SHAPE for an unknown name / value; fa2_get_option the value (>= 0) or that code.
+ * Changing an option while launches are being issued from other threads is safe (atomics) but the switch-over point is not ordered.
+ */
+int fa2_set_option(const char* name, int value);
+int fa2_get_option(const char* name);
 
 /* Text for a return code of this library (validation codes and hipError_t values). */
 const char* fa2_error_string(int code);

@@ -29,11 +29,10 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[("ct",), (), ("pre",)], ids=["folded-scale", "f32-scale", "folded-scale-extra-k-step"])
+@pytest.fixture(params=[(), ("ct",)], ids=["f32-scale", "folded-scale"])
 def variant(request):
-    """The bodies the library ships — scale applied in f32 (default) and scale folded into Q with the running reference in the
-    C operand of the first QK^T k-step (opt-in, FA2_D128_FOLD=1) — and the earlier form of the fold (reference through a ninth
-    k-step; generator option usepre)."""
+    """The body the library ships — scale applied to the f32 scores — and the generator's folded-scale variant (Q * scale*log2e
+    rounded once, the running reference in the C operand of the first QK^T k-step; not shipped since 0.7, kept correct)."""
     saved = harness.OPT
     harness.OPT = request.param
     harness._PROGS.clear()
@@ -102,7 +101,7 @@ def test_emulator_flags_a_missing_wait():
             harness._PROGS.pop(False, None)
 
 
-@pytest.mark.parametrize("opt", [(), ("ct",), ("pre",)])
+@pytest.mark.parametrize("opt", [(), ("ct",)])
 def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     """Every line of the rendered body goes through the gfx950 assembler (operand classes, constant-bus limits, offsets):
     the emulator interprets instruction objects, so this is the check that the TEXT is legal."""

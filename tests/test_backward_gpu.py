@@ -212,33 +212,23 @@ def test_wave_pair_dkdv_pass_against_oracle(shape, dt, causal):
         assert torch.equal(a, b), "the pair pass is not deterministic"
 
 
-def test_separate_dk_dv_passes_in_a_child_process():
-    """FA2_BWD_PAIR=0 selects the two separate KV-owned sweeps (dV, then dK) at head dims 65..128 — the A/B baseline of the pair
-    pass and the path of a build with -DFA2_BWD_PAIR=0.  The library reads the switch once, so the backward parity cases run again
-    in a child process."""
-    import os
-    import subprocess
+def test_pinned_workgroup_shapes_and_kernel_families():
+    """Small grids run dQ as 128-row, 4-wave workgroups and head dim 128 runs the hand-scheduled bodies when the shape allows, so
+    most parity cases above reach only one of the kernels that can serve them.  The library options (fa2_set_option) pin the other
+    choices in this process: rows = 256 / 128 (the 8-wave / 4-wave dQ shapes) and asm = 1 (compiler-scheduled backward kernels,
+    hand-scheduled forward) — the same cases must pass through each of them."""
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    env = dict(os.environ, FA2_BWD_PAIR="0")
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_backward_gpu.py"), "-m", "gpu", "-q", "-x",
-                          "-k", "golden or seeded or wave_pair or head_dims or deterministic"], capture_output=True, text=True,
-                         timeout=1200, cwd=root, env=env)
-    assert res.returncode == 0, res.stdout[-3000:]
-    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
-
-
-def test_256_row_dq_workgroups_in_a_child_process():
-    """Small grids (B*H*ceil(Nq/256) <= 128) run dQ as 128-row, 4-wave workgroups, so most parity cases above no longer reach the
-    8-wave dQ kernel.  FA2_BWD_DQ_ROWS=256 pins the 256-row shape (read once per process): the backward parity cases run again
-    in a child process through it; FA2_BWD_DQ_ROWS=128 likewise forces the small shape onto the full-size cases."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    for rows, sel in (("256", "golden or seeded or wave_pair or head_dims or deterministic"), ("128", "full_size or autograd")):
-        env = dict(os.environ, FA2_BWD_DQ_ROWS=rows)
-        res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_backward_gpu.py"), "-m", "gpu", "-q", "-x",
-                              "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
-        assert res.returncode == 0, res.stdout[-3000:]
-        assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
+    from rocwmma_fattn import _fa2_lib
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from test_parity_gpu import _expand_and_call
+    mod = sys.modules[__name__]
+    groups = {"small": [n for n in dir(mod) if n.startswith("test_") and any(k in n for k in ("golden", "seeded", "wave_pair", "head_dims", "deterministic"))],
+              "big": [n for n in dir(mod) if n.startswith("test_") and any(k in n for k in ("full_size", "autograd"))]}
+    assert groups["small"] and groups["big"], groups
+    n = 0
+    for opts, names in (({"rows": 256}, groups["small"]), ({"rows": 128}, groups["big"]), ({"asm": 1}, groups["small"] + groups["big"]),
+                        ({"asm": 1, "rows": 256}, groups["small"])):
+        with _fa2_lib.options(**opts):
+            for name in names:
+                n += _expand_and_call(getattr(mod, name))
+    assert n >= 20, n

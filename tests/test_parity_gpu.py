@@ -525,10 +525,10 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    for workload in ("c2", "c5"):
+    for workload in ("c5",):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-               "--workload", workload, "--backend", "gloo", "--same-device", "--steady-launches", "0"]
+               "--workload", workload, "--backend", "gloo", "--same-device", "--steady-launches", "0", "--collectives"]
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
         assert res.returncode == 0, res.stderr[-2000:]
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -538,6 +538,31 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
         assert rec["scaling"] == ("strong" if workload == "c5" else "weak")
         assert rec["config"]["global_batch"] == (64 if workload == "c5" else 4)
         assert "roofline" in rec and rec["check"]["max_abs_err_vs_dense_fp32"] <= rec["check"]["tol"]
+        assert rec["collectives"]["backend"] == "gloo" and rec["collectives"]["scatter_qkv_ms"] > 0     # host-staged edge transfers ran (and were verified)
+
+
+def test_bench_runs_the_rccl_path_with_one_rank():
+    """`bench.py --force-dist --collectives` on the one GPU of this box: init_process_group("nccl", device_id=...), the device
+    barriers, the MAX all-reduce of the timings and scatter_batch / gather_batch on DEVICE tensors all go through RCCL with a
+    world of one rank — the calls the 2/4/8-GPU runs of the driver make, executed here so that they are not first run there."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "c2",
+           "--force-dist", "--collectives", "--steady-launches", "0", "--no-cpu-baseline", "--no-backward"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["dist"]["backend"] == "nccl" and "dry_run" not in rec
+    assert rec["collectives"]["backend"] == "nccl" and rec["collectives"]["world"] == 1
+    assert rec["collectives"]["scatter_qkv_ms"] > 0 and rec["collectives"]["gather_o_ms"] > 0
 
 
 @pytest.mark.parametrize("shape", [(2, 10, 4096, 64), (2, 17, 4096, 64), (1, 24, 4096, 128), (3, 7, 2816, 128), (1, 20, 3500, 80)])
@@ -559,21 +584,52 @@ def test_tail_split_launches_cover_every_head(shape):
     assert float((o.float() - truth).abs().max()) <= FLOOR[0] * 2
 
 
+def _expand_and_call(fn):
+    """Call a parametrized test function for the cartesian product of its @pytest.mark.parametrize lists (and every golden case
+    for a `golden` argument) — used to re-run whole groups of tests under another library option in THIS process."""
+    import inspect
+    import itertools
+    from conftest import GOLDEN_CASES, load_golden
+    names, lists = [], []
+    for m in getattr(fn, "pytestmark", []):
+        if m.name == "parametrize":
+            argn = [a.strip() for a in m.args[0].split(",")] if isinstance(m.args[0], str) else list(m.args[0])
+            names.append(argn)
+            lists.append(list(m.args[1]))
+    params = inspect.signature(fn).parameters
+    n = 0
+    for combo in itertools.product(*lists):
+        kw = {}
+        for argn, val in zip(names, combo):
+            val = getattr(val, "values", val)      # pytest.param(...)
+            if len(argn) == 1:
+                kw[argn[0]] = val[0] if isinstance(val, tuple) and not isinstance(combo, tuple) else val
+            else:
+                kw.update(dict(zip(argn, val)))
+        if "golden" in params:
+            for name in GOLDEN_CASES:
+                fn(golden=load_golden(name), **kw)
+                n += 1
+        else:
+            fn(**kw)
+            n += 1
+    return n
+
+
 def test_d128_asm_kernel_on_small_and_ragged_grids():
     """Grids of fewer than 97 workgroups run on the 128-row HIP kernel, so the seeded / golden / ragged / poisoned-tail cases
-    above no longer reach the hand-scheduled D = 128 kernel.  This re-runs them in a child process with FA2_FWD_ROWS=256,
-    which pins the 256-row shapes (the library reads the switch once per process) — i.e. every head-dim-128 case, ragged
-    Nq / Nkv, cross-attention, causal, BNHD strides, NaN-poisoned tails, through the asm block on the GPU."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    env = dict(os.environ, FA2_FWD_ROWS="256")
-    sel = "golden or seeded or ragged_tail or scale or large_logits or bnhd_d128 or precision_shape"
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
-                          "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
-    assert res.returncode == 0, res.stdout[-3000:]
-    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
+    above do not reach the hand-scheduled D = 128 kernel.  This re-runs them with the library option rows = 256 (fa2_set_option),
+    which pins the 256-row shapes — i.e. every head-dim-128 case, ragged Nq / Nkv, cross-attention, causal, BNHD strides,
+    NaN-poisoned tails, goes through the asm block on the GPU."""
+    from rocwmma_fattn import _fa2_lib
+    n = 0
+    with _fa2_lib.options(rows=256):
+        for fn in (test_golden_fixtures_through_cabi, test_golden_fixtures_through_operator, test_seeded_shapes_against_oracle,
+                   test_explicit_and_negative_scale, test_scale_zero_is_the_uniform_softmax, test_ragged_tail_ignores_memory_past_nkv,
+                   test_large_logits_and_forced_rescale, test_bnhd_d128_zero_copy, test_reference_precision_shape):
+            n += _expand_and_call(fn)
+    assert n >= 40, n
+    assert _fa2_lib.load().fa2_get_option(b"rows") == 0
 
 
 PERSISTENT_SHAPES = [
@@ -587,42 +643,24 @@ PERSISTENT_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
-def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape, tmp_path):
+def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape):
     """Non-causal D = 128 launches run persistent workgroups (grid = CUs; the last two bodies of an item fetch the next item's
     Q fragments and first K / V tiles).  The arithmetic of an item does not depend on how it was scheduled, so the outputs must
-    be BIT-IDENTICAL to a child process that launches one workgroup per item (FA2_D128_PERSIST=0), and close to dense fp32."""
-    import os
-    import subprocess
-    import sys
+    be BIT-IDENTICAL to a launch of one workgroup per item (library option persist = 0), and close to dense fp32."""
+    from rocwmma_fattn import _fa2_lib
     B, H, Nq, Nkv, bnhd = shape
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    code = (
-        "import sys, numpy as np, torch\n"
-        "sys.path.insert(0, %r)\n"
-        "from rocwmma_fattn.FlashAttn import FlashAttentionFunction as F\n"
-        "B, H, Nq, Nkv, bnhd, out = %d, %d, %d, %d, %d, %r\n"
-        "g = torch.Generator(device='cpu').manual_seed(77)\n"
-        "q = torch.randn((B, H, Nq, 128), generator=g).half().cuda()\n"
-        "k = torch.randn((B, H, Nkv, 128), generator=g).half().cuda()\n"
-        "v = torch.randn((B, H, Nkv, 128), generator=g).half().cuda()\n"
-        "if bnhd:\n"
-        "    q, k, v = (t.transpose(1, 2).contiguous() for t in (q, k, v))\n"
-        "o = F.apply(q, k, v, None, False, None, bool(bnhd))\n"
-        "torch.cuda.synchronize()\n"
-        "np.save(out, o.cpu().view(torch.int16).numpy())\n"
-    ) % (os.path.join(root, "flash-attention-v2-rdna3-minimal_amd"), B, H, Nq, Nkv, int(bnhd), str(tmp_path / "o_%s.npy"))
-    outs = {}
-    for mode, env_extra in (("persist", {"FA2_FWD_ROWS": "256"}), ("single", {"FA2_FWD_ROWS": "256", "FA2_D128_PERSIST": "0"})):
-        res = subprocess.run([sys.executable, "-c", code.replace("o_%s.npy", "o_%s.npy" % mode)], capture_output=True, text=True,
-                             timeout=900, cwd=root, env=dict(os.environ, **env_extra))
-        assert res.returncode == 0, res.stderr[-2000:]
-        outs[mode] = np.load(tmp_path / ("o_%s.npy" % mode))
-    assert np.array_equal(outs["persist"], outs["single"])
     g = torch.Generator(device="cpu").manual_seed(77)
     q = torch.randn((B, H, Nq, 128), generator=g).half().to(_dev())
     k = torch.randn((B, H, Nkv, 128), generator=g).half().to(_dev())
     v = torch.randn((B, H, Nkv, 128), generator=g).half().to(_dev())
-    got = torch.from_numpy(outs["persist"]).view(torch.float16).to(_dev()).float()
+    qq, kk, vv = (t.transpose(1, 2).contiguous() for t in (q, k, v)) if bnhd else (q, k, v)
+    outs = {}
+    for mode, persist in (("persist", 1), ("single", 0)):
+        with _fa2_lib.options(rows=256, persist=persist):
+            outs[mode] = FlashAttentionFunction.apply(qq, kk, vv, None, False, None, bool(bnhd))
+        torch.cuda.synchronize()
+    assert torch.equal(outs["persist"], outs["single"])
+    got = outs["persist"].float()
     if bnhd:
         got = got.transpose(1, 2)
     worst = 0.0
@@ -631,44 +669,6 @@ def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape, tmp_path
         truth = torch.matmul(torch.softmax(s, -1), v[b].float())
         worst = max(worst, float((got[b] - truth).abs().max()))
     assert worst <= 2e-3, worst
-
-
-def test_d128_fold_variant_in_a_child_process():
-    """The opt-in folded-scale bodies of the D = 128 kernel (FA2_D128_FOLD=1: Q * scale*log2e rounded once to the I/O dtype, the
-    running reference in the C operand of the first QK^T k-step).  The library reads the switch once per process, so the
-    head-dim-128 parity cases run again in a child process; `_assert_close_to_oracle` asks fa2_fwd_prescales_q() which scaling
-    contract the oracle must use, so the comparison is against the same-contract oracle at the usual tolerances."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    env = dict(os.environ, FA2_FWD_ROWS="256", FA2_D128_FOLD="1")
-    chk = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from rocwmma_fattn import _fa2_lib as L; "
-                          "print(L.load().fa2_fwd_prescales_q(128, 128 ** -0.5))" % os.path.join(root, "flash-attention-v2-rdna3-minimal_amd")],
-                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
-    assert chk.stdout.strip().endswith("1"), chk.stdout + chk.stderr[-2000:]
-    sel = "golden or seeded or ragged_tail or scale or large_logits or bnhd_d128 or precision_shape"
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
-                          "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
-    assert res.returncode == 0, res.stdout[-3000:]
-    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
-
-
-def test_mfma16_variant_in_a_kid_process():
-    """The opt-in 8-wave kernel on v_mfma_f32_16x16x32 (csrc/fa2_fwd_kernel16.hip.h, FA2_MFMA16=1; head dims <= 128, 256-row
-    workgroups): a different register layout of S, P and O, a different V image swizzle and two-step row reductions, so the
-    parity cases run again in a child process (the library reads the switch once).  FA2_FWD_D128=hip takes the hand-scheduled
-    kernel out of the way so that head dim 128 reaches it too; FA2_FWD_ROWS=256 keeps small grids on the 8-wave shape."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-    env = dict(os.environ, FA2_FWD_ROWS="256", FA2_MFMA16="1", FA2_FWD_D128="hip")
-    sel = "golden or seeded or ragged_tail or scale or large_logits or precision_shape or head_dims_masked or bnhd_layout"
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
-                          "-k", sel], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
-    assert res.returncode == 0, res.stdout[-3000:]
-    assert " passed" in res.stdout and "failed" not in res.stdout.splitlines()[-1]
 
 
 def test_bnhd_d128_zero_copy():

@@ -189,7 +189,7 @@ def check(Nq, Nkv, qblk, causal, bf16=False, seed=0, kind="randn", spike=False, 
         k[min(Nkv - 1, 70)] = q[40] * 2
     o, lse, m = run_block(q, k, v, qblk, causal, bf16=bf16)
     r0 = qblk * 256
-    o_ref, lse_ref = dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre=("pre" in OPT or "ct" in OPT))
+    o_ref, lse_ref = dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre=("ct" in OPT))
     err = float(np.abs(o - o_ref).max())
     lerr = float(np.abs(lse - lse_ref).max())
     if verbose:

@@ -46,45 +46,44 @@ CFGS = {
 
 
 def build(specs):
+    """NAME[:flag,flag,...]: flags are -D... compiler flags, gen=<options of csrc/gen/fwd_d128_gen.py> and bgen=<options of
+    bwd_d128_gen.py> (';' between options, e.g. gen=e=10:64;abl=exp+dma).  Generator options go through --probe into a private
+    directory of the variant — the product build (build.py) never sees them."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_b", os.path.join(PKG, "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     os.makedirs(VAR_DIR, exist_ok=True)
-    b.generate()
-    procs = []
+    ok = True
     for s in specs:
         name, _, flags = s.partition(":")
-        extra = [f for f in flags.split(",") if f and not f.startswith("gen=")]
-        gen = [f[4:] for f in flags.split(",") if f.startswith("gen=")]
-        if gen:     # schedule variant of the hand-scheduled D = 128 kernel: NAME:gen=e0=0:40;dma=4:12;abl=exp+dma (';' between options)
-            gdir = os.path.join(VAR_DIR, name + "_gen")
-            subprocess.check_call([sys.executable, os.path.join(b.CSRC, "gen", "fwd_d128_gen.py"), "--out", gdir,
-                                   "--opt", gen[0].replace(";", ",")], stdout=subprocess.DEVNULL)
-            extra += ["-DFA2_D128_INC_DIR=%s" % gdir]
+        fl = [f for f in flags.split(",") if f]
+        extra = [f for f in fl if not f.startswith(("gen=", "bgen="))]
+        opts = {}
+        for f in fl:
+            if f.startswith("gen="):
+                opts["fwd_d128_gen.py"] = f[4:].replace(";", ",")
+            if f.startswith("bgen="):
+                opts["bwd_d128_gen.py"] = f[5:].replace(";", ",")
+        gdir = os.path.join(VAR_DIR, name + "_gen")
+        os.makedirs(gdir, exist_ok=True)
+        b.generate(gdir, opts, probe=True)
         out = os.path.join(VAR_DIR, name + ".so")
-        cmd = [b._hipcc()] + b.HIPCC_FLAGS + extra + ["-I", b.INCLUDE, "-I", b.CSRC,
-                                                      os.path.join(b.CSRC, "host.cpp"), "-o", out,
-                                                      "-Rpass-analysis=kernel-resource-usage"]
-        procs.append((name, subprocess.Popen(cmd, cwd=b.CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    ok = True
-    for name, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
+        try:
+            log = b.compile_library(out, extra_flags=extra, inc_dir=gdir, verbose=True)
+        except RuntimeError as e:
             ok = False
-            print("== %s: BUILD FAILED\n%s" % (name, out[-3000:]))
+            print("== %s: BUILD FAILED\n%s" % (name, str(e)[-3000:]))
             continue
-        # resource usage of the D=128 non-causal f16 kernel
-        lines = out.splitlines()
-        info = []
+        lines = log.splitlines()
         for i, l in enumerate(lines):
-            if "Function Name" in l and "ILi128ELi128ELb0ELb0EL" in l:
+            if "Function Name" in l and ("d128" in l or "d64" in l) and "Lb0ELb0E" in l:
+                info = []
                 for m in lines[i + 1:i + 12]:
                     for key in ("VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "SGPRs:", "VGPRs Spill", "LDS Size"):
                         if key in m:
-                            info.append(m.split("]")[0].split(":0:")[-1].strip().replace("remark: ", ""))
-                break
-        print("== %s: %s" % (name, "; ".join(x.split("    ")[-1] for x in info)))
+                            info.append(m.split("remark: ")[-1].strip())
+                print("== %s: %s: %s" % (name, l.split("Function Name: ")[-1][:60], "; ".join(x.split("    ")[-1] for x in info)))
     return ok
 
 

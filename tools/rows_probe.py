@@ -1,5 +1,5 @@
 """A/B of the 256-row and 128-row forward workgroup shapes on small / awkward grids (developer tool).
-Run once per setting: FA2_FWD_ROWS=256|128 [FA2_FWD_D128=hip] python tools/rows_probe.py"""
+Run once per setting: FA2_ROWS=256|128 [FA2_ASM=0] python tools/rows_probe.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v2-rdna3-minimal_amd"))
@@ -20,4 +20,4 @@ for name, B, H, N, D in SHAPES:
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 30 * 1e3)
     out.append("%s %.1f" % (name, best))
-print(os.environ.get("FA2_FWD_ROWS", "auto"), os.environ.get("FA2_FWD_D128", "asm"), " | ".join(out))
+print(os.environ.get("FA2_ROWS", "auto"), os.environ.get("FA2_ASM", "3"), " | ".join(out))

@@ -1,0 +1,31 @@
+// bwd_asm.cpp — launchers of the hand-scheduled backward kernels for head dim 128 (generated inline-asm bodies, csrc/gen/bwd_d128_gen.py).
+// Reference counterpart: backward_fp16 / backward_bf16 (kernel_fp16.cu:878-1028).
+#include "fa2_launch.h"
+
+#include "fa2_bwd_d128.hip.h"
+#include "fa2_gfx950.h"
+
+namespace {
+
+template <bool BF16, bool CAUSAL>
+int launch_t(fa2::BwdParams p, int parts, hipStream_t stream) {
+    if (parts & 1) {        // dQ (+ delta): one workgroup per 256 Q rows
+        constexpr auto kern = fa2::bwd_dq_d128_kernel<BF16, CAUSAL>;
+        if (int rc = fa2::set_lds<kern>(fa2::kBwdDqLdsBytes)) return rc;
+        p.nblk = (p.Nq + 255) / 256;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), fa2::kBwdDqLdsBytes, stream, p);
+        if (int rc = (int)hipGetLastError()) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+namespace fa2 {
+
+int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
+    if (bf16) return causal ? launch_t<true, true>(p, parts, stream) : launch_t<true, false>(p, parts, stream);
+    return causal ? launch_t<false, true>(p, parts, stream) : launch_t<false, false>(p, parts, stream);
+}
+
+}  // namespace fa2

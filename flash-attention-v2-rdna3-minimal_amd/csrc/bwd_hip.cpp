@@ -22,8 +22,9 @@ int launch_bwd_pair(const fa2::BwdParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// parts: bit 0 = the dQ pass (which also fills the delta workspace), bit 1 = the dK / dV pass(es)
 template <int HD, bool CAUSAL>
-int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
+int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
     constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
@@ -36,7 +37,8 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
         const int forced = fa2::options().rows.load(std::memory_order_relaxed);      // option "rows" pins this shape too
         dq_small = forced == 128 || (forced != 256 && (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= fa2::device_cus() / 2);
     }
-    if (dq_small) {
+    if (!(parts & 1)) {
+    } else if (dq_small) {
         if constexpr (NW == 8) {
             constexpr int lds = 2 * 3 * fa2::Geo<HD, 4>::TILEB;
             constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, 4>;
@@ -53,6 +55,7 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
     }
+    if (!(parts & 2)) return 0;
     if constexpr (HD == 128) {
         // D in 65..128: dK and dV in one sweep by wave pairs (bwd_dkv_pair_kernel): 128 KV rows per workgroup, S and P formed once
         p.nblk = (p.Nkv + 127) / 128;
@@ -87,8 +90,8 @@ int launch_bwd_t(fa2::BwdParams p, hipStream_t stream) {
 }
 
 template <int HD>
-int launch_bwd(const fa2::BwdParams& p, bool causal, hipStream_t stream) {
-    return causal ? launch_bwd_t<HD, true>(p, stream) : launch_bwd_t<HD, false>(p, stream);
+int launch_bwd(const fa2::BwdParams& p, bool causal, int parts, hipStream_t stream) {
+    return causal ? launch_bwd_t<HD, true>(p, parts, stream) : launch_bwd_t<HD, false>(p, parts, stream);
 }
 
 }  // namespace
@@ -96,14 +99,14 @@ int launch_bwd(const fa2::BwdParams& p, bool causal, hipStream_t stream) {
 namespace fa2 {
 
 #if FA2_TU_BF16
-int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
 #else
-int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
 #endif
     switch (HD) {
-        case 64: return launch_bwd<64>(p, causal, stream);
-        case 128: return launch_bwd<128>(p, causal, stream);
-        case 256: return launch_bwd<256>(p, causal, stream);
+        case 64: return launch_bwd<64>(p, causal, parts, stream);
+        case 128: return launch_bwd<128>(p, causal, parts, stream);
+        case 256: return launch_bwd<256>(p, causal, parts, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
 }

@@ -1,0 +1,141 @@
+// fa2_bwd_d128.hip.h — backward kernels for head dim 128 whose tile sweeps are hand-scheduled inline-asm blocks.
+//
+// Same contract and same math as the compiler-scheduled passes of fa2_bwd_kernel.hip.h (reference: bwd_kernel,
+// kernel_fp16.cu:547-740), different machine mapping: 4-wave workgroups with ONE wave per SIMD and the whole 512-entry
+// register file per wave, KV (dQ pass) / Q (dK/dV pass) swept in tiles of 32 rows, every LDS fragment read feeding two
+// MFMAs, the instruction stream between MFMAs placed by csrc/gen/bwd_d128_gen.py (register maps, pipelines and the LDS
+// image formats are documented there) and validated instruction by instruction on the CPU by tools/asm_emu.py
+// (tests/test_asm_emu_bwd.py).  This file is the shell: workgroup -> (head, block) mapping, the per-lane addresses the
+// blocks take as operands, and the global stores of what they leave in LDS.
+#pragma once
+#include "fa2_bwd_kernel.hip.h"
+
+#ifndef FA2_D128_INC_DIR
+#define FA2_BWD_INC(name) #name
+#else
+#define FA2_BWD_STR2(x) #x
+#define FA2_BWD_STR(x) FA2_BWD_STR2(x)
+#define FA2_BWD_INC(name) FA2_BWD_STR(FA2_D128_INC_DIR/name)
+#endif
+
+namespace fa2 {
+
+constexpr int kBwdEpiRowB = 272;                       // bytes per staged output row (EPI_ROWB of the generator)
+constexpr int kBwdDqEpiBase = 49152;                   // DQ.EPI_BASE: above the row ring (2 x 16 KiB) and the transposed-read ring (2 x 8 KiB)
+constexpr int kBwdDqLdsBytes = kBwdDqEpiBase + 4 * 64 * kBwdEpiRowB;      // DQ.LDS_BYTES = 118784
+constexpr int kBwdTile = 32;                           // rows per swept tile of the hand-scheduled backward kernels
+
+typedef uint32_t bwd_u32x4s __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// dQ pass: workgroup = 256 Q rows (4 waves x 64), sweep over KV tiles of 32.  Also writes delta = rowsum(dO * O).
+// Requires D == 128 (host.cpp dispatch); any Nq, Nkv (clamped rows, masked tail tiles), causal or not.
+template <bool BF16, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> (head, q block): as in bwd_dq_kernel (causal: longest-first across the heads of an XCD)
+    const int nbh = p.B * p.H, bid = blockIdx.x;
+    int bh, qblk;
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;
+        if (CAUSAL) { bh = (bid & 7) + 8 * (slot % hpx); qblk = p.nblk - 1 - slot / hpx; }
+        else { bh = (bid & 7) + 8 * (slot / p.nblk); qblk = slot % p.nblk; }
+    } else if (CAUSAL) { bh = bid % nbh; qblk = p.nblk - 1 - bid / nbh; }
+    else { bh = bid / p.nblk; qblk = bid % p.nblk; }
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * 256, qw0 = q0 + 64 * wave;
+
+    const uint32_t q_rowb = (uint32_t)p.qs[2] * 2u, g_rowb = (uint32_t)p.dos[2] * 2u, o_rowb = (uint32_t)p.os[2] * 2u;
+    const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
+
+    // KV sweep bounds in tiles of 32 (workgroup: staging + barriers; wave: compute)
+    const int ntiles = (p.Nkv + kBwdTile - 1) / kBwdTile;
+    int ntwg = ntiles, ntw = ntiles;
+    if (CAUSAL) {
+        const int qmax = (q0 + 256 < p.Nq ? q0 + 256 : p.Nq) - 1;
+        const int nt_c = qmax / kBwdTile + 1;
+        ntwg = nt_c < ntiles ? nt_c : ntiles;
+        const int nt_w = (qw0 + 63) / kBwdTile + 1;
+        ntw = nt_w < ntwg ? nt_w : ntwg;
+    }
+
+    uint32_t qo[2], go[2], oo[2], lo[2];
+    int lim[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = qw0 + 32 * qb + l31;
+        const uint32_t qr = (uint32_t)(qrow < p.Nq ? qrow : p.Nq - 1);
+        qo[qb] = qr * q_rowb + 16u * hi;
+        go[qb] = qr * g_rowb + 16u * hi;
+        oo[qb] = qr * o_rowb + 16u * hi;
+        lo[qb] = qr * 4u;
+        // the wave's last two tiles are masked where kv > min(q row (causal), Nkv - 1); local to the LAST tile, minus this lane half's 4*hi
+        const int lim_c = CAUSAL ? qrow : 0x3fffffff;
+        lim[qb] = (lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1) - kBwdTile * (ntw - 1) - 4 * hi;
+    }
+    // LDS-DMA: piece i of this wave fills image bytes [wave*2048 + i*1024, +1024): lane l supplies the source of image slot
+    // (row = 8*wave + 4*i + l/16, slot = l%16); the asm block derives piece 1 from piece 0
+    const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
+    const uint32_t kd0 = drow * k_rowb + ((dslot ^ (drow & 15u)) << 4);                                   // row images: granule ^ (row & 15)
+    const uint32_t vd0 = drow * v_rowb + ((dslot ^ (drow & 15u)) << 4);
+    const uint32_t td0 = drow * k_rowb + (((((dslot >> 2) ^ (drow & 3u)) << 2) | (dslot & 3u)) << 4);     // "tr" image: 64-B chunk ^ (row & 3)
+    const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ ((uint32_t)l31 & 15u)) << 4);
+    const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1;
+    const uint32_t vr0 = (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
+    const uint32_t epi = kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
+
+    const uint64_t qbase = (uint64_t)((const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1]);
+    const uint64_t gbase = (uint64_t)((const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1]);
+    const uint64_t obase = (uint64_t)((const uint16_t*)p.o + b * p.os[0] + h * p.os[1]);
+    const uint64_t lbase = (uint64_t)(p.lse + b * p.ls[0] + h * p.ls[1]);
+    const uint64_t ka = (uint64_t)((const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1]);
+    const uint64_t va = (uint64_t)((const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1]);
+    const bwd_u32x4s krs = {(uint32_t)ka, (uint32_t)(ka >> 32) & 0xffffu, p.k_bytes, 0x00020000u};
+    const bwd_u32x4s vrs = {(uint32_t)va, (uint32_t)(va >> 32) & 0xffffu, p.v_bytes, 0x00020000u};
+    const uint32_t k_tile = kBwdTile * k_rowb, v_tile = kBwdTile * v_rowb, k_row4 = 4 * k_rowb - 1024, v_row4 = 4 * v_rowb - 1024;
+    const uint32_t ldsw = wave * 2048;
+    const float c = p.c, scale = p.scale;
+    float d0, d1;
+
+#define FA2_BWD_DQ_OPERANDS                                                                                                     \
+    : "=&v"(d0), "=&v"(d1)                                                                                                      \
+    : "v"(qo[0]), "v"(qo[1]), "v"(go[0]), "v"(go[1]), "v"(oo[0]), "v"(oo[1]), "v"(lo[0]), "v"(lo[1]), "v"(kd0), "v"(vd0),       \
+      "v"(td0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(epi), "s"(qbase), "s"(gbase), "s"(obase), "s"(lbase), "s"(krs), "s"(vrs), \
+      "s"(c), "s"(scale), "s"(ntw), "s"(ntwg), "s"(k_tile), "s"(v_tile), "s"(k_row4), "s"(v_row4), "s"(ldsw)                     \
+    :
+    if constexpr (BF16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dq_d128_bf16.inc)
+            FA2_BWD_DQ_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dq_d128_clobbers.inc)
+        );
+    } else {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dq_d128_f16.inc)
+            FA2_BWD_DQ_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dq_d128_clobbers.inc)
+        );
+    }
+#undef FA2_BWD_DQ_OPERANDS
+
+    // ---- delta out; the wave's 64 x 128 dQ tile is in its LDS image: whole-row stores (4 rows of 256 B per instruction)
+    if (hi == 0) {
+        float* dp = p.delta + b * p.ls[0] + h * p.ls[1];
+        if (qw0 + l31 < p.Nq) dp[qw0 + l31] = d0;
+        if (qw0 + 32 + l31 < p.Nq) dp[qw0 + 32 + l31] = d1;
+    }
+    const char* img = smem + kBwdDqEpiBase + wave * 64 * kBwdEpiRowB;
+    const int rl = lane >> 4, cl = lane & 15;
+    uint16_t* out = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = i * 4 + rl;
+        const u32x4 w = *(const u32x4*)(img + r * kBwdEpiRowB + cl * 16);
+        if (qw0 + r < p.Nq) *(u32x4*)(out + (int64_t)(qw0 + r) * p.dqs[2] + cl * 8) = w;
+    }
+}
+
+}  // namespace fa2

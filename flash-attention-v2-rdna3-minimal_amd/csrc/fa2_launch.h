@@ -20,6 +20,7 @@ struct Options {
     std::atomic<int> rows{0};      // FA2_ROWS: 0 = heuristic, 128 | 256 = rows per forward workgroup
     std::atomic<int> asm_mask{3};      // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
+    std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
 };
 FA2_HIDDEN Options& options();
 FA2_HIDDEN int device_cus();           // compute units of the current device (cached per device index)
@@ -44,8 +45,12 @@ FA2_HIDDEN int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int r
 FA2_HIDDEN int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
 // hand-scheduled forward, head dim exactly 128 (fwd_asm.cpp)
 FA2_HIDDEN int launch_fwd_d128(bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
-// HIP backward (bwd_hip.cpp): dQ (+ delta), then dK / dV
-FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
-FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
+// HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
+FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// hand-scheduled backward, head dim exactly 128 (bwd_asm.cpp); same `parts`
+FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+
+constexpr int kBwdAsmParts = 1;      // passes the hand-scheduled backward covers: bit 0 = dQ, bit 1 = dK / dV
 
 }  // namespace fa2

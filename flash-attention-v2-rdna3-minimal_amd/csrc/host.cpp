@@ -131,8 +131,21 @@ int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStre
     return launch_range(HD, bf16, p0, causal, stream);
 }
 
+// Head dim exactly 128 runs the hand-scheduled backward kernels (fa2_bwd_d128.hip.h) unless option "asm" bit 1 is cleared; bits 2 / 3 of
+// the option take only the dQ pass / only the dK-dV pass off them (A/B measurements of one pass at a time).
 int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStream_t stream) {
-    return bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, stream);
+    const int m = fa2::options().asm_mask.load(std::memory_order_relaxed);
+    const int want = fa2::options().bwd_parts.load(std::memory_order_relaxed);      // 3 unless a profiling run asked for one pass only
+    int asm_parts = 0;
+    if (HD == 128 && p.D == 128 && (m & 2)) asm_parts = 3 & ~((m >> 2) & 3) & fa2::kBwdAsmParts;
+    for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
+        if (!(want & part)) continue;
+        int rc;
+        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, stream);
+        else rc = bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, part, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, part, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -173,6 +186,7 @@ int fa2_set_option(const char* name, int value) {
     if (!std::strcmp(name, "rows")) { if (value != 0 && value != 128 && value != 256) return FA2_ERR_BAD_SHAPE; o.rows = value; }
     else if (!std::strcmp(name, "asm")) o.asm_mask = value;
     else if (!std::strcmp(name, "persist")) o.persist = value != 0;
+    else if (!std::strcmp(name, "bwd_parts")) { if (value < 1 || value > 3) return FA2_ERR_BAD_SHAPE; o.bwd_parts = value; }
     else return FA2_ERR_BAD_SHAPE;
     return FA2_OK;
 }
@@ -183,6 +197,7 @@ int fa2_get_option(const char* name) {
     if (!std::strcmp(name, "rows")) return o.rows.load();
     if (!std::strcmp(name, "asm")) return o.asm_mask.load();
     if (!std::strcmp(name, "persist")) return o.persist.load();
+    if (!std::strcmp(name, "bwd_parts")) return o.bwd_parts.load();
     return FA2_ERR_BAD_SHAPE;
 }
 

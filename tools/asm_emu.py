@@ -70,6 +70,7 @@ class Wave:
         self.issue_idx = 0                  # wait-state counter
         self.last_valu_write = {}           # (kind, idx) -> issue_idx
         self.last_trans_write = {}
+        self.last_dot_write = {}            # (kind, idx) -> issue_idx of a v_dot2* write (3 wait states before another kind of VALU may read it)
         self.last_m0_write = -100
         self.at_barrier = False
         self.done = False
@@ -178,6 +179,10 @@ class Machine:
                 lw = w.last_valu_write.get(key, -100)
                 if w.issue_idx - lw < 3:
                     self.err(w, "MFMA reads %s%d %d wait states after a VALU write (needs 2)" % (kind, i, w.issue_idx - lw - 1))
+            if reader in ("valu", "permlane", "mfma_ab", "mfma_c"):
+                lw = w.last_dot_write.get(key, -100)
+                if w.issue_idx - lw < 4:
+                    self.err(w, "%s%d read %d wait states after a DOT instruction wrote it (needs 3; not interlocked on gfx950)" % (kind, i, w.issue_idx - lw - 1))
             if reader == "valu":
                 lw = w.last_trans_write.get(key, -100)
                 if w.issue_idx - lw < 2:
@@ -197,6 +202,10 @@ class Machine:
             self.err(w, "%s%d written while a load into it is in flight" % key)
         self.regfile(w, o.kind)[o.idx] = val.astype(np.uint32)
         w.mfma_ready.pop(key, None)
+        w.last_dot_write.pop(key, None)
+        if writer == "dot":
+            w.last_valu_write[key] = w.issue_idx
+            w.last_dot_write[key] = w.issue_idx
         if writer == "valu":
             w.last_valu_write[key] = w.issue_idx
             w.last_trans_write.pop(key, None)
@@ -541,6 +550,25 @@ class Machine:
                 for i in range(4):
                     rf[dst.idx + i] = data[:, i]
             w.vm.append(land)
+        elif op == "global_load_dword":
+            dst, a, sb = R(0), R(1), R(2)
+            self.check_read(w, a.kind, a.idx, 1, "valu")
+            base = int(sb[0]) | (int(sb[1]) << 32)
+            addr = base + self.regfile(w, a.kind)[a.idx].astype(np.int64) + ins.mods.get("offset", 0)
+            data = np.array([self.gread(int(x), 4).view(np.uint32)[0] for x in addr], dtype=np.uint32)
+            self.mark_inflight(w, dst, 1, +1)
+
+            def land(dst=dst, data=data):
+                self.mark_inflight(w, dst, 1, -1)
+                self.regfile(w, dst.kind)[dst.idx] = data
+            w.vm.append(land)
+        elif op in ("v_dot2_f32_f16", "v_dot2_f32_bf16"):
+            conv = bf16_to_f32 if op.endswith("bf16") else f16_to_f32
+            x, y = self.rd32(w, ops[1]), self.rd32(w, ops[2])
+            acc = self.rdf(w, ops[3], "dot_c").astype(np.float64)          # (the same opcode may chain on its accumulator)
+            for sh in (0, 16):
+                acc = acc + conv(((x >> sh) & 0xffff).astype(np.uint16)).astype(np.float64) * conv(((y >> sh) & 0xffff).astype(np.uint16)).astype(np.float64)
+            self.wr32(w, ops[0], acc.astype(np.float32), writer="dot")
         elif op == "buffer_load_dwordx4":
             assert ins.mods.get("lds") and ins.mods.get("offen")
             if self.check and w.issue_idx - w.last_m0_write < 2:

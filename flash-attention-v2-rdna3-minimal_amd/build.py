@@ -115,9 +115,13 @@ def generate(out_dir=None, opts=None, probe=False):
     return out_dir
 
 
-def compile_library(out_path, extra_flags=(), inc_dir=None, verbose=False, jobs=None):
+OBJ_DIR = os.path.join(PKG_DIR, "build", "obj")      # objects of the last product build (developer variants relink against them)
+
+
+def compile_library(out_path, extra_flags=(), inc_dir=None, verbose=False, jobs=None, only=None, keep_objects=False):
     """hipcc every translation unit (in parallel) and link them into `out_path`.  inc_dir: where the generated .inc files are
-    (default csrc/).  Returns the concatenated compiler output (resource usage remarks with verbose=True)."""
+    (default csrc/).  only: names of the units to recompile (developer variants: the others are taken from the objects the last
+    product build kept in build/obj).  Returns the concatenated compiler output (resource usage remarks with verbose=True)."""
     units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[1]))]
     tmpdir = tempfile.mkdtemp(prefix="fa2_build_")
     log = []
@@ -132,8 +136,15 @@ def compile_library(out_path, extra_flags=(), inc_dir=None, verbose=False, jobs=
             cmd += ["-c", os.path.join(CSRC, src), "-o", os.path.join(tmpdir, obj + ".o")]
             res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
             return obj, res
-        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as ex:
-            for obj, res in ex.map(one, units):
+        todo = [u for u in units if only is None or u[0] in only]
+        for u in units:
+            if u not in todo:
+                cached = os.path.join(OBJ_DIR, u[0] + ".o")
+                if not os.path.exists(cached):
+                    raise RuntimeError("no cached object for %s: run build.py --force first" % u[0])
+                shutil.copy(cached, os.path.join(tmpdir, u[0] + ".o"))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 4)) as ex:
+            for obj, res in ex.map(one, todo):
                 log.append(res.stdout + res.stderr)
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed on %s (%d):\n%s\n%s" % (obj, res.returncode, res.stdout[-4000:], res.stderr[-8000:]))
@@ -145,6 +156,10 @@ def compile_library(out_path, extra_flags=(), inc_dir=None, verbose=False, jobs=
                 os.remove(tmp)
             raise RuntimeError("link failed (%d):\n%s\n%s" % (res.returncode, res.stdout, res.stderr))
         os.replace(tmp, out_path)
+        if keep_objects:
+            os.makedirs(OBJ_DIR, exist_ok=True)
+            for u in units:
+                shutil.copy(os.path.join(tmpdir, u[0] + ".o"), os.path.join(OBJ_DIR, u[0] + ".o"))
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
     return "\n".join(log)
@@ -209,7 +224,7 @@ def build(force=False, verbose=False):
                 return LIB_PATH
             digest = _source_digest()
             generate()
-            log = compile_library(LIB_PATH, verbose=verbose)
+            log = compile_library(LIB_PATH, verbose=verbose, keep_objects=True)
             if verbose:
                 print(log, file=sys.stderr)
             ok = build_frontend(verbose) is not None

@@ -27,10 +27,15 @@ constexpr int kBwdTile = 32;                           // rows per swept tile of
 
 typedef uint32_t bwd_u32x4s __attribute__((ext_vector_type(4)));
 
+// granule swizzle of the unified LDS image format (f_swz of the generator): one image serves ds_read_b128 row reads and
+// ds_read_b64_tr_b16 transposed reads
+__device__ __forceinline__ uint32_t bwd_swz(uint32_t r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); }
+
 // ---------------------------------------------------------------------------------------------------------
 // dQ pass: workgroup = 256 Q rows (4 waves x 64), sweep over KV tiles of 32.  Also writes delta = rowsum(dO * O).
 // Requires D == 128 (host.cpp dispatch); any Nq, Nkv (clamped rows, masked tail tiles), causal or not.
-template <bool BF16, bool CAUSAL>
+// NEG_DELTA: the delta workspace receives -delta (what the hand-scheduled dK/dV pass takes as the C operand of its dP product).
+template <bool BF16, bool CAUSAL, bool NEG_DELTA>
 __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -79,12 +84,19 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
     // LDS-DMA: piece i of this wave fills image bytes [wave*2048 + i*1024, +1024): lane l supplies the source of image slot
     // (row = 8*wave + 4*i + l/16, slot = l%16); the asm block derives piece 1 from piece 0
     const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
+#ifdef FA2_BWD_DQ_UNI      // developer build (generator opt "uni"): every image in the unified format of the dK/dV pass
+    const uint32_t kd0 = drow * k_rowb + ((dslot ^ bwd_swz(drow)) << 4), vd0 = drow * v_rowb + ((dslot ^ bwd_swz(drow)) << 4), td0 = kd0;
+    const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
+    const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
+    const uint32_t vr0 = trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
+#else
     const uint32_t kd0 = drow * k_rowb + ((dslot ^ (drow & 15u)) << 4);                                   // row images: granule ^ (row & 15)
     const uint32_t vd0 = drow * v_rowb + ((dslot ^ (drow & 15u)) << 4);
     const uint32_t td0 = drow * k_rowb + (((((dslot >> 2) ^ (drow & 3u)) << 2) | (dslot & 3u)) << 4);     // "tr" image: 64-B chunk ^ (row & 3)
     const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ ((uint32_t)l31 & 15u)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1;
     const uint32_t vr0 = (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
+#endif
     const uint32_t epi = kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
 
     const uint64_t qbase = (uint64_t)((const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1]);
@@ -97,14 +109,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
     const bwd_u32x4s vrs = {(uint32_t)va, (uint32_t)(va >> 32) & 0xffffu, p.v_bytes, 0x00020000u};
     const uint32_t k_tile = kBwdTile * k_rowb, v_tile = kBwdTile * v_rowb, k_row4 = 4 * k_rowb - 1024, v_row4 = 4 * v_rowb - 1024;
     const uint32_t ldsw = wave * 2048;
-    const float c = p.c, scale = p.scale;
+    const float c = p.c, scale = p.scale, dsign = NEG_DELTA ? -1.0f : 1.0f;
     float d0, d1;
 
 #define FA2_BWD_DQ_OPERANDS                                                                                                     \
     : "=&v"(d0), "=&v"(d1)                                                                                                      \
     : "v"(qo[0]), "v"(qo[1]), "v"(go[0]), "v"(go[1]), "v"(oo[0]), "v"(oo[1]), "v"(lo[0]), "v"(lo[1]), "v"(kd0), "v"(vd0),       \
       "v"(td0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(epi), "s"(qbase), "s"(gbase), "s"(obase), "s"(lbase), "s"(krs), "s"(vrs), \
-      "s"(c), "s"(scale), "s"(ntw), "s"(ntwg), "s"(k_tile), "s"(v_tile), "s"(k_row4), "s"(v_row4), "s"(ldsw)                     \
+      "s"(c), "s"(scale), "s"(ntw), "s"(ntwg), "s"(k_tile), "s"(v_tile), "s"(k_row4), "s"(v_row4), "s"(ldsw), "s"(dsign)         \
     :
     if constexpr (BF16) {
         asm volatile(
@@ -135,6 +147,100 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
         const int r = i * 4 + rl;
         const u32x4 w = *(const u32x4*)(img + r * kBwdEpiRowB + cl * 16);
         if (qw0 + r < p.Nq) *(u32x4*)(out + (int64_t)(qw0 + r) * p.dqs[2] + cl * 8) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dK / dV pass: workgroup = 128 KV rows = two wave pairs (P side + dS side, csrc/gen/bwd_d128_gen.py class KV), sweep over Q tiles of 32.
+// Requires D == 128 and Nq % 32 == 0 (host dispatch); any Nkv; causal or not.  Reads -delta from the workspace.
+constexpr int kBwdKvLdsBytes = 4 * 64 * kBwdEpiRowB;         // KV.LDS_BYTES = 69632 (rings 48 KiB + P slots 16 KiB; the epilogue image reuses them)
+constexpr int kBwdKvPSlots = 49152;
+
+template <bool BF16, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, role = wave & 1;
+
+    // block -> (head, kv block of 128): as in bwd_dkv_pair_kernel (causal: the FIRST kv block sweeps the most Q tiles -> ascending, across heads)
+    const int nbh = p.B * p.H, bid = blockIdx.x;
+    int bh, kblk;
+    if ((nbh & 7) == 0) {
+        const int slot = bid >> 3, hpx = nbh >> 3;
+        if (CAUSAL) { bh = (bid & 7) + 8 * (slot % hpx); kblk = slot / hpx; }
+        else { bh = (bid & 7) + 8 * (slot / p.nblk); kblk = slot % p.nblk; }
+    } else if (CAUSAL) { bh = bid % nbh; kblk = bid / nbh; }
+    else { bh = bid / p.nblk; kblk = bid % p.nblk; }
+    const int b = bh / p.H, h = bh % p.H;
+    const int kv0 = kblk * 128, kvw0 = kv0 + 64 * pair;
+
+    const uint32_t q_rowb = (uint32_t)p.qs[2] * 2u, g_rowb = (uint32_t)p.dos[2] * 2u;
+    const uint32_t f_rowb = (uint32_t)(role ? p.vs[2] : p.ks[2]) * 2u;
+    const int tile0 = CAUSAL ? kv0 / kBwdTile : 0;
+    int n = p.Nq / kBwdTile - tile0;
+    n = n < 1 ? 1 : n;                 // (a causal block whose rows all lie past Nq: one fully masked tile, the results are zeros)
+
+    uint32_t fo[2];
+    int lim[2];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) {
+        const int kvrow = kvw0 + 32 * kvb + l31;
+        const uint32_t kr = (uint32_t)(kvrow < p.Nkv ? kvrow : p.Nkv - 1);
+        fo[kvb] = kr * f_rowb + 16u * hi;
+        lim[kvb] = CAUSAL ? kvrow - kBwdTile * tile0 - 4 * hi : -(1 << 30);
+    }
+    const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
+    const uint32_t qd0 = drow * q_rowb + ((dslot ^ bwd_swz(drow)) << 4), gd0 = drow * g_rowb + ((dslot ^ bwd_swz(drow)) << 4);
+    const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
+    const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
+    const uint32_t vr0 = trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
+    const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = 16u * hi;
+    const uint32_t epi = wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
+
+    const uint64_t fbase = role ? (uint64_t)((const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1]) : (uint64_t)((const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1]);
+    const uint64_t qa = (uint64_t)((const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1]);
+    const uint64_t ga = (uint64_t)((const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1]);
+    const uint64_t la = (uint64_t)((role ? p.delta : p.lse) + b * p.ls[0] + h * p.ls[1]);
+    const bwd_u32x4s qrs = {(uint32_t)qa, (uint32_t)(qa >> 32) & 0xffffu, p.q_bytes, 0x00020000u};
+    const bwd_u32x4s grs = {(uint32_t)ga, (uint32_t)(ga >> 32) & 0xffffu, p.do_bytes, 0x00020000u};
+    const bwd_u32x4s lrs = {(uint32_t)la, (uint32_t)(la >> 32) & 0xffffu, p.l_bytes, 0x00020000u};
+    const float c = p.c, oscale = role ? p.scale : 1.0f;
+    const uint32_t qoff0 = (uint32_t)tile0 * kBwdTile * q_rowb, goff0 = (uint32_t)tile0 * kBwdTile * g_rowb, loff0 = (uint32_t)tile0 * 128u;
+    const uint32_t q_tile = kBwdTile * q_rowb, g_tile = kBwdTile * g_rowb, q_row4 = 4 * q_rowb - 1024, g_row4 = 4 * g_rowb - 1024;
+    const uint32_t ldsw = wave * 2048;
+
+#define FA2_BWD_KV_OPERANDS                                                                                                       \
+    :                                                                                                                             \
+    : "v"(fo[0]), "v"(fo[1]), "v"(qd0), "v"(gd0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(pxa), "v"(lda), "v"(epi),      \
+      "s"(fbase), "s"(qrs), "s"(grs), "s"(lrs), "s"(c), "s"(oscale), "s"(n), "s"(qoff0), "s"(goff0), "s"(loff0), "s"(q_tile),     \
+      "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role)                                                                 \
+    :
+    if constexpr (BF16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_bf16.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    } else {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_f16.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    }
+#undef FA2_BWD_KV_OPERANDS
+
+    // ---- the wave's 64 x 128 tile (dV on the P side, dK on the dS side) is in its LDS image: whole-row stores
+    const char* img = smem + wave * 64 * kBwdEpiRowB;
+    const int rl = lane >> 4, cl = lane & 15;
+    uint16_t* out = role ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1];
+    const int64_t orow = role ? p.dks[2] : p.dvs[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = i * 4 + rl;
+        const u32x4 w = *(const u32x4*)(img + r * kBwdEpiRowB + cl * 16);
+        if (kvw0 + r < p.Nkv) *(u32x4*)(out + (int64_t)(kvw0 + r) * orow + cl * 8) = w;
     }
 }
 

@@ -49,8 +49,9 @@ FA2_HIDDEN int launch_fwd_d128(bool bf16, const FwdParams& p, bool causal, hipSt
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 // hand-scheduled backward, head dim exactly 128 (bwd_asm.cpp); same `parts`
-FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// neg_delta: the dQ pass writes -delta (the hand-scheduled dK/dV pass reads it as such; the HIP dK/dV passes read +delta)
+FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, hipStream_t stream);
 
-constexpr int kBwdAsmParts = 1;      // passes the hand-scheduled backward covers: bit 0 = dQ, bit 1 = dK / dV
+constexpr int kBwdAsmParts = 3;      // passes the hand-scheduled backward covers: bit 0 = dQ, bit 1 = dK / dV
 
 }  // namespace fa2

@@ -40,6 +40,13 @@ from isa import A, S, V, Arg, Ins, Label, M0, Neg, Program, VCC, mk  # noqa: E40
 NEG_INF = float("-inf")
 
 
+def f_swz(r):
+    """granule swizzle of the UNIFIED image format (one image for ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads):
+    granule g of row r at r*256 + ((g ^ f(r)) << 4).  The 16 rows of a b128 lane group get 16 different granule slots, the 4 rows x 64 B
+    of a transposed read 4 different 64-byte bank quarters."""
+    return ((r & 3) << 2) | ((r >> 2) & 3)
+
+
 def _flat(items):
     out = []
     for x in items:
@@ -87,7 +94,8 @@ class DQ:
     A_KTILE, A_VTILE = Arg(28, "s"), Arg(29, "s")  # bytes between consecutive KV tiles in K / V
     A_KROW4, A_VROW4 = Arg(30, "s"), Arg(31, "s")  # 4 * row bytes - 1024: source stride between the two DMA pieces of a wave
     A_LDSW = Arg(32, "s")                          # wave * 2048: this wave's quarter of a tile image
-    N_ARGS = 33
+    A_DSIGN = Arg(33, "s")                         # +1.0 / -1.0 (f32 bits): the sign delta leaves with (the hand-scheduled dK/dV pass wants -delta)
+    N_ARGS = 34
     N_VARGS = 18
 
     VBASE = 24
@@ -116,6 +124,7 @@ class DQ:
     NL = [V(234), V(235)]                          # -LSE of this lane's row, per q block
     DD = [V(236), V(237)]                          # delta of this lane's row
     TMP = [V(238 + i) for i in range(8)]
+    VRB = [V(246 + i) for i in range(4)]           # opt "uni" only: transposed read addresses of rows +8..11 (the unified swizzle differs in one bit)
 
     @staticmethod
     def ACC(qb, dt):
@@ -213,7 +222,7 @@ class GenDQ(BodyEmitter):
             for dt in range(4):
                 off = DQ.TR_RING + par * DQ.TR_SLOT + 16 * ks * 256
                 out.append(mk("ds_read_b64_tr_b16", DQ.TP(dt, ks).sub(0, 2), DQ.VR[dt], tag="lds", offset=off))
-                out.append(mk("ds_read_b64_tr_b16", DQ.TP(dt, ks).sub(2, 2), DQ.VR[dt], tag="lds", offset=off + 8 * 256))
+                out.append(mk("ds_read_b64_tr_b16", DQ.TP(dt, ks).sub(2, 2), (DQ.VRB if "uni" in self.opt else DQ.VR)[dt], tag="lds", offset=off + 8 * 256))
         return out
 
     def dma_group(self, which, slot_par, guarded, ahead):
@@ -290,6 +299,10 @@ class GenDQ(BodyEmitter):
             p.emit("v_xor_b32", DQ.KR[ks], ks << 5, DQ.A_KR0)
         for dt in range(4):
             p.emit("v_xor_b32", DQ.VR[dt], dt << 6, DQ.A_VR0)
+        if "uni" in self.opt:
+            p.emit("s_nop", 0)
+            for dt in range(4):
+                p.emit("v_xor_b32", DQ.VRB[dt], 32, DQ.VR[dt])
         # loads: Q fragments straight into their AGPRs; dO and O through the (still unused) S / dP banks for delta
         tg, to = V(24, 64), V(88, 64)
         for qb in range(2):
@@ -308,9 +321,15 @@ class GenDQ(BodyEmitter):
         p.emit("v_mov_b32", DQ.KD[0], DQ.A_KD0)
         p.emit("v_mov_b32", DQ.VD[0], DQ.A_VD0)
         p.emit("v_mov_b32", DQ.TD[0], DQ.A_TD0)
-        p.emit("v_xor_b32", DQ.KD[1], 64, DQ.A_KD0)
-        p.emit("v_xor_b32", DQ.VD[1], 64, DQ.A_VD0)
-        p.emit("v_add_u32", DQ.TD[1], DQ.A_KROW4, DQ.A_TD0)
+        uni = "uni" in self.opt     # unified format: rows +4 flip bit 0 of the granule swizzle in every image
+        p.emit("v_xor_b32", DQ.KD[1], 16 if uni else 64, DQ.A_KD0)
+        p.emit("v_xor_b32", DQ.VD[1], 16 if uni else 64, DQ.A_VD0)
+        if uni:
+            p.emit("v_xor_b32", DQ.TD[1], 16, DQ.A_TD0)
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", DQ.TD[1], DQ.A_KROW4, DQ.TD[1])
+        else:
+            p.emit("v_add_u32", DQ.TD[1], DQ.A_KROW4, DQ.A_TD0)
         p.emit("s_nop", 0)
         p.emit("v_add_u32", DQ.KD[1], DQ.A_KROW4, DQ.KD[1])
         p.emit("v_add_u32", DQ.VD[1], DQ.A_VROW4, DQ.VD[1])
@@ -432,12 +451,449 @@ class GenDQ(BodyEmitter):
                     p.emit("ds_write_b128", DQ.A_EPI, V(T[0].idx, 4), offset=32 * qb * DQ.EPI_ROWB + (32 * dt + 8 * r4) * 2)
                     p.emit("s_nop", 1)
         p.emit("s_waitcnt", lgkmcnt=0)
-        p.emit("v_mov_b32", DQ.A_D0, DQ.DD[0])
-        p.emit("v_mov_b32", DQ.A_D1, DQ.DD[1])
+        p.emit("v_mul_f32", DQ.A_D0, DQ.A_DSIGN, DQ.DD[0])
+        p.emit("v_mul_f32", DQ.A_D1, DQ.A_DSIGN, DQ.DD[1])
         p.emit("s_branch", Label("end"))
         for r in self.rare:
             p.extend(r)
         p.label("end")
+        return p
+
+
+# =====================================================================================================================
+#                                                     dK / dV pass
+# =====================================================================================================================
+class KV:
+    """Register map and operand list of the dK/dV statement (order = the operand list in fa2_bwd_d128.hip.h).
+
+    Workgroup = 4 waves = 128 KV rows = two wave PAIRS; pair p owns KV rows [64p, 64p+64) as two 32-row blocks kvb.  The two waves
+    of a pair sit on different SIMDs and split the four products (the two KV-owned accumulators do not fit one wave):
+        P side   (wave 2p)    S[q,kv] = Q K^T (K rows as B fragments), P = 2^(S c - L), dV^T[d,kv] += dO^T P     accumulates dV
+        dS side  (wave 2p+1)  dP[q,kv] = dO V^T - delta (V rows as B fragments; -delta is the C operand of the first k-step),
+                              dS = P (dP - delta), dK^T[d,kv] += Q^T dS                                              accumulates dK
+    P crosses once per tile through a 4-KiB LDS slot as the packed 16-bit B fragments the dV product consumes (lane for lane: S and
+    dP have the same register layout), so S and P are formed once for both products: 4 GEMMs per (q, kv) pair.
+    Q is swept in tiles of 32 rows (the launcher requires Nq % 32 == 0: no partial tile, so no row of a tile lies beyond Nq; KV rows
+    beyond Nkv are clamped reads whose results are not stored); Q and dO tiles are staged ONCE each, in the unified image format (f_swz) that serves the row
+    reads of one wave and the transposed reads of its partner: Q ring 4 slots (a tile lives from body t-3 to body t), dO ring 2.
+    L and -delta of a tile bypass LDS: four buffer_load_dwordx4 per wave return them in the accumulator's register layout.
+
+    Pipelines (body B(t), t = -2 .. n, one barrier each, 32 MFMAs per wave):
+        P side    MFMA 0..15 dV(t), 16..31 S(t+2);  VALU: P(t+1) -> packed in place -> written to the pair's slot
+        dS side   MFMA 0..15 dK(t-1), 16..31 dP(t+1);  VALU: dS(t) = P(t) * dP'(t), packed in place
+      every phase's A fragments are read from LDS one phase earlier; LDS-DMA: Q(t+3), dO(t+2); loads: L(t+2) / -delta(t+2).
+    """
+    A_FO0, A_FO1 = Arg(0), Arg(1)                  # byte offset of this lane's 16 bytes (k-step 0) of its own K (P side) / V (dS side) row, block 0 / 1
+    A_QD0, A_GD0 = Arg(2), Arg(3)                  # per-lane LDS-DMA source byte offset (piece 0, tile 0) in Q / dO
+    A_KR0, A_VR0 = Arg(4), Arg(5)                  # per-lane LDS read offset: row fragment k-step 0 / transposed fragment d block 0 (rows +0..3)
+    A_LIM0, A_LIM1 = Arg(6), Arg(7)                # P side, causal: this lane's kv row (minus 4*hi, minus the first tile's q0) per block; -big otherwise
+    A_PXA = Arg(8)                                 # per-lane LDS byte address in the pair's P slot (parity 0)
+    A_LDA = Arg(9)                                 # per-lane byte offset into a tile's 32 L / delta values: 16 * hi
+    A_EPI = Arg(10)                                # per-lane LDS byte address of the epilogue image: row l31, half hi
+    A_FB = Arg(11, "s", 2)                         # head base of K (P side) / V (dS side)
+    A_QRS, A_GRS, A_LRS = Arg(12, "s", 4), Arg(13, "s", 4), Arg(14, "s", 4)   # buffer descriptors: Q, dO, LSE (P side) / delta workspace (dS side)
+    A_C, A_OSCALE = Arg(15, "s"), Arg(16, "s")     # scale * log2(e); factor of the stored accumulator (1.0: dV, scale: dK)
+    A_N = Arg(17, "s")                             # number of 32-row Q tiles this workgroup sweeps
+    A_QOFF0, A_GOFF0, A_LOFF0 = Arg(18, "s"), Arg(19, "s"), Arg(20, "s")     # byte offset of the first swept tile in Q / dO / the L array
+    A_QTILE, A_GTILE = Arg(21, "s"), Arg(22, "s")  # bytes between consecutive tiles in Q / dO
+    A_QROW4, A_GROW4 = Arg(23, "s"), Arg(24, "s")  # 4 * row bytes - 1024
+    A_LDSW = Arg(25, "s")                          # wave * 2048: this wave's quarter of a tile image
+    A_ROLE = Arg(26, "s")                          # 0: P side, 1: dS side
+    N_ARGS, N_VARGS = 27, 11
+    VBASE = 16
+
+    @staticmethod
+    def BK(par, kvb):                              # S / P bank (P side) or dP / dS bank (dS side): f32, packed in place
+        return V(16 + 32 * par + 16 * kvb, 16)
+
+    @staticmethod
+    def LR(par):                                   # L (P side) / -delta (dS side) of a tile in the accumulator's register layout
+        return V(80 + 16 * par, 16)
+
+    @staticmethod
+    def RP(ks):                                    # row fragments of the next phase B: Q rows (P side) / dO rows (dS side)
+        return V(112 + 4 * ks, 4)
+
+    @staticmethod
+    def TP(dt, ks):                                # transposed fragments of the next phase A: dO^T (P side) / Q^T (dS side)
+        return V(144 + 16 * ks + 4 * dt, 4)
+
+    KR = [V(176 + i) for i in range(8)]            # row read addresses (P side: Q ring, moves every body; dS side: dO ring, static)
+    VR = [V(184 + i) for i in range(4)]            # transposed read addresses, rows +0..3 (P side: dO ring, static; dS side: Q ring, moves)
+    VRB = [V(188 + i) for i in range(4)]           # ... rows +8..11
+    QD = [V(192), V(193)]                          # LDS-DMA source offsets of this wave's 2 pieces of a Q tile
+    GD = [V(194), V(195)]                          # ... dO tile
+    PR = V(196, 16)                                # dS side: the pair's packed P words of a tile
+    LIMT = [V(212), V(213)]                        # P side, masked bodies: the limit relative to the tile
+    TMP = [V(214 + i) for i in range(8)]
+    XA = V(222)                                    # P slot address of this lane
+
+    @staticmethod
+    def ACC(kvb, dt):
+        return A(64 * kvb + 16 * dt, 16)
+
+    @staticmethod
+    def FF(kvb, ks):                               # the wave's own rows as B fragments: K (P side) / V (dS side)
+        return A(128 + 32 * kvb + 4 * ks, 4)
+
+    S_T, S_QOFF, S_GOFF, S_LOFF, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
+    S_NFAST, S_D, S_QSLOT, S_BUMP, S_M0Q = S(66), S(67), S(68), S(69), S(70)
+    CLOBBER_S = list(range(60, 72))
+
+    Q_RING, G_RING, P_SLOTS, SLOT = 0, 32768, 49152, 8192
+    EPI_ROWB = 272
+    LDS_BYTES = 4 * 64 * 272                       # 69632: the epilogue image (over the rings, which are dead by then) is the largest user
+
+
+class GenDKV(BodyEmitter):
+    DEFAULTS = {"valu_p": (1.0, 31.0), "valu_s": (1.0, 31.0), "rowread": (0.0, 15.0), "trread": (16.0, 31.0), "dma": (1.0, 12.0), "opt": (), "abl": ()}
+
+    def __init__(self, bf16=False, **cfg):
+        self.cfg = dict(self.DEFAULTS)
+        self.cfg.update(cfg)
+        self.opt = set(self.cfg["opt"])
+        self.bf16 = bf16
+        self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if bf16 else "v_cvt_pk_f16_f32"
+        self.p = Program()
+
+    # ------------------------------------------------------------------ MFMA lists (shared shapes, role-specific operands)
+    def acc_mfmas(self, par):
+        """phase A: ACC[kvb][dt] += T(dt, ks') . X(kvb, ks') with X = the packed fragments in bank `par` (P side: P(t), dS side: dS(t-1))"""
+        out = []
+        for ks in range(2):
+            for kvb in range(2):
+                for dt in range(4):
+                    out.append(mk(self.mfma, KV.ACC(kvb, dt), KV.TP(dt, ks), KV.BK(par, kvb).sub(8 * ks, 4), KV.ACC(kvb, dt), tag="mfma"))
+        return out
+
+    def row_mfmas(self, par, cinit):
+        """phase B: BK[par][kvb] = R(ks) . F(kvb, ks) over the 8 k-steps (P side: S(t+2); dS side: dP(t+1), starting from -delta)"""
+        out = []
+        for ks in range(8):
+            for kvb in range(2):
+                dst = KV.BK(par, kvb)
+                c0 = KV.LR(par) if cinit else 0
+                out.append(mk(self.mfma, dst, KV.RP(ks), KV.FF(kvb, ks), c0 if ks == 0 else dst, tag="mfma"))
+        return out
+
+    # ------------------------------------------------------------------ filler streams
+    def stream_p(self, kvb, par, masked):
+        """P side: P = 2^(S c - L[q]) for the tile in bank par, pairs packed in place, then the block's two fragments go to the slot."""
+        s, L = KV.BK(par, kvb), KV.LR(par)
+        out = []
+        if masked:      # causal: q (tile-local: (r&3) + 8(r>>2), + 4*hi folded into the limit) must be >= this lane's kv row
+            t2 = KV.TMP[4 * kvb]
+            out.append(mk("v_mov_b32", t2, NEG_INF, tag="valu"))
+            for r in range(16):
+                out.append([mk("v_cmp_ge_i32", VCC, (r & 3) + 8 * (r >> 2), KV.LIMT[kvb], tag="valu"),
+                            mk("v_cndmask_b32", s[r], t2, s[r], VCC, tag="valu")])
+        for k in range(8 + 2):
+            F, E, C = [], [], []
+            if k < 8:
+                for e in (2 * k, 2 * k + 1):
+                    F.append(mk("v_fma_f32", s[e], s[e], KV.A_C, Neg(L[e]), tag="valu"))
+            if 0 <= k - 1 < 8:
+                for e in (2 * (k - 1), 2 * (k - 1) + 1):
+                    E.append(mk("v_exp_f32", s[e], s[e], tag="trans"))
+            if 0 <= k - 2 < 8:
+                e = 2 * (k - 2)
+                C.append(mk(self.cvt, s[8 * (e // 8) + (e % 8) // 2], s[e], s[e + 1], tag="valu"))
+            out += F + E + C
+            if k - 2 in (3, 7):      # a k-step's four words are packed: hand them to the partner wave
+                ks = (k - 2) // 4
+                out.append(mk("ds_write_b128", KV.XA, s.sub(8 * ks, 4), tag="lds", offset=par * 4096 + 1024 * (2 * kvb + ks)))
+        return out
+
+    def stream_pread(self, par):
+        return [mk("ds_read_b128", KV.PR.sub(4 * j, 4), KV.XA, tag="lds", offset=par * 4096 + 1024 * j) for j in range(4)]
+
+    def stream_ds(self, kvb, par):
+        """dS side: dS = P16 * dP' for the tile in bank par (dP' = dP - delta left the MFMA), pairs packed in place."""
+        d = KV.BK(par, kvb)
+        out = []
+        for k in range(8 + 1):
+            M, C = [], []
+            if k < 8:
+                for e in (2 * k, 2 * k + 1):
+                    word = KV.PR[4 * (2 * kvb + e // 8) + (e % 8) // 2]
+                    if self.bf16:
+                        t = KV.TMP[4 * kvb + (2 * k + (e & 1)) % 4]      # (the two blocks' streams are interleaved: own scratch registers each)
+                        M.append(mk("v_and_b32", t, 0xffff0000, word, tag="valu") if e & 1 else mk("v_lshlrev_b32", t, 16, word, tag="valu"))
+                        M.append(mk("v_mul_f32", d[e], t, d[e], tag="valu"))
+                    else:
+                        M.append(mk("v_fma_mix_f32", d[e], word, d[e], 0, tag="valu", op_sel="[%d,0,0]" % (e & 1), op_sel_hi="[1,0,0]"))
+            if 0 <= k - 1 < 8:
+                e = 2 * (k - 1)
+                C.append(mk(self.cvt, d[8 * (e // 8) + (e % 8) // 2], d[e], d[e + 1], tag="valu"))
+            out += M + C
+        return out
+
+    def stream_rowread(self, base):
+        return [mk("ds_read_b128", KV.RP(ks), KV.KR[ks], tag="lds", offset=base) for ks in range(8)]
+
+    def stream_trread(self, base):
+        out = []
+        for ks in range(2):
+            for dt in range(4):
+                out.append(mk("ds_read_b64_tr_b16", KV.TP(dt, ks).sub(0, 2), KV.VR[dt], tag="lds", offset=base + 16 * ks * 256))
+                out.append(mk("ds_read_b64_tr_b16", KV.TP(dt, ks).sub(2, 2), KV.VRB[dt], tag="lds", offset=base + (16 * ks + 8) * 256))
+        return out
+
+    def stream_dma(self, par):
+        """Q(t+3) -> Q ring slot (t+3) % 4 (M0 from the running slot counter), dO(t+2) -> dO ring slot t % 2 = par; then the four
+        loads of L / -delta of tile t+2 into LR(par) (not LDS: they return in the accumulator's register layout)."""
+        out = [[mk("s_mov_b32", M0, KV.S_M0Q, tag="salu"), mk("s_nop", 0, tag="salu")]]
+        for i in range(2):
+            out.append(mk("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, tag="dma", offen=True, offset=1024 * i, lds=True))
+        out.append([mk("s_add_u32", M0, KV.A_LDSW, KV.G_RING + par * KV.SLOT, tag="salu"), mk("s_nop", 0, tag="salu")])
+        for i in range(2):
+            out.append(mk("buffer_load_dwordx4", KV.GD[i], KV.A_GRS, KV.S_GOFF, tag="dma", offen=True, offset=1024 * i, lds=True))
+        for g in range(4):
+            out.append(mk("buffer_load_dwordx4", KV.LR(par).sub(4 * g, 4), KV.A_LDA, KV.A_LRS, KV.S_LOFF, tag="dma", offen=True, offset=32 * g))
+        return out
+
+    # ------------------------------------------------------------------ one body
+    def body(self, role, par, acc=True, valu=True, row=True, masked=False, tr=True, rr=True, name="body"):
+        """B(t), t & 1 == par, for one role.  acc: phase A (P: dV(t), dS: dK(t-1)); valu: the VALU work (P: tile t+1, bank par^1;
+        dS: tile t, bank par); row: phase B (P: S(t+2) -> bank par; dS: dP(t+1) -> bank par^1); tr / rr: the transposed / row
+        fragment reads for the NEXT body's phase A / this body's phase B."""
+        p, cfg = self.p, self.cfg
+        abl = set(cfg["abl"]) if name.startswith("F") else set()
+        ng = 32
+        P = role == 0
+        if P:
+            mf = (self.acc_mfmas(par) if acc else [None] * 16) + (self.row_mfmas(par, False) if row else [None] * 16)
+        else:
+            mf = (self.acc_mfmas(par ^ 1) if acc else [None] * 16) + (self.row_mfmas(par ^ 1, True) if row else [None] * 16)
+        if "mfma" in abl:
+            mf = [None] * ng
+        load = [0.0] * ng
+        slots = [[] for _ in range(ng)]
+        pre = []
+        if not acc:
+            pre += [mk("s_nop", 15), mk("s_nop", 15)]
+        if P and masked and valu:
+            for kvb in range(2):      # this lane's limit relative to tile t+1: LIM - 32 (t + 1)
+                pre.append(mk("s_add_u32", KV.S_TMP, KV.S_T, 1))
+                pre.append(mk("s_lshl_b32", KV.S_TMP, KV.S_TMP, 5))
+                pre.append(mk("v_subrev_u32", KV.LIMT[kvb], KV.S_TMP, KV.A_LIM0 if kvb == 0 else KV.A_LIM1))
+        if "dma" not in abl:
+            sched.place(load, slots, self.stream_dma(par), cfg["dma"][0], cfg["dma"][1], 2)
+        if P:
+            # Q rows of tile t+2 (Q ring, running address) for phase B; dO^T of tile t+1 (dO ring slot par^1) for the next body's phase A
+            if rr and "rowread" not in abl:
+                sched.place(load, slots, self.stream_rowread(KV.Q_RING), cfg["rowread"][0], cfg["rowread"][1], 3)
+            if tr and "trread" not in abl:
+                sched.place(load, slots, self.stream_trread(KV.G_RING + (par ^ 1) * KV.SLOT), cfg["trread"][0], cfg["trread"][1], 4)
+            if valu and "valu" not in abl:
+                w = cfg["valu_p"]
+                sched.place(load, slots, self.stream_p(0, par ^ 1, masked), w[0], w[1] - 1.0, 5)
+                sched.place(load, slots, self.stream_p(1, par ^ 1, masked), w[0], w[1], 6)
+        else:
+            # dO rows of tile t+1 (dO ring slot par^1) for phase B; Q^T of tile t (Q ring, running address) for the next body's phase A
+            if valu and "valu" not in abl:
+                sched.place(load, slots, self.stream_pread(par), 0.0, 1.0, 1)
+                w = cfg["valu_s"]
+                sched.place(load, slots, self.stream_ds(0, par), w[0], w[1] - 1.0, 5)
+                sched.place(load, slots, self.stream_ds(1, par), w[0], w[1], 6)
+            if rr and "rowread" not in abl:
+                sched.place(load, slots, self.stream_rowread(KV.G_RING + (par ^ 1) * KV.SLOT), cfg["rowread"][0], cfg["rowread"][1], 3)
+            if tr and "trread" not in abl:
+                sched.place(load, slots, self.stream_trread(KV.Q_RING), cfg["trread"][0], cfg["trread"][1], 4)
+        self.last_load = load
+        # end of body: the running tile offsets and the Q ring position move one tile on; everybody meets
+        post = [mk("s_add_u32", KV.S_T, KV.S_T, 1), mk("s_add_u32", KV.S_QOFF, KV.S_QOFF, KV.A_QTILE),
+                mk("s_add_u32", KV.S_GOFF, KV.S_GOFF, KV.A_GTILE), mk("s_add_u32", KV.S_LOFF, KV.S_LOFF, 128),
+                mk("s_add_u32", KV.S_QSLOT, KV.S_QSLOT, 1), mk("s_and_b32", KV.S_QSLOT, KV.S_QSLOT, 3),
+                # this wave's own ring position wraps when the counter reaches 0 (P side: row reads of tile t+2) / 2 (dS side: tile t)
+                mk("s_cmp_eq_u32", KV.S_QSLOT, 0 if P else 2), mk("s_cselect_b32", KV.S_BUMP, 4 * KV.SLOT, 0),
+                mk("s_sub_u32", KV.S_BUMP, KV.SLOT, KV.S_BUMP),
+                # the DMA slot runs one ahead of the P side's row-read slot
+                mk("s_add_u32", KV.S_TMP, KV.S_QSLOT, 1), mk("s_and_b32", KV.S_TMP, KV.S_TMP, 3), mk("s_lshl_b32", KV.S_TMP, KV.S_TMP, 13),
+                mk("s_add_u32", KV.S_M0Q, KV.S_TMP, KV.A_LDSW),
+                mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
+        moving = KV.KR if P else KV.VR + KV.VRB
+        for r in moving:
+            post.append(mk("v_add_u32", r, KV.S_BUMP, r))
+        if "barrier" not in abl:
+            post.append(mk("s_barrier"))
+        self.emit_body(p, mf, slots, pre=pre, post=post)
+
+    # ------------------------------------------------------------------ one role's sweep
+    def role_code(self, role):
+        """bodies t = -2 .. n for one role (labels carry the role suffix).  Every path runs exactly n + 3 bodies."""
+        p = self.p
+        P = role == 0
+        sfx = "_p" if P else "_s"
+        L = lambda name: Label(name + sfx)  # noqa: E731
+        # ---- t = -2 (parity 0): P: S(0);  dS: nothing
+        if P:
+            self.body(0, 0, acc=False, valu=False, row=True, tr=False, name="H1")
+        else:
+            self.body(1, 0, acc=False, valu=False, row=False, tr=False, rr=False, name="H1")
+        # ---- t = -1 (parity 1): P: P(0) (masked), S(1) if n >= 2;  dS: dP(0)
+        if P:
+            p.emit("s_cmp_ge_i32", KV.A_N, 2)
+            p.emit("s_cbranch_scc1", L("h2"))
+            self.body(0, 1, acc=False, valu=True, row=False, masked=True, rr=False, name="H2b")
+            p.emit("s_branch", L("loop"))
+            p.label("h2" + sfx)
+            self.body(0, 1, acc=False, valu=True, row=True, masked=True, name="H2")
+        else:
+            self.body(1, 1, acc=False, valu=False, row=True, tr=False, name="H2")
+        # ---- t >= 0: dispatch on the tiles left, d = n - t (tile t included)
+        p.label("loop" + sfx)
+        p.emit("s_cmp_gt_i32", KV.S_T, KV.A_N)
+        p.emit("s_cbranch_scc1", L("epilogue"))
+        p.emit("s_sub_u32", KV.S_D, KV.A_N, KV.S_T)
+        p.emit("s_and_b32", KV.S_TMP, KV.S_T, 1)
+        p.emit("s_cmp_eq_u32", KV.S_TMP, 1)
+        p.emit("s_cbranch_scc1", L("disp_odd"))
+        for par, ps in ((0, "e"), (1, "o")):
+            if par == 1:
+                p.label("disp_odd" + sfx)
+            # fast bodies: t >= 3 (past the causal diagonal of every pair) and d >= 3 (tiles t+1, t+2 exist): d - 2 of them in a row
+            p.emit("s_cmp_lt_i32", KV.S_D, 3)
+            p.emit("s_cbranch_scc1", L("tail_" + ps))
+            p.emit("s_cmp_lt_i32", KV.S_T, 3)
+            p.emit("s_cbranch_scc1", L("full_" + ps))
+            p.emit("s_sub_u32", KV.S_NFAST, KV.S_D, 2)
+            p.emit("s_branch", L("fast%d" % par))
+            p.label("full_" + ps + sfx)         # like a fast body; the P side masks (tiles 1..3 of the sweep); dS side at t = 0 has no dK yet
+            if P:
+                self.body(0, par, masked=True, name="G%d" % par)
+            else:
+                p.emit("s_cmp_eq_u32", KV.S_T, 0)
+                p.emit("s_cbranch_scc1", L("first_" + ps))
+                self.body(1, par, name="G%d" % par)
+                p.emit("s_branch", L("loop"))
+                p.label("first_" + ps + sfx)
+                self.body(1, par, acc=False, name="G0%d" % par)
+            p.emit("s_branch", L("loop"))
+            p.label("tail_" + ps + sfx)
+            p.emit("s_cmp_eq_u32", KV.S_D, 2)
+            p.emit("s_cbranch_scc1", L("d2_" + ps))
+            p.emit("s_cmp_eq_u32", KV.S_D, 1)
+            p.emit("s_cbranch_scc1", L("d1_" + ps))
+            # d == 0 (t == n): P: nothing;  dS: dK(n-1)
+            if P:
+                self.body(0, par, acc=False, valu=False, row=False, tr=False, rr=False, name="T0%d" % par)
+            else:
+                self.body(1, par, acc=True, valu=False, row=False, tr=False, rr=False, name="T0%d" % par)
+            p.emit("s_branch", L("loop"))
+            p.label("d2_" + ps + sfx)           # tiles t, t+1 left.  P: dV(t), P(t+1), no S;  dS: dK(t-1) (if t >= 1), dS(t), dP(t+1)
+            if P:
+                self.body(0, par, row=False, masked=True, rr=False, name="T2%d" % par)
+            else:
+                p.emit("s_cmp_eq_u32", KV.S_T, 0)
+                p.emit("s_cbranch_scc1", L("d2first_" + ps))
+                self.body(1, par, name="T2%d" % par)
+                p.emit("s_branch", L("loop"))
+                p.label("d2first_" + ps + sfx)
+                self.body(1, par, acc=False, name="T20%d" % par)
+            p.emit("s_branch", L("loop"))
+            p.label("d1_" + ps + sfx)           # tile t is the last.  P: dV(t) only;  dS: dK(t-1) (if t >= 1), dS(t), no dP
+            if P:
+                self.body(0, par, valu=False, row=False, tr=False, rr=False, name="T1%d" % par)
+            else:
+                p.emit("s_cmp_eq_u32", KV.S_T, 0)
+                p.emit("s_cbranch_scc1", L("d1first_" + ps))
+                self.body(1, par, row=False, rr=False, name="T1%d" % par)
+                p.emit("s_branch", L("loop"))
+                p.label("d1first_" + ps + sfx)
+                self.body(1, par, acc=False, row=False, rr=False, name="T10%d" % par)
+            p.emit("s_branch", L("loop"))
+        # the fast loop: alternating parities until the counter runs out, then back to the dispatch
+        for par in (0, 1):
+            p.label("fast%d" % par + sfx)
+            self.body(role, par, name="F%d" % par)
+            p.emit("s_sub_u32", KV.S_NFAST, KV.S_NFAST, 1)
+            p.emit("s_cmp_gt_i32", KV.S_NFAST, 0)
+            if par == 0:
+                p.emit("s_cbranch_scc0", L("loop"))
+            else:
+                p.emit("s_cbranch_scc1", L("fast0"))
+                p.emit("s_branch", L("loop"))
+        p.label("epilogue" + sfx)
+
+    # ------------------------------------------------------------------ whole block
+    def build(self):
+        p = self.p
+        p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        for ks in range(8):
+            p.emit("v_xor_b32", KV.KR[ks], ks << 5, KV.A_KR0)
+        for dt in range(4):
+            p.emit("v_xor_b32", KV.VR[dt], dt << 6, KV.A_VR0)
+        p.emit("s_nop", 0)
+        for dt in range(4):
+            p.emit("v_xor_b32", KV.VRB[dt], 32, KV.VR[dt])
+        # own rows (K or V) -> B fragments in AGPRs
+        for kvb in range(2):
+            for ks in range(8):
+                p.emit("global_load_dwordx4", KV.FF(kvb, ks), KV.A_FO0 if kvb == 0 else KV.A_FO1, KV.A_FB, offset=32 * ks)
+        # DMA source offsets of piece 1: rows 4 further down flip bit 0 of the unified granule swizzle
+        p.emit("v_mov_b32", KV.QD[0], KV.A_QD0)
+        p.emit("v_mov_b32", KV.GD[0], KV.A_GD0)
+        p.emit("v_xor_b32", KV.QD[1], 16, KV.A_QD0)
+        p.emit("v_xor_b32", KV.GD[1], 16, KV.A_GD0)
+        p.emit("v_mov_b32", KV.XA, KV.A_PXA)
+        p.emit("v_add_u32", KV.QD[1], KV.A_QROW4, KV.QD[1])
+        p.emit("v_add_u32", KV.GD[1], KV.A_GROW4, KV.GD[1])
+        p.emit("s_mov_b32", KV.S_T, -2)
+        p.emit("s_mov_b32", KV.S_QOFF, KV.A_QOFF0)
+        # Q(0) -> Q ring slot 0
+        p.emit("s_add_u32", M0, KV.A_LDSW, KV.Q_RING)
+        p.emit("s_nop", 0)
+        for i in range(2):
+            p.emit("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, offen=True, offset=1024 * i, lds=True)
+        # running state of body -2: it stages Q(1) -> slot 1, dO(0) -> slot 0, loads L / -delta (0); the P side reads Q rows from slot 0
+        # (tile t+2 = 0), the dS side's transposed reads belong to tile t = -2, i.e. slot 2 of the ring
+        p.emit("s_add_u32", KV.S_QOFF, KV.S_QOFF, KV.A_QTILE)
+        p.emit("s_mov_b32", KV.S_GOFF, KV.A_GOFF0)
+        p.emit("s_mov_b32", KV.S_LOFF, KV.A_LOFF0)
+        p.emit("s_mov_b32", KV.S_QSLOT, 0)
+        p.emit("s_add_u32", KV.S_M0Q, KV.A_LDSW, KV.Q_RING + KV.SLOT)
+        for i in range(128):
+            p.emit("v_accvgpr_write_b32", A(i), 0)
+        p.emit("s_cmp_eq_u32", KV.A_ROLE, 1)
+        p.emit("s_cbranch_scc1", Label("role_s"))
+        p.emit("s_waitcnt", vmcnt=0)
+        p.emit("s_barrier")
+        self.role_code(0)
+        p.emit("s_branch", Label("epilogue"))
+        p.label("role_s")
+        for r in KV.VR + KV.VRB:
+            p.emit("v_add_u32", r, 2 * KV.SLOT, r)
+        p.emit("s_waitcnt", vmcnt=0)
+        p.emit("s_barrier")
+        self.role_code(1)
+
+        # ---- epilogue (both roles): acc * factor -> 16 bit -> wave-private LDS image (rows of 272 B) over the dead rings
+        p.label("epilogue")
+        p.emit("s_nop", 15)
+        T = KV.TMP
+        for kvb in range(2):
+            for dt in range(4):
+                acc = KV.ACC(kvb, dt)
+                for r4 in (0, 2):
+                    for j in range(8):
+                        p.emit("v_accvgpr_read_b32", T[j], acc[4 * r4 + j])
+                    p.emit("s_nop", 0)
+                    for j in range(8):
+                        p.emit("v_mul_f32", T[j], KV.A_OSCALE, T[j])
+                    p.emit("s_nop", 0)
+                    p.emit(self.cvt, T[0], T[0], T[1])
+                    p.emit(self.cvt, T[1], T[2], T[3])
+                    p.emit(self.cvt, T[2], T[4], T[5])
+                    p.emit(self.cvt, T[3], T[6], T[7])
+                    p.emit("s_nop", 1)
+                    p.emit("v_permlane32_swap_b32", T[0], T[2])
+                    p.emit("v_permlane32_swap_b32", T[1], T[3])
+                    p.emit("s_nop", 0)
+                    p.emit("ds_write_b128", KV.A_EPI, V(T[0].idx, 4), offset=32 * kvb * KV.EPI_ROWB + (32 * dt + 8 * r4) * 2)
+                    p.emit("s_nop", 1)
+        p.emit("s_waitcnt", lgkmcnt=0)
         return p
 
 
@@ -495,8 +951,14 @@ def main():
         write_atomic(os.path.join(a.out, "fa2_bwd_dq_d128_%s.inc" % dt),
                      "// GENERATED by csrc/gen/bwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog, "fa2dq"))
         print("fa2_bwd_dq_d128_%s.inc" % dt, len(prog.ins), "instructions")
+        prog = GenDKV(bf16, **cfgs["dkv"]).build()
+        write_atomic(os.path.join(a.out, "fa2_bwd_dkv_d128_%s.inc" % dt),
+                     "// GENERATED by csrc/gen/bwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog, "fa2dkv"))
+        print("fa2_bwd_dkv_d128_%s.inc" % dt, len(prog.ins), "instructions")
     write_atomic(os.path.join(a.out, "fa2_bwd_dq_d128_clobbers.inc"),
                  "// GENERATED by csrc/gen/bwd_d128_gen.py — do not edit.\n" + clobber_list(DQ.VBASE, DQ.CLOBBER_S) + "\n")
+    write_atomic(os.path.join(a.out, "fa2_bwd_dkv_d128_clobbers.inc"),
+                 "// GENERATED by csrc/gen/bwd_d128_gen.py — do not edit.\n" + clobber_list(KV.VBASE, KV.CLOBBER_S) + "\n")
 
 
 if __name__ == "__main__":

@@ -138,10 +138,15 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     const int want = fa2::options().bwd_parts.load(std::memory_order_relaxed);      // 3 unless a profiling run asked for one pass only
     int asm_parts = 0;
     if (HD == 128 && p.D == 128 && (m & 2)) asm_parts = 3 & ~((m >> 2) & 3) & fa2::kBwdAsmParts;
+    if (p.Nq % 32 != 0) asm_parts &= ~2;              // the hand-scheduled dK/dV pass sweeps whole 32-row Q tiles
+    // the sign delta crosses the workspace with: the hand-scheduled dK/dV pass takes -delta (C operand of its dP product); a dQ pass
+    // that is not the hand-scheduled one writes +delta, so the two only go together
+    if ((asm_parts & 2) && !(asm_parts & 1)) asm_parts = 0;
+    const bool neg_delta = (asm_parts & 2) != 0;
     for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
         if (!(want & part)) continue;
         int rc;
-        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, stream);
+        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, stream);
         else rc = bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, part, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, part, stream);
         if (rc) return rc;
     }

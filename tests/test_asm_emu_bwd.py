@@ -39,7 +39,35 @@ def test_dq_block_matches_dense_gradients(case):
     assert derr <= 1e-5 * max(1.0, float(abs(ref["delta"]).max())), derr
 
 
-@pytest.mark.parametrize("kind", ["dq"])
+DKV_CASES = [
+    # Nq, Nkv, kv block (128 rows), causal, bf16
+    (256, 128, 0, False, False),
+    (32, 128, 0, False, False),         # one tile
+    (64, 128, 0, False, False),         # two tiles
+    (96, 128, 0, False, True),          # three tiles, bf16 (the dS side unpacks P with shifts instead of v_fma_mix)
+    (32, 77, 0, False, True),           # clamped KV rows
+    (640, 128, 0, False, False),        # fast loop, both parities, Q ring wrap-around
+    (320, 200, 1, False, False),        # second kv block, ragged Nkv
+    (512, 512, 1, True, False),         # causal: sweep starts at the block's diagonal
+    (288, 300, 2, True, True),
+    (256, 256, 0, True, False),
+    (512, 512, 3, True, False),         # last block: short sweep, masked bodies only
+    (640, 256, 1, True, True),
+    (128, 256, 1, True, False),         # causal block whose rows all lie past Nq: one fully masked tile, zeros
+]
+
+
+@pytest.mark.parametrize("case", DKV_CASES)
+def test_dkv_block_matches_dense_gradients(case):
+    nq, nkv, kblk, causal, bf16 = case
+    ek, ev, m, ref = harness.check_dkv(nq, nkv, kblk, causal, bf16=bf16, seed=nq + nkv + kblk, verbose=False)
+    assert not m.errors, m.errors[:5]
+    tol = 8e-3 if bf16 else 1e-3
+    assert ek <= tol * max(1.0, float(abs(ref["dk"]).max())), ek
+    assert ev <= tol * max(1.0, float(abs(ref["dv"]).max())), ev
+
+
+@pytest.mark.parametrize("kind", ["dq", "dkv"])
 def test_generated_backward_text_assembles_for_gfx950(kind, tmp_path):
     """Every line of the rendered bodies goes through the gfx950 assembler (operand classes, constant-bus limits, literals)."""
     import re
@@ -49,7 +77,7 @@ def test_generated_backward_text_assembles_for_gfx950(kind, tmp_path):
     mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
     if not os.path.exists(mc):
         pytest.skip("llvm-mc not available")
-    cls, n_v = (gen.GenDQ, gen.DQ.N_VARGS)
+    cls, n_v = (gen.GenDQ, gen.DQ.N_VARGS) if kind == "dq" else (gen.GenDKV, gen.KV.N_VARGS)
     sregs = iter(range(0, 60))
 
     def operand(n):

@@ -392,6 +392,9 @@ class Machine:
             sy = y - (1 << 32) if y & 0x80000000 else y
             w.scc = int({"s_cmp_eq_u32": x == y, "s_cmp_lg_u32": x != y, "s_cmp_lt_i32": sx < sy, "s_cmp_gt_i32": sx > sy,
                          "s_cmp_ge_i32": sx >= sy, "s_cmp_le_i32": sx <= sy, "s_cmp_lt_u32": x < y}[op])
+        elif op == "s_cselect_b32":
+            d = R(0)
+            w.s[d.idx] = np.uint32(self.rds(w, ops[1]) if w.scc else self.rds(w, ops[2]))
         elif op == "s_bitcmp1_b32":
             w.scc = int((self.rds(w, ops[0]) >> (self.rds(w, ops[1]) & 31)) & 1)
         elif op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccnz", "s_cbranch_vccz"):
@@ -402,6 +405,15 @@ class Machine:
                 w.cycle += 16
         elif op == "v_mov_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]))
+        elif op == "v_subrev_u32":
+            self.wr32(w, ops[0], (self.rd32(w, ops[2]).astype(np.int64) - self.rd32(w, ops[1]).astype(np.int64)).astype(np.uint32))
+        elif op == "v_fma_mix_f32":
+            # src0 is an f16 half (op_sel picks it), src1 f32, src2 the constant 0: the only form the generators emit
+            assert ins.mods.get("op_sel_hi") == "[1,0,0]" and isinstance(ops[3], int) and ops[3] == 0
+            half = 16 if ins.mods.get("op_sel") == "[1,0,0]" else 0
+            x = f16_to_f32(((self.rd32(w, ops[1]) >> half) & 0xffff).astype(np.uint16))
+            with np.errstate(invalid="ignore", over="ignore"):
+                self.wr32(w, ops[0], (x.astype(np.float64) * self.rdf(w, ops[2]).astype(np.float64)).astype(np.float32))
         elif op == "v_add_u32":
             self.wr32(w, ops[0], (self.rd32(w, ops[1]).astype(np.uint64) + self.rd32(w, ops[2]).astype(np.uint64)).astype(np.uint32))
         elif op == "v_cvt_f32_u32":
@@ -465,9 +477,9 @@ class Machine:
             lo, hi = self.rdf(w, ops[1]), self.rdf(w, ops[2])
             cv = f32_to_bf16_bits if op.endswith("bf16_f32") else f32_to_f16_bits
             self.wr32(w, ops[0], (cv(lo) | (cv(hi) << 16)).astype(np.uint32))
-        elif op in ("v_cmp_gt_i32", "v_cmp_le_i32"):
+        elif op in ("v_cmp_gt_i32", "v_cmp_le_i32", "v_cmp_ge_i32"):
             x, y = self.rd32(w, ops[1]).view(np.int32), self.rd32(w, ops[2]).view(np.int32)
-            w.vcc = (x > y) if op == "v_cmp_gt_i32" else (x <= y)
+            w.vcc = {"v_cmp_gt_i32": x > y, "v_cmp_le_i32": x <= y, "v_cmp_ge_i32": x >= y}[op]
         elif op == "v_cmp_lt_f32":
             x, y = self.rdf(w, ops[1]), self.rdf(w, ops[2])
             with np.errstate(invalid="ignore"):
@@ -569,6 +581,28 @@ class Machine:
             for sh in (0, 16):
                 acc = acc + conv(((x >> sh) & 0xffff).astype(np.uint16)).astype(np.float64) * conv(((y >> sh) & 0xffff).astype(np.uint16)).astype(np.float64)
             self.wr32(w, ops[0], acc.astype(np.float32), writer="dot")
+        elif op == "buffer_load_dwordx4" and not ins.mods.get("lds"):
+            # plain buffer load into VGPRs: dst, voffset, descriptor, soffset (out-of-range reads return 0)
+            assert ins.mods.get("offen")
+            dst = R(0)
+            voff = self.rd32(w, ops[1]).astype(np.int64)
+            rs = R(2)
+            base = int(rs[0]) | ((int(rs[1]) & 0xffff) << 32)
+            nrec = int(rs[2])
+            off = voff + self.rds(w, ops[3]) + ins.mods.get("offset", 0)
+            data = np.zeros((NLANE, 4), dtype=np.uint32)
+            for l in range(NLANE):
+                o = int(off[l]) & 0xffffffff
+                if o + 16 <= nrec:
+                    data[l] = self.gread(base + o, 16).view(np.uint32)
+            self.mark_inflight(w, dst, 4, +1)
+
+            def land(dst=dst, data=data):
+                self.mark_inflight(w, dst, 4, -1)
+                rf = self.regfile(w, dst.kind)
+                for i in range(4):
+                    rf[dst.idx + i] = data[:, i]
+            w.vm.append(land)
         elif op == "buffer_load_dwordx4":
             assert ins.mods.get("lds") and ins.mods.get("offen")
             if self.check and w.issue_idx - w.last_m0_write < 2:

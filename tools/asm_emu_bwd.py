@@ -108,6 +108,7 @@ def dq_wave_args(w, qblk, Nq, Nkv, causal, scale, bases):
     args[28] = args[29] = 32 * rb
     args[30] = args[31] = 4 * rb - 1024
     args[32] = w * 2048
+    args[33] = int(np.float32(1.0).view(np.uint32))
     args["vregs"] = v
     return args
 
@@ -155,3 +156,89 @@ def check_dq(Nq, Nkv, qblk, causal, bf16=False, seed=0, verbose=True):
 
 if __name__ == "__main__":
     check_dq(256, 256, 0, False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+KV = gen.KV
+
+
+def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
+    lane = np.arange(64)
+    l31, hi, pp, g1 = lane & 31, lane >> 5, lane & 15, (lane >> 4) & 1
+    rb = 256
+    pair, role = w >> 1, w & 1
+    kv0 = kblk * 128
+    kvw0 = kv0 + 64 * pair
+    tile0 = kv0 // 32 if causal else 0
+    n = max(1, (Nq + 31) // 32 - tile0)
+    v = np.zeros((KV.VBASE, 64), dtype=np.uint32)
+    for kvb in range(2):
+        kvrow = kvw0 + 32 * kvb + l31
+        kr = np.minimum(kvrow, Nkv - 1).astype(np.int64)
+        v[kvb] = (kr * rb + hi * 16).astype(np.uint32)
+        lim = (kvrow - 32 * tile0 - 4 * hi) if causal else np.full(64, -(1 << 30))
+        v[6 + kvb] = lim.astype(np.int32).view(np.uint32)
+    drow, dslot = 8 * w + (lane >> 4), lane & 15
+    v[2] = v[3] = (drow * rb + ((dslot ^ gen.f_swz(drow)) << 4)).astype(np.uint32)
+    v[4] = (l31 * 256 + ((hi ^ gen.f_swz(l31)) << 4)).astype(np.uint32)
+    i, j = pp >> 2, pp & 3
+    trow = 4 * hi + i
+    v[5] = (trow * 256 + (((2 * g1 + (j >> 1)) ^ gen.f_swz(trow)) << 4) + 8 * (j & 1)).astype(np.uint32)
+    v[8] = (KV.P_SLOTS + pair * 8192 + lane * 16).astype(np.uint32)
+    v[9] = (hi * 16).astype(np.uint32)
+    v[10] = (w * 64 * KV.EPI_ROWB + l31 * KV.EPI_ROWB + hi * 16).astype(np.uint32)
+    args = {k: Reg("v", k) for k in range(KV.N_VARGS)}
+    args[11] = _pair(bases["v"] if role else bases["k"])
+    args[12], args[13] = _srd(bases["q"], Nq), _srd(bases["do"], Nq)
+    lb = bases["ndelta"] if role else bases["lse"]
+    args[14] = np.array([lb & 0xffffffff, lb >> 32, Nq * 4, 0x00020000], dtype=np.uint32)
+    args[15] = int(np.float32(scale * LOG2E).view(np.uint32))
+    args[16] = int(np.float32(scale if role else 1.0).view(np.uint32))
+    args[17] = n
+    args[18] = args[19] = tile0 * 32 * rb
+    args[20] = tile0 * 128
+    args[21] = args[22] = 32 * rb
+    args[23] = args[24] = 4 * rb - 1024
+    args[25] = w * 2048
+    args[26] = role
+    args["vregs"] = v
+    return args
+
+
+def run_dkv(q, k, v, do, kblk, causal, scale=None, bf16=False, check_hazards=True):
+    """One workgroup of the dK/dV pass on KV block kblk (128 rows).  Returns (dk, dv [rows,128] f32, machine, reference dict)."""
+    scale = 128 ** -0.5 if scale is None else scale
+    Nq, Nkv = q.shape[0], k.shape[0]
+    o_ref, lse_ref, delta_ref, dq_ref, dk_ref, dv_ref = dense_bwd(q, k, v, do, causal, scale, bf16)
+    o16 = from_bits(to_bits(o_ref, bf16), bf16).astype(np.float64)
+    do16 = from_bits(to_bits(do, bf16), bf16).astype(np.float64)
+    delta = (do16 * o16).sum(axis=1)
+    b = Bufs(bf16)
+    bases = {"q": b.add16(q), "k": b.add16(k), "v": b.add16(v), "do": b.add16(do), "lse": b.add32(lse_ref), "ndelta": b.add32(-delta)}
+    wa = [dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases) for w in range(4)]
+    m = asm_emu.Machine(program("dkv", bf16), wa, KV.LDS_BYTES, b.list, bf16=bf16, check_hazards=check_hazards)
+    for w, a in zip(m.waves, wa):
+        w.v[:KV.VBASE] = a["vregs"]
+    m.run()
+    rows = min(128, Nkv - kblk * 128)
+    img = m.lds[:4 * 64 * KV.EPI_ROWB].reshape(256, KV.EPI_ROWB)[:, :256].copy().view(np.uint16)
+    t = from_bits(img, bf16).reshape(2, 2, 64, 128)          # [pair, role, row, d]
+    dv = t[:, 0].reshape(128, 128)[:rows]
+    dk = t[:, 1].reshape(128, 128)[:rows]
+    r0 = kblk * 128
+    return dk, dv, m, {"dk": dk_ref[r0:r0 + rows], "dv": dv_ref[r0:r0 + rows]}
+
+
+def check_dkv(Nq, Nkv, kblk, causal, bf16=False, seed=0, verbose=True):
+    rng = np.random.default_rng(seed)
+    q, k, v, do = (rng.standard_normal((n, 128)) for n in (Nq, Nkv, Nkv, Nq))
+    dk, dv, m, ref = run_dkv(q, k, v, do, kblk, causal, bf16=bf16)
+    ek, ev = float(np.abs(dk - ref["dk"]).max()), float(np.abs(dv - ref["dv"]).max())
+    if verbose:
+        cyc = np.diff(np.array([0.0] + m.body_cycles))
+        print("dKV Nq %d Nkv %d kblk %d causal %d bf16 %d: max|dK-ref| %.2e (max %.2f)  max|dV-ref| %.2e (max %.2f)  hazards %d  issued/wave %s  body cycles %s"
+              % (Nq, Nkv, kblk, causal, bf16, ek, np.abs(ref["dk"]).max(), ev, np.abs(ref["dv"]).max(), len(m.errors),
+                 [w.n_issued for w in m.waves[:2]], np.round(cyc[:10]).astype(int)))
+        for e in m.errors[:12]:
+            print("   !", e)
+    return ek, ev, m, ref

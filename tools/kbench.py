@@ -59,6 +59,7 @@ def build(specs):
         name, _, flags = s.partition(":")
         fl = [f for f in flags.split(",") if f]
         extra = [f for f in fl if not f.startswith(("gen=", "bgen="))]
+        only = None if extra else ["fwd_asm", "bwd_asm"]          # generator-only variants: recompile just the units that include the bodies
         opts = {}
         for f in fl:
             if f.startswith("gen="):
@@ -70,7 +71,7 @@ def build(specs):
         b.generate(gdir, opts, probe=True)
         out = os.path.join(VAR_DIR, name + ".so")
         try:
-            log = b.compile_library(out, extra_flags=extra, inc_dir=gdir, verbose=True)
+            log = b.compile_library(out, extra_flags=extra, inc_dir=gdir, verbose=True, only=only)
         except RuntimeError as e:
             ok = False
             print("== %s: BUILD FAILED\n%s" % (name, str(e)[-3000:]))

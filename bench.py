@@ -316,9 +316,16 @@ def main():
         torch.cuda.synchronize()
         bwd_ms = b0.elapsed_time(b1) / n_b
         assert all(torch.isfinite(t.grad.float()).all() for t in (qg, kg, vg)), "non-finite gradient"
-        bwd = {"bwd_ms": round(bwd_ms, 4),
-               "bwd_tflops": round(2.5 * attention_flops(B_local, H, N, N, D, causal) / (bwd_ms * 1e-3) / 1e12, 1),
-               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41)"}
+        fwd_flops = attention_flops(B_local, H, N, N, D, causal)
+        useful = 2.5 * fwd_flops / (bwd_ms * 1e-3) / 1e12           # the reference's convention: backward = 2.5 x forward = 5 GEMMs
+        executed = 3.5 * fwd_flops / (bwd_ms * 1e-3) / 1e12         # what the two passes execute: 3 (dQ pass) + 4 (dK/dV pass) = 7 GEMMs
+        bwd = {"bwd_ms": round(bwd_ms, 4), "bwd_tflops": round(useful, 1),
+               "roofline": {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "useful": round(useful, 1), "frac_useful": round(useful / MFMA_PEAK_TFLOPS, 4),
+                            "executed": round(executed, 1), "frac_executed": round(executed / MFMA_PEAK_TFLOPS, 4),
+                            "gemms_executed": 7, "gemms_counted": 5},
+               "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); two deterministic passes (dQ: S, dP, dQ; dK/dV: S, dP, dV, dK) "
+                       "recompute S and dP, so 7 GEMM-equivalents execute; time = wall of 30 autograd backward calls / 30 (HIP events)"}
 
     elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms])
 

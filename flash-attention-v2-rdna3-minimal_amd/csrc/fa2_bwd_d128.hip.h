@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
 // ---------------------------------------------------------------------------------------------------------
 // dK / dV pass: workgroup = 128 KV rows = two wave pairs (P side + dS side, csrc/gen/bwd_d128_gen.py class KV), sweep over Q tiles of 32.
 // Requires D == 128 and Nq % 32 == 0 (host dispatch); any Nkv; causal or not.  Reads -delta from the workspace.
-constexpr int kBwdKvLdsBytes = 4 * 64 * kBwdEpiRowB;         // KV.LDS_BYTES = 69632 (rings 48 KiB + P slots 16 KiB; the epilogue image reuses them)
-constexpr int kBwdKvPSlots = 49152;
+constexpr int kBwdKvLdsBytes = 65536 + 16384;                // KV.LDS_BYTES: Q ring 32 KiB | dO ring 16 KiB | L, -delta 1 KiB (below 64 KiB: LDS-DMA targets) | P slots 16 KiB
+constexpr int kBwdKvLdBase = 49152, kBwdKvPSlots = 65536;
 
 template <bool BF16, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p) {
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
     const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
     const uint32_t vr0 = trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
-    const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = 16u * hi;
+    const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = 16u * hi + 512u * role, l4 = 4u * lane;
+    const uint32_t ldm0 = pair == 0 ? kBwdKvLdBase + 512u * role : 0u;        // pair 0's waves stage L (P side) / -delta (dS side) for the workgroup
     const uint32_t epi = wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
 
     const uint64_t fbase = role ? (uint64_t)((const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1]) : (uint64_t)((const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1]);
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
 
 #define FA2_BWD_KV_OPERANDS                                                                                                       \
     :                                                                                                                             \
-    : "v"(fo[0]), "v"(fo[1]), "v"(qd0), "v"(gd0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(pxa), "v"(lda), "v"(epi),      \
+    : "v"(fo[0]), "v"(fo[1]), "v"(qd0), "v"(gd0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(pxa), "v"(lda), "v"(l4), "v"(epi), \
       "s"(fbase), "s"(qrs), "s"(grs), "s"(lrs), "s"(c), "s"(oscale), "s"(n), "s"(qoff0), "s"(goff0), "s"(loff0), "s"(q_tile),     \
-      "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role)                                                                 \
+      "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role), "s"(ldm0)                                                      \
     :
     if constexpr (BF16) {
         asm volatile(

@@ -150,7 +150,7 @@ class DQ:
 
 
 class GenDQ(BodyEmitter):
-    DEFAULTS = {"valu": (1.0, 47.0), "rowread": (0.0, 15.0), "trread": (17.0, 47.0), "dma": (4.0, 40.0), "opt": (), "abl": ()}
+    DEFAULTS = {"valu": (1.0, 47.0), "rowread": (0.0, 15.0), "trread": (17.0, 47.0), "dma": (1.0, 14.0), "opt": (), "abl": ()}
 
     def __init__(self, bf16=False, **cfg):
         self.cfg = dict(self.DEFAULTS)
@@ -284,9 +284,11 @@ class GenDQ(BodyEmitter):
         boundary = {}
         if s2:
             boundary[16] = [mk("s_nop", 1)]      # (the LDS-wait pass puts the counted wait for the first row fragments here)
-        post = [mk("s_add_u32", DQ.S_T, DQ.S_T, 1), mk("s_add_u32", DQ.S_KOFF, DQ.S_KOFF, DQ.A_KTILE),
-                mk("s_add_u32", DQ.S_VOFF, DQ.S_VOFF, DQ.A_VTILE), mk("s_add_u32", DQ.S_TOFF, DQ.S_TOFF, DQ.A_KTILE),
-                mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
+        # the running tile offsets move on behind the DMA pieces that use them (not after the body: that would idle the matrix pipe)
+        bk = [mk("s_add_u32", DQ.S_T, DQ.S_T, 1, tag="salu"), mk("s_add_u32", DQ.S_KOFF, DQ.S_KOFF, DQ.A_KTILE, tag="salu"),
+              mk("s_add_u32", DQ.S_VOFF, DQ.S_VOFF, DQ.A_VTILE, tag="salu"), mk("s_add_u32", DQ.S_TOFF, DQ.S_TOFF, DQ.A_KTILE, tag="salu")]
+        sched.place(load, slots, bk, 44.0, 47.0, 9)
+        post = [mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
         if "barrier" not in abl:
             post.append(mk("s_barrier"))
         self.emit_body(p, mf, slots, pre=pre, boundary=boundary, post=post)
@@ -476,30 +478,34 @@ class KV:
     Q is swept in tiles of 32 rows (the launcher requires Nq % 32 == 0: no partial tile, so no row of a tile lies beyond Nq; KV rows
     beyond Nkv are clamped reads whose results are not stored); Q and dO tiles are staged ONCE each, in the unified image format (f_swz) that serves the row
     reads of one wave and the transposed reads of its partner: Q ring 4 slots (a tile lives from body t-3 to body t), dO ring 2.
-    L and -delta of a tile bypass LDS: four buffer_load_dwordx4 per wave return them in the accumulator's register layout.
+    L and -delta of a tile (32 floats each) are staged by ONE 4-byte-per-lane LDS-DMA per array and tile (pair 0's waves issue them) and read
+    back with four ds_read_b128 per wave in the accumulator's register layout — VMEM instructions are the dearest fillers of these bodies
+    (~45 cycles of lost matrix-pipe time each, measured), LDS reads the cheapest (~5).
 
     Pipelines (body B(t), t = -2 .. n, one barrier each, 32 MFMAs per wave):
         P side    MFMA 0..15 dV(t), 16..31 S(t+2);  VALU: P(t+1) -> packed in place -> written to the pair's slot
         dS side   MFMA 0..15 dK(t-1), 16..31 dP(t+1);  VALU: dS(t) = P(t) * dP'(t), packed in place
-      every phase's A fragments are read from LDS one phase earlier; LDS-DMA: Q(t+3), dO(t+2); loads: L(t+2) / -delta(t+2).
+      every phase's A fragments are read from LDS one phase earlier; LDS-DMA: Q(t+3), dO(t+2), L / -delta (t+3); LR(t+2) is read from LDS.
     """
     A_FO0, A_FO1 = Arg(0), Arg(1)                  # byte offset of this lane's 16 bytes (k-step 0) of its own K (P side) / V (dS side) row, block 0 / 1
     A_QD0, A_GD0 = Arg(2), Arg(3)                  # per-lane LDS-DMA source byte offset (piece 0, tile 0) in Q / dO
     A_KR0, A_VR0 = Arg(4), Arg(5)                  # per-lane LDS read offset: row fragment k-step 0 / transposed fragment d block 0 (rows +0..3)
     A_LIM0, A_LIM1 = Arg(6), Arg(7)                # P side, causal: this lane's kv row (minus 4*hi, minus the first tile's q0) per block; -big otherwise
     A_PXA = Arg(8)                                 # per-lane LDS byte address in the pair's P slot (parity 0)
-    A_LDA = Arg(9)                                 # per-lane byte offset into a tile's 32 L / delta values: 16 * hi
-    A_EPI = Arg(10)                                # per-lane LDS byte address of the epilogue image: row l31, half hi
-    A_FB = Arg(11, "s", 2)                         # head base of K (P side) / V (dS side)
-    A_QRS, A_GRS, A_LRS = Arg(12, "s", 4), Arg(13, "s", 4), Arg(14, "s", 4)   # buffer descriptors: Q, dO, LSE (P side) / delta workspace (dS side)
-    A_C, A_OSCALE = Arg(15, "s"), Arg(16, "s")     # scale * log2(e); factor of the stored accumulator (1.0: dV, scale: dK)
-    A_N = Arg(17, "s")                             # number of 32-row Q tiles this workgroup sweeps
-    A_QOFF0, A_GOFF0, A_LOFF0 = Arg(18, "s"), Arg(19, "s"), Arg(20, "s")     # byte offset of the first swept tile in Q / dO / the L array
-    A_QTILE, A_GTILE = Arg(21, "s"), Arg(22, "s")  # bytes between consecutive tiles in Q / dO
-    A_QROW4, A_GROW4 = Arg(23, "s"), Arg(24, "s")  # 4 * row bytes - 1024
-    A_LDSW = Arg(25, "s")                          # wave * 2048: this wave's quarter of a tile image
-    A_ROLE = Arg(26, "s")                          # 0: P side, 1: dS side
-    N_ARGS, N_VARGS = 27, 11
+    A_LDA = Arg(9)                                 # per-lane LDS byte offset into a tile's 32 L / -delta values: 16 * hi (+ the role's array)
+    A_L4 = Arg(10)                                 # lane * 4: source offset of the 4-byte LDS-DMA that stages L / -delta
+    A_EPI = Arg(11)                                # per-lane LDS byte address of the epilogue image: row l31, half hi
+    A_FB = Arg(12, "s", 2)                         # head base of K (P side) / V (dS side)
+    A_QRS, A_GRS, A_LRS = Arg(13, "s", 4), Arg(14, "s", 4), Arg(15, "s", 4)   # buffer descriptors: Q, dO, LSE (P side) / delta workspace (dS side)
+    A_C, A_OSCALE = Arg(16, "s"), Arg(17, "s")     # scale * log2(e); factor of the stored accumulator (1.0: dV, scale: dK)
+    A_N = Arg(18, "s")                             # number of 32-row Q tiles this workgroup sweeps
+    A_QOFF0, A_GOFF0, A_LOFF0 = Arg(19, "s"), Arg(20, "s"), Arg(21, "s")     # byte offset of the first swept tile in Q / dO / the L array
+    A_QTILE, A_GTILE = Arg(22, "s"), Arg(23, "s")  # bytes between consecutive tiles in Q / dO
+    A_QROW4, A_GROW4 = Arg(24, "s"), Arg(25, "s")  # 4 * row bytes - 1024
+    A_LDSW = Arg(26, "s")                          # wave * 2048: this wave's quarter of a tile image
+    A_ROLE = Arg(27, "s")                          # 0: P side, 1: dS side
+    A_LDM0 = Arg(28, "s")                          # pair 0 only (its waves stage L / -delta for the workgroup): LDS address of the role's array, parity 0; 0 = this wave does not
+    N_ARGS, N_VARGS = 29, 12
     VBASE = 16
 
     @staticmethod
@@ -540,13 +546,14 @@ class KV:
     S_NFAST, S_D, S_QSLOT, S_BUMP, S_M0Q = S(66), S(67), S(68), S(69), S(70)
     CLOBBER_S = list(range(60, 72))
 
-    Q_RING, G_RING, P_SLOTS, SLOT = 0, 32768, 49152, 8192
+    # (LDS-DMA destinations must lie below 64 KiB: M0 carries a 16-bit LDS address; the P slots are written by ds_write and sit above)
+    Q_RING, G_RING, LD_BASE, P_SLOTS, SLOT = 0, 32768, 49152, 65536, 8192      # LD_BASE: L[2 parities][64 floats] at +0, -delta likewise at +512
     EPI_ROWB = 272
-    LDS_BYTES = 4 * 64 * 272                       # 69632: the epilogue image (over the rings, which are dead by then) is the largest user
+    LDS_BYTES = 65536 + 16384                      # 81920 (the epilogue image, 4 x 64 rows of 272 B from 0, reuses the rings, which are dead by then)
 
 
 class GenDKV(BodyEmitter):
-    DEFAULTS = {"valu_p": (1.0, 31.0), "valu_s": (1.0, 31.0), "rowread": (0.0, 15.0), "trread": (16.0, 31.0), "dma": (1.0, 12.0), "opt": (), "abl": ()}
+    DEFAULTS = {"valu_p": (1.0, 31.0), "valu_s": (1.0, 31.0), "rowread": (0.0, 15.0), "trread": (16.0, 31.0), "dma": (1.0, 12.0), "lread": (20.0, 31.0), "opt": (), "abl": ()}
 
     def __init__(self, bf16=False, **cfg):
         self.cfg = dict(self.DEFAULTS)
@@ -641,17 +648,24 @@ class GenDKV(BodyEmitter):
         return out
 
     def stream_dma(self, par):
-        """Q(t+3) -> Q ring slot (t+3) % 4 (M0 from the running slot counter), dO(t+2) -> dO ring slot t % 2 = par; then the four
-        loads of L / -delta of tile t+2 into LR(par) (not LDS: they return in the accumulator's register layout)."""
+        """Q(t+3) -> Q ring slot (t+3) % 4 (M0 from the running slot counter), dO(t+2) -> dO ring slot t % 2 = par; pair 0's waves also
+        stage the 32 L / -delta values of tile t+3 (one 4-byte-per-lane piece; lanes 32..63 bring the next tile's, which nobody reads)."""
         out = [[mk("s_mov_b32", M0, KV.S_M0Q, tag="salu"), mk("s_nop", 0, tag="salu")]]
         for i in range(2):
             out.append(mk("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, tag="dma", offen=True, offset=1024 * i, lds=True))
         out.append([mk("s_add_u32", M0, KV.A_LDSW, KV.G_RING + par * KV.SLOT, tag="salu"), mk("s_nop", 0, tag="salu")])
         for i in range(2):
             out.append(mk("buffer_load_dwordx4", KV.GD[i], KV.A_GRS, KV.S_GOFF, tag="dma", offen=True, offset=1024 * i, lds=True))
-        for g in range(4):
-            out.append(mk("buffer_load_dwordx4", KV.LR(par).sub(4 * g, 4), KV.A_LDA, KV.A_LRS, KV.S_LOFF, tag="dma", offen=True, offset=32 * g))
+        skip = self.p.fresh("ld_skip")
+        out.append([mk("s_cmp_eq_u32", KV.A_LDM0, 0, tag="salu"), mk("s_cbranch_scc1", Label(skip), tag="branch"),
+                    mk("s_add_u32", M0, KV.A_LDM0, (par ^ 1) * 256, tag="salu"), mk("s_nop", 0, tag="salu"),
+                    mk("buffer_load_dword", KV.A_L4, KV.A_LRS, KV.S_LOFF, tag="dma", offen=True, lds=True),
+                    Ins("label", (Label(skip),))])
         return out
+
+    def stream_lread(self, par):
+        """L (P side) / -delta (dS side) of tile t+2 -> LR(par), from the parity-par slot of the role's array (A_LDA carries the array)"""
+        return [mk("ds_read_b128", KV.LR(par).sub(4 * g, 4), KV.A_LDA, tag="lds", offset=KV.LD_BASE + par * 256 + 32 * g) for g in range(4)]
 
     # ------------------------------------------------------------------ one body
     def body(self, role, par, acc=True, valu=True, row=True, masked=False, tr=True, rr=True, name="body"):
@@ -680,6 +694,7 @@ class GenDKV(BodyEmitter):
                 pre.append(mk("v_subrev_u32", KV.LIMT[kvb], KV.S_TMP, KV.A_LIM0 if kvb == 0 else KV.A_LIM1))
         if "dma" not in abl:
             sched.place(load, slots, self.stream_dma(par), cfg["dma"][0], cfg["dma"][1], 2)
+            sched.place(load, slots, self.stream_lread(par), cfg["lread"][0], cfg["lread"][1], 8)
         if P:
             # Q rows of tile t+2 (Q ring, running address) for phase B; dO^T of tile t+1 (dO ring slot par^1) for the next body's phase A
             if rr and "rowread" not in abl:
@@ -700,22 +715,26 @@ class GenDKV(BodyEmitter):
             if rr and "rowread" not in abl:
                 sched.place(load, slots, self.stream_rowread(KV.G_RING + (par ^ 1) * KV.SLOT), cfg["rowread"][0], cfg["rowread"][1], 3)
             if tr and "trread" not in abl:
-                sched.place(load, slots, self.stream_trread(KV.Q_RING), cfg["trread"][0], cfg["trread"][1], 4)
-        self.last_load = load
-        # end of body: the running tile offsets and the Q ring position move one tile on; everybody meets
-        post = [mk("s_add_u32", KV.S_T, KV.S_T, 1), mk("s_add_u32", KV.S_QOFF, KV.S_QOFF, KV.A_QTILE),
-                mk("s_add_u32", KV.S_GOFF, KV.S_GOFF, KV.A_GTILE), mk("s_add_u32", KV.S_LOFF, KV.S_LOFF, 128),
-                mk("s_add_u32", KV.S_QSLOT, KV.S_QSLOT, 1), mk("s_and_b32", KV.S_QSLOT, KV.S_QSLOT, 3),
-                # this wave's own ring position wraps when the counter reaches 0 (P side: row reads of tile t+2) / 2 (dS side: tile t)
-                mk("s_cmp_eq_u32", KV.S_QSLOT, 0 if P else 2), mk("s_cselect_b32", KV.S_BUMP, 4 * KV.SLOT, 0),
-                mk("s_sub_u32", KV.S_BUMP, KV.SLOT, KV.S_BUMP),
-                # the DMA slot runs one ahead of the P side's row-read slot
-                mk("s_add_u32", KV.S_TMP, KV.S_QSLOT, 1), mk("s_and_b32", KV.S_TMP, KV.S_TMP, 3), mk("s_lshl_b32", KV.S_TMP, KV.S_TMP, 13),
-                mk("s_add_u32", KV.S_M0Q, KV.S_TMP, KV.A_LDSW),
-                mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
+                sched.place(load, slots, self.stream_trread(KV.Q_RING), cfg["trread"][0], cfg["trread"][1] - 3.0, 4)
+        # book-keeping for the next body — the running tile offsets, the Q ring position of this wave's moving read addresses and of
+        # the DMA — rides in the gaps behind the last use of each value in this body (after the body it would idle the matrix pipe)
+        bk1 = [mk("s_add_u32", KV.S_T, KV.S_T, 1, tag="salu"), mk("s_add_u32", KV.S_QOFF, KV.S_QOFF, KV.A_QTILE, tag="salu"),
+               mk("s_add_u32", KV.S_GOFF, KV.S_GOFF, KV.A_GTILE, tag="salu"), mk("s_add_u32", KV.S_LOFF, KV.S_LOFF, 128, tag="salu"),
+               mk("s_add_u32", KV.S_QSLOT, KV.S_QSLOT, 1, tag="salu"), mk("s_and_b32", KV.S_QSLOT, KV.S_QSLOT, 3, tag="salu"),
+               # this wave's own ring position wraps when the counter reaches 0 (P side: row reads of tile t+2) / 2 (dS side: tile t)
+               [mk("s_cmp_eq_u32", KV.S_QSLOT, 0 if P else 2, tag="salu"), mk("s_cselect_b32", KV.S_BUMP, 4 * KV.SLOT, 0, tag="salu")],
+               mk("s_sub_u32", KV.S_BUMP, KV.SLOT, KV.S_BUMP, tag="salu"),
+               # the DMA slot runs one ahead of the P side's row-read slot
+               mk("s_add_u32", KV.S_TMP2, KV.S_QSLOT, 1, tag="salu"), mk("s_and_b32", KV.S_TMP2, KV.S_TMP2, 3, tag="salu"),
+               mk("s_lshl_b32", KV.S_TMP2, KV.S_TMP2, 13, tag="salu"), mk("s_add_u32", KV.S_M0Q, KV.S_TMP2, KV.A_LDSW, tag="salu")]
         moving = KV.KR if P else KV.VR + KV.VRB
-        for r in moving:
-            post.append(mk("v_add_u32", r, KV.S_BUMP, r))
+        bk2 = [mk("v_add_u32", r, KV.S_BUMP, r, tag="valu") for r in moving]
+        if "bk" in abl:
+            bk1, bk2 = [], []
+        sched.place(load, slots, bk1, 20.0, 27.0, 9)
+        sched.place(load, slots, bk2, 28.0, 31.0, 9)
+        self.last_load = load
+        post = [mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
         if "barrier" not in abl:
             post.append(mk("s_barrier"))
         self.emit_body(p, mf, slots, pre=pre, post=post)
@@ -847,11 +866,18 @@ class GenDKV(BodyEmitter):
         p.emit("s_nop", 0)
         for i in range(2):
             p.emit("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, offen=True, offset=1024 * i, lds=True)
-        # running state of body -2: it stages Q(1) -> slot 1, dO(0) -> slot 0, loads L / -delta (0); the P side reads Q rows from slot 0
+        p.emit("s_mov_b32", KV.S_LOFF, KV.A_LOFF0)
+        p.emit("s_cmp_eq_u32", KV.A_LDM0, 0)
+        p.emit("s_cbranch_scc1", Label("no_ld0"))
+        p.emit("s_mov_b32", M0, KV.A_LDM0)
+        p.emit("s_nop", 0)
+        p.emit("buffer_load_dword", KV.A_L4, KV.A_LRS, KV.S_LOFF, offen=True, lds=True)
+        p.label("no_ld0")
+        # running state of body -2: it stages Q(1) -> slot 1, dO(0) -> slot 0, L / -delta (1); the P side reads Q rows from slot 0
         # (tile t+2 = 0), the dS side's transposed reads belong to tile t = -2, i.e. slot 2 of the ring
         p.emit("s_add_u32", KV.S_QOFF, KV.S_QOFF, KV.A_QTILE)
         p.emit("s_mov_b32", KV.S_GOFF, KV.A_GOFF0)
-        p.emit("s_mov_b32", KV.S_LOFF, KV.A_LOFF0)
+        p.emit("s_add_u32", KV.S_LOFF, KV.S_LOFF, 128)
         p.emit("s_mov_b32", KV.S_QSLOT, 0)
         p.emit("s_add_u32", KV.S_M0Q, KV.A_LDSW, KV.Q_RING + KV.SLOT)
         for i in range(128):

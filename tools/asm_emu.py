@@ -581,6 +581,25 @@ class Machine:
             for sh in (0, 16):
                 acc = acc + conv(((x >> sh) & 0xffff).astype(np.uint16)).astype(np.float64) * conv(((y >> sh) & 0xffff).astype(np.uint16)).astype(np.float64)
             self.wr32(w, ops[0], acc.astype(np.float32), writer="dot")
+        elif op == "buffer_load_dword":
+            assert ins.mods.get("lds") and ins.mods.get("offen")
+            if self.check and w.issue_idx - w.last_m0_write < 2:
+                self.err(w, "LDS-DMA issued right after an M0 write (needs 1 wait state)")
+            voff = self.rd32(w, ops[0]).astype(np.int64)
+            rs = R(1)
+            base = int(rs[0]) | ((int(rs[1]) & 0xffff) << 32)
+            nrec = int(rs[2])
+            off = voff + self.rds(w, ops[2]) + ins.mods.get("offset", 0)
+            data = np.zeros((NLANE, 4), dtype=np.uint8)
+            for l in range(NLANE):
+                o = int(off[l]) & 0xffffffff
+                if o + 4 <= nrec:
+                    data[l] = self.gread(base + o, 4)
+            dst_addr = (w.m0 & 0xffff) + LANES * 4 + ins.mods.get("offset", 0)
+
+            def land(dst_addr=dst_addr, data=data):
+                self.lds_write(w, dst_addr, data)
+            w.vm.append(land)
         elif op == "buffer_load_dwordx4" and not ins.mods.get("lds"):
             # plain buffer load into VGPRs: dst, voffset, descriptor, soffset (out-of-range reads return 0)
             assert ins.mods.get("offen")

@@ -185,22 +185,24 @@ def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
     trow = 4 * hi + i
     v[5] = (trow * 256 + (((2 * g1 + (j >> 1)) ^ gen.f_swz(trow)) << 4) + 8 * (j & 1)).astype(np.uint32)
     v[8] = (KV.P_SLOTS + pair * 8192 + lane * 16).astype(np.uint32)
-    v[9] = (hi * 16).astype(np.uint32)
-    v[10] = (w * 64 * KV.EPI_ROWB + l31 * KV.EPI_ROWB + hi * 16).astype(np.uint32)
+    v[9] = (hi * 16 + role * 512).astype(np.uint32)
+    v[10] = (lane * 4).astype(np.uint32)
+    v[11] = (w * 64 * KV.EPI_ROWB + l31 * KV.EPI_ROWB + hi * 16).astype(np.uint32)
     args = {k: Reg("v", k) for k in range(KV.N_VARGS)}
-    args[11] = _pair(bases["v"] if role else bases["k"])
-    args[12], args[13] = _srd(bases["q"], Nq), _srd(bases["do"], Nq)
+    args[12] = _pair(bases["v"] if role else bases["k"])
+    args[13], args[14] = _srd(bases["q"], Nq), _srd(bases["do"], Nq)
     lb = bases["ndelta"] if role else bases["lse"]
-    args[14] = np.array([lb & 0xffffffff, lb >> 32, Nq * 4, 0x00020000], dtype=np.uint32)
-    args[15] = int(np.float32(scale * LOG2E).view(np.uint32))
-    args[16] = int(np.float32(scale if role else 1.0).view(np.uint32))
-    args[17] = n
-    args[18] = args[19] = tile0 * 32 * rb
-    args[20] = tile0 * 128
-    args[21] = args[22] = 32 * rb
-    args[23] = args[24] = 4 * rb - 1024
-    args[25] = w * 2048
-    args[26] = role
+    args[15] = np.array([lb & 0xffffffff, lb >> 32, Nq * 4, 0x00020000], dtype=np.uint32)
+    args[16] = int(np.float32(scale * LOG2E).view(np.uint32))
+    args[17] = int(np.float32(scale if role else 1.0).view(np.uint32))
+    args[18] = n
+    args[19] = args[20] = tile0 * 32 * rb
+    args[21] = tile0 * 128
+    args[22] = args[23] = 32 * rb
+    args[24] = args[25] = 4 * rb - 1024
+    args[26] = w * 2048
+    args[27] = role
+    args[28] = (KV.LD_BASE + role * 512) if pair == 0 else 0
     args["vregs"] = v
     return args
 

@@ -11,12 +11,23 @@ namespace {
 // strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
 // (fa2_fwd_d128.hip.h).  Option "persist" = 0 launches one workgroup per item instead (A/B measurements, bit-identity tests).
 template <bool BF16, bool CAUSAL>
-int launch_d128_t(const fa2::FwdParams& p, hipStream_t stream) {
+int launch_d128_t(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL>;
     if (int rc = fa2::set_lds<kern>(fa2::kD128LdsBytes)) return rc;
-    int64_t grid = (int64_t)p.nbh * p.nqblk;
-    const int pg = fa2::options().persist.load(std::memory_order_relaxed) ? fa2::device_cus() & ~7 : 0;   // a multiple of 8: an item stays on its head's XCD
-    if (!CAUSAL && pg > 0 && grid > pg) grid = pg;
+    fa2::FwdParams p = p0;
+    p.persist = fa2::options().persist.load(std::memory_order_relaxed) ? 1 : 0;
+    const int pg = fa2::device_cus() & ~7;       // a multiple of 8: a unit stays on its head's XCD
+    if (CAUSAL && p.persist) {
+        // Causal pair units against one item per workgroup in longest-first order, same box (tools/fwd_ab.py, MI355X): B8 H16 N4096 +5.2 %,
+        // B1 H8 N16384 +1.4 %, B1 H32 N8192 +0.7 %, but B2 H16 N4096 -2.2 % and B4 H16 N2048 -2.0 %: with a single short unit per workgroup
+        // the hardware's dynamic dispatch of single items is the better balancer.  Pairs when a workgroup gets several units or a head has >= 32 blocks.
+        const int64_t units = (int64_t)p.nbh * ((p.nqblk + 1) / 2);
+        if (!(units > pg || p.nqblk >= 32)) p.persist = 0;
+    }
+    // work units: non-causal one per (head, q block); causal one per PAIR of q blocks of a head (fa2_fwd_d128.hip.h)
+    const int64_t per_head = (CAUSAL && p.persist) ? (p.nqblk + 1) / 2 : p.nqblk;
+    int64_t grid = (int64_t)p.nbh * per_head;
+    if (p.persist && pg > 0 && grid > pg) grid = pg;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), fa2::kD128LdsBytes, stream, p);
     return (int)hipGetLastError();
 }

@@ -70,7 +70,7 @@ A_LDSW = Arg(20, "s")                              # wave * 4096: this wave's qu
 A_EPI = Arg(21)                                    # per-lane LDS byte address of the epilogue image: row l31, half hi
 # persistent workgroups: the asm statement runs once per (head, q block) item of the workgroup's list; the last two bodies of
 # an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
-A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists
+A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles
 A_NQO0, A_NQO1 = Arg(23), Arg(24)                  # the next item's Q offsets / head base / K and V descriptors
 A_NQB = Arg(25, "s", 2)
 A_NKRS, A_NVRS = Arg(26, "s", 4), Arg(27, "s", 4)
@@ -395,8 +395,8 @@ class Gen:
                 r.append(mk("buffer_load_dwordx4", vd[i], nrs, 0, offen=True, offset=1024 * i, lds=True))
             if which == "k":
                 one = self.p.fresh("dma_next_one")
-                r.append(mk("s_cmp_lt_i32", A_NTWG, 2))          # (items of one launch have the same number of tiles)
-                r.append(mk("s_cbranch_scc1", Label(one)))
+                r.append(mk("s_bitcmp1_b32", A_FLAGS, 2))        # the next item has a second tile (causal items differ in length)
+                r.append(mk("s_cbranch_scc0", Label(one)))
                 r.append(mk("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B))
                 r.append(mk("s_nop", 0))
                 for i in range(4):

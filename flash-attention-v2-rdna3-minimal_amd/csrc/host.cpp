@@ -267,6 +267,7 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     p.bh0 = 0;
     p.nbh = B * H;
     p.rows_hint = 0;
+    p.persist = 1;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
     p.bias = bias;

@@ -79,6 +79,33 @@ def test_persistent_workgroup_seams(seam, variant):
         assert np.abs(lse - lse_ref).max() <= 1e-4
 
 
+CAUSAL_SEAMS = [
+    # Nq = Nkv, [q block per item]: the pairs a causal launch hands to one workgroup — a long block, then its short partner
+    (1024, [3, 0], False),            # 16 tiles, then 4: the ring parities and the per-wave tile counts differ across the seam
+    (768, [2, 0, 1], True),           # odd block count: (2, 0) is a unit, the middle block comes alone in the next unit
+    (512, [1, 0, 1, 0], False),       # two units in a row
+]
+
+
+@pytest.mark.parametrize("seam", CAUSAL_SEAMS)
+def test_persistent_workgroup_causal_pairs(seam):
+    """Causal launches hand a workgroup PAIRS of q blocks of one head (fa2_fwd_d128.hip.h): items of different length run back to
+    back through the item seam (the next item's Q / K(0) / K(1) / V(0) are fetched while waves of the current item that finished
+    early only stage and sync).  Every item must match dense causal attention, with no hazard."""
+    import numpy as np
+    n, qblks, bf16 = seam
+    rng = np.random.default_rng(n + len(qblks))
+    q, k, v = rng.standard_normal((n, 128)), rng.standard_normal((n, 128)), rng.standard_normal((n, 128))
+    items = [(q, k, v, qb) for qb in qblks]
+    outs, m = harness.run_items(items, True, bf16=bf16)
+    assert not m.errors, m.errors[:5]
+    for (_, _, _, qb), (o, lse) in zip(items, outs):
+        r0 = qb * 256
+        o_ref, lse_ref = harness.dense(q, k, v, True, bf16=bf16)
+        assert np.abs(o - o_ref[r0:r0 + o.shape[0]]).max() <= (1e-2 if bf16 else 1e-3)      # (bf16: randn V, rows with one or two visible keys)
+        assert np.abs(lse - lse_ref[r0:r0 + o.shape[0]]).max() <= 1e-4
+
+
 def test_emulator_flags_a_missing_wait():
     """The checker itself: drop the lgkmcnt wait in front of the QK^T phase and the emulator must object."""
     import fwd_d128_gen as gen

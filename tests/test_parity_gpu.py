@@ -639,16 +639,21 @@ PERSISTENT_SHAPES = [
     (40, 8, 512, 64, False),        # 640 items of ONE KV tile: the staging body is a head body
     (24, 8, 600, 100, True),        # 576 items of two tiles, ragged tail, BNHD strides
     (2, 16, 4096, 4096, False),     # config 2 itself: two items per workgroup
+    (1, 9, 1280, 1280, False),      # five q blocks per head: a causal head's middle block is a unit of its own
 ]
 
 
+@pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
-def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape):
-    """Non-causal D = 128 launches run persistent workgroups (grid = CUs; the last two bodies of an item fetch the next item's
-    Q fragments and first K / V tiles).  The arithmetic of an item does not depend on how it was scheduled, so the outputs must
-    be BIT-IDENTICAL to a launch of one workgroup per item (library option persist = 0), and close to dense fp32."""
+def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape, causal):
+    """D = 128 launches run persistent workgroups (grid = CUs; the last two bodies of an item fetch the next item's Q fragments and
+    first K / V tiles; causal launches hand a workgroup pairs of q blocks (nqblk-1-i, i) of one head).  The arithmetic of an item does
+    not depend on how it was scheduled, so the outputs must be BIT-IDENTICAL to a launch of one workgroup per item (library option
+    persist = 0), and close to dense fp32."""
     from rocwmma_fattn import _fa2_lib
     B, H, Nq, Nkv, bnhd = shape
+    if causal and Nkv < Nq:
+        Nkv = Nq                      # (top-left aligned causal mask: rows past Nkv would see every key; keep the square case)
     g = torch.Generator(device="cpu").manual_seed(77)
     q = torch.randn((B, H, Nq, 128), generator=g).half().to(_dev())
     k = torch.randn((B, H, Nkv, 128), generator=g).half().to(_dev())
@@ -657,7 +662,7 @@ def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape):
     outs = {}
     for mode, persist in (("persist", 1), ("single", 0)):
         with _fa2_lib.options(rows=256, persist=persist):
-            outs[mode] = FlashAttentionFunction.apply(qq, kk, vv, None, False, None, bool(bnhd))
+            outs[mode] = FlashAttentionFunction.apply(qq, kk, vv, None, causal, None, bool(bnhd))
         torch.cuda.synchronize()
     assert torch.equal(outs["persist"], outs["single"])
     got = outs["persist"].float()
@@ -666,6 +671,8 @@ def test_d128_persistent_workgroups_match_one_workgroup_per_item(shape):
     worst = 0.0
     for b in range(0, B, max(1, B // 3)):
         s = torch.matmul(q[b].float(), k[b].float().transpose(-1, -2)) * (128 ** -0.5)
+        if causal:
+            s = s.masked_fill(torch.ones(Nq, Nkv, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
         truth = torch.matmul(torch.softmax(s, -1), v[b].float())
         worst = max(worst, float((got[b] - truth).abs().max()))
     assert worst <= 2e-3, worst

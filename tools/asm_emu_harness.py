@@ -127,9 +127,13 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
         nxt = None
         if it + 1 < len(items):
             nq_, nk_, _, nqblk = items[it + 1]
-            assert (nk_.shape[0] + 63) // 64 == (Nkv + 63) // 64, "items of one launch have the same number of KV tiles"
             nxt = (nqblk, nq_.shape[0], bases[it + 1][0], bases[it + 1][1], bases[it + 1][2], nk_.shape[0])
         flags = (1 if it > 0 else 0) | (2 if nxt is not None else 0)
+        if nxt is not None:
+            n_nk = (nxt[5] + 63) // 64
+            if causal:
+                n_nk = min(n_nk, (min(nxt[0] * 256 + 256, nxt[1]) - 1) // 64 + 1)
+            flags |= 4 if n_nk >= 2 else 0
         wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt)
               for w in range(4)]
         if m is None:

@@ -43,8 +43,8 @@ int set_lds(int bytes) {
 // generic HIP forward (fwd_hip.cpp): rows = 256 (8 waves) or 128 (4 waves) per workgroup; bias: the BIAS kernels (always 128 rows)
 FA2_HIDDEN int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
-// hand-scheduled forward, head dim exactly 128 (fwd_asm.cpp)
-FA2_HIDDEN int launch_fwd_d128(bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
+// hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
+FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);

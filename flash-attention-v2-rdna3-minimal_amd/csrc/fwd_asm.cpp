@@ -10,10 +10,11 @@ namespace {
 // Persistent workgroups of the d128 kernel (non-causal launches): at most one workgroup per CU, each working through a
 // strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
 // (fa2_fwd_d128.hip.h).  Option "persist" = 0 launches one workgroup per item instead (A/B measurements, bit-identity tests).
-template <bool BF16, bool CAUSAL>
-int launch_d128_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_d128_kernel<BF16, CAUSAL>;
-    if (int rc = fa2::set_lds<kern>(fa2::kD128LdsBytes)) return rc;
+template <int HD, bool BF16, bool CAUSAL>
+int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
+    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL>;
+    constexpr int lds = fa2::AsmGeo<HD>::LDS_BYTES;
+    if (int rc = fa2::set_lds<kern>(lds)) return rc;
     fa2::FwdParams p = p0;
     p.persist = fa2::options().persist.load(std::memory_order_relaxed) ? 1 : 0;
     const int pg = fa2::device_cus() & ~7;       // a multiple of 8: a unit stays on its head's XCD
@@ -28,7 +29,7 @@ int launch_d128_t(const fa2::FwdParams& p0, hipStream_t stream) {
     const int64_t per_head = (CAUSAL && p.persist) ? (p.nqblk + 1) / 2 : p.nqblk;
     int64_t grid = (int64_t)p.nbh * per_head;
     if (p.persist && pg > 0 && grid > pg) grid = pg;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), fa2::kD128LdsBytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -36,9 +37,13 @@ int launch_d128_t(const fa2::FwdParams& p0, hipStream_t stream) {
 
 namespace fa2 {
 
-int launch_fwd_d128(bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
-    if (bf16) return causal ? launch_d128_t<true, true>(p, stream) : launch_d128_t<true, false>(p, stream);
-    return causal ? launch_d128_t<false, true>(p, stream) : launch_d128_t<false, false>(p, stream);
+int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
+    if (HD == 128) {
+        if (bf16) return causal ? launch_asm_t<128, true, true>(p, stream) : launch_asm_t<128, true, false>(p, stream);
+        return causal ? launch_asm_t<128, false, true>(p, stream) : launch_asm_t<128, false, false>(p, stream);
+    }
+    if (bf16) return causal ? launch_asm_t<64, true, true>(p, stream) : launch_asm_t<64, true, false>(p, stream);
+    return causal ? launch_asm_t<64, false, true>(p, stream) : launch_asm_t<64, false, false>(p, stream);
 }
 
 }  // namespace fa2

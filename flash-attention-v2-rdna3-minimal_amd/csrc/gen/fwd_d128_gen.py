@@ -4,7 +4,7 @@
 Replaces the compiler-scheduled steady state of fa2_fwd_kernel.hip.h for the headline shape class
 (reference counterpart: kernel_fp16.cu:381-508, the per-KV-block loop of fwd_kernel).  The output is
 the body of ONE inline-asm statement (fa2_fwd_d128_{f16,bf16}.inc) that the HIP kernel
-`fwd_d128_kernel` (fa2_fwd_d128.hip.h) wraps: the HIP side computes addresses, the asm block does
+`fwd_asm_kernel` (fa2_fwd_d128.hip.h) wraps: the HIP side computes addresses, the asm block does
 everything from the Q load to the normalised O tile staged in LDS, the HIP side stores it.
 
 Shape of the computation (one workgroup = 4 waves = 256 Q rows, ONE wave per SIMD, 512 registers):
@@ -109,23 +109,48 @@ S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, firs
 CLOBBER_S = list(range(60, 94))
 CLOBBER_V = list(range(VBASE, 256))
 
-K_SLOT, V_BASE, SLOT_B = 0, 32768, 16384
-EPI_ROWB = 272                                     # bytes per staged O row (256 + 16 pad)
-EPI_BASE = 65536                                   # the epilogue image sits above the K / V rings: they hold the next item's first tiles by then
-LDS_BYTES = EPI_BASE + 4 * 64 * EPI_ROWB           # 135168
 
 
 
-def OACC(qb, dt):
-    return A(64 * qb + 16 * dt, 16)
+class Geo:
+    """Head-dim dependent sizes of a forward body (HD = 128: the headline kernel; HD = 64: the reference harness's own shape and SDXL's)."""
+
+    def __init__(self, hd):
+        assert hd in (64, 128)
+        self.HD = hd
+        self.NKS = hd // 16                 # MFMA k-steps of Q.K^T
+        self.NDT = hd // 32                 # 32-wide d blocks of O
+        self.ROWB = 2 * hd                  # bytes per tile row
+        self.SLOT_B = 64 * self.ROWB        # bytes of one K (or V) tile image
+        self.NP = self.SLOT_B // 4096       # LDS-DMA pieces of 1 KiB per wave and tile
+        self.RPP = 1024 // self.ROWB        # tile rows per piece
+        self.K_SLOT, self.V_BASE = 0, 2 * self.SLOT_B
+        self.EPI_ROWB = self.ROWB + 16      # bytes per staged O row (padded: conflict-free column writes and row reads)
+        self.EPI_BASE = 4 * self.SLOT_B     # the epilogue image sits above the K / V rings: they hold the next item's first tiles by then
+        self.LDS_BYTES = self.EPI_BASE + 4 * 64 * self.EPI_ROWB
+        self.QF0 = 32 * self.NDT            # accumulator file: O[qb][dt] | Q[qb][ks] | K[kvb][ks]
+        self.KF0 = self.QF0 + 8 * self.NKS
+        self.LA0 = self.KF0 + 8 * self.NKS  # "lmfma": the row sums as two more accumulator tiles (row 0 of each)
 
 
-def QF(qb, ks):
-    return A(128 + 32 * qb + 4 * ks, 4)
+G128 = Geo(128)
+K_SLOT, V_BASE, SLOT_B = G128.K_SLOT, G128.V_BASE, G128.SLOT_B          # (module-level names: the HD = 128 geometry, used by the emulator harness)
+EPI_ROWB, EPI_BASE, LDS_BYTES = G128.EPI_ROWB, G128.EPI_BASE, G128.LDS_BYTES   # 272, 65536, 135168
 
 
-def KF(kvb, ks):
-    return A(192 + 32 * kvb + 4 * ks, 4)
+def OACC(qb, dt, g=G128):
+    return A(16 * (g.NDT * qb + dt), 16)
+
+
+def QF(qb, ks, g=G128):
+    return A(g.QF0 + 4 * (g.NKS * qb + ks), 4)
+
+
+def KF(kvb, ks, g=G128):
+    return A(g.KF0 + 4 * (g.NKS * kvb + ks), 4)
+
+
+ONESF = V(248, 4)                                  # "lmfma": A fragment whose row 0 is all ones (lanes 0 and 32), every other row zero
 
 
 def KF_POOL(kvb, ks):                              # "ct" kernels: a 32-register pool, k-step ks lives in slot ks % 4
@@ -170,22 +195,38 @@ class Gen:
                 "shift": (0.0, 0.0),
                 "dmaw": (0.0, 0.0)}      # (width, step) > 0: one copy of the fast loop per wave, wave w stages in gaps [dma0 + w*step, +width)     # code-placement probe: (n s_nop before the fast loop, log2 alignment of its first instruction)
 
-    def __init__(self, bf16=False, **cfg):
+    # HD = 64: half the MFMAs per tile for the same softmax work, so the windows are those of a 32-gap body
+    # (with the row sums on the matrix pipe: 24 PV-phase + 16 QK-phase MFMAs)
+    DEFAULTS64 = {"m": (1.0, 8.0), "e": (8.0, 40.0), "vread": (25.0, 32.0), "kread": (0.0, 14.0), "dma": (4.0, 18.0), "mmask": (1.0, 18.0)}
+
+    def __init__(self, bf16=False, hd=128, **cfg):
+        self.g = Geo(hd)
         self.cfg = dict(self.DEFAULTS)
+        if hd == 64:
+            self.cfg.update(self.DEFAULTS64)
         self.cfg.update(cfg)
         if "w1" in self.cfg and "w2" in self.cfg:     # scheduler weights: w1=trans:lds, w2=dma:salu
             set_weights(self.cfg["w1"][0], self.cfg["w1"][1], self.cfg["w2"][0], self.cfg["w2"][1])
         self.opt = set(self.cfg["opt"])
         self.ct = "ct" in self.opt        # folded scale: Q * c rounded once, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
         self.fold = self.ct               # prescaled Q, S leaves the MFMA as (score - reference)
-        self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else KF      # ctk64: timing probe (K and V^T fragments collide)
+        g = self.g
+        assert hd == 128 or not (self.opt & {"ct", "vagpr", "ctk64"}), "the folded-scale / probe register maps exist for head dim 128 only"
+        self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else (lambda kvb, ks: KF(kvb, ks, g))      # ctk64: timing probe (K and V^T fragments collide)
         self.vf = VF_CT if self.ct else VF
-        self.qf = QF
+        self.qf = lambda qb, ks: QF(qb, ks, g)
+        self.oacc = lambda qb, dt: OACC(qb, dt, g)
         if "vagpr" in self.opt:
             self.vf = VF_ACC
             self.qf = QF_SPLIT if self.ct else QF_ARCH
-        self.nqk = 32
-        self.ng = 32 + self.nqk           # MFMAs (= gaps) per body
+        # "lmfma": the row sums ride the matrix pipe — one more accumulator tile per q block whose row 0 is sum_kv P (A = ONESF): the 64
+        # v_add_f32 per tile go, 8 MFMAs come.  Default at head dim 64, where the body is VALU-bound (32 MFMAs per tile for the same
+        # softmax work as at 128); at 128 the round-2 measurement of the idea in the 8-wave kernel was -3 %.
+        self.lmfma = ("lmfma" in self.opt) or (hd == 64 and "nolmfma" not in self.opt)
+        self.lacc = lambda qb: A(g.LA0 + 16 * qb, 16)
+        self.npv = 8 * g.NDT + (8 if self.lmfma else 0)   # MFMAs of the PV phase (both q blocks) ...
+        self.nqk = 4 * g.NKS              # ... and of the QK phase
+        self.ng = self.npv + self.nqk     # MFMAs (= gaps) per body
         self.bf16 = bf16
         self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if bf16 else "v_cvt_pk_f16_f32"
@@ -197,21 +238,23 @@ class Gen:
     def pv_mfmas(self, par, qb):
         out = []
         if "chainpv" in self.opt:      # probe: the four k-steps of an accumulator back to back (C forwarded inside the pipe?)
-            for dt in range(4):
+            for dt in range(self.g.NDT):
                 for ks in range(4):
                     pfrag = SB(qb, par).sub(16 * (ks >> 1) + 8 * (ks & 1), 4)
-                    out.append(mk(self.mfma, OACC(qb, dt), self.vf(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
+                    out.append(mk(self.mfma, self.oacc(qb, dt), self.vf(dt, ks), pfrag, self.oacc(qb, dt), tag="mfma"))
             return out
         for ks in range(4):
             pfrag = SB(qb, par).sub(16 * (ks >> 1) + 8 * (ks & 1), 4)
-            for dt in range(4):
-                out.append(mk(self.mfma, OACC(qb, dt), self.vf(dt, ks), pfrag, OACC(qb, dt), tag="mfma"))
+            for dt in range(self.g.NDT):
+                out.append(mk(self.mfma, self.oacc(qb, dt), self.vf(dt, ks), pfrag, self.oacc(qb, dt), tag="mfma"))
+            if self.lmfma:
+                out.append(mk(self.mfma, self.lacc(qb), ONESF, pfrag, self.lacc(qb), tag="mfma"))
         return out
 
     def qk_mfmas(self, par):
         """S(t+2) for both q blocks; the four 32x32 accumulators take turns (a dependent MFMA is four issues away)."""
         out = []
-        order = [(ks, qb, kvb) for ks in range(8) for qb in range(2) for kvb in range(2)]
+        order = [(ks, qb, kvb) for ks in range(self.g.NKS) for qb in range(2) for kvb in range(2)]
         if "chainqk" in self.opt:      # probe: pairs of k-steps of one accumulator back to back
             order = [(2 * kp + j, qb, kvb) for kp in range(4) for qb in range(2) for kvb in range(2) for j in range(2)]
         for (ks, qb, kvb) in order:
@@ -238,7 +281,7 @@ class Gen:
                 e = 2 * (k - 1)
                 E.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
                 E.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
-            if 0 <= k - 2 < 16 and "noadd" not in self.opt:   # stage 2: row sums
+            if 0 <= k - 2 < 16 and "noadd" not in self.opt and not self.lmfma:   # stage 2: row sums
                 e = 2 * (k - 2)
                 Ad.append(mk("v_add_f32", LA[qb], LA[qb], b[e], tag="valu"))
                 Ad.append(mk("v_add_f32", LB[qb], LB[qb], b[e + 1], tag="valu"))
@@ -311,8 +354,9 @@ class Gen:
         if not first:               # the q block's first tile: O is still all zeros, nothing to rescale later
             r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
         r.append(mk("s_nop", 0))
-        r.append(mk("v_mul_f32", LA[qb], LA[qb], mxb))
-        r.append(mk("v_mul_f32", LB[qb], LB[qb], mxb))
+        if not self.lmfma:      # (with the row sums in the accumulator file they are rescaled with O, at the phase boundary)
+            r.append(mk("v_mul_f32", LA[qb], LA[qb], mxb))
+            r.append(mk("v_mul_f32", LB[qb], LB[qb], mxb))
         r.append(mk("v_mov_b32", FSC[qb], mxb))
         r.append(mk("s_branch", Label(lab + "_ret")))
         self.rare.append(r)
@@ -349,18 +393,20 @@ class Gen:
 
     def stream_kread(self, par):
         out = []
-        for ks in range(8):
+        g = self.g
+        for ks in range(g.NKS):
             for kvb in range(2):
-                out.append(mk("ds_read_b128", self.kf(kvb, ks), KR[ks], tag="lds", offset=K_SLOT + par * SLOT_B + kvb * 8192))
+                out.append(mk("ds_read_b128", self.kf(kvb, ks), KR[ks], tag="lds", offset=g.K_SLOT + par * g.SLOT_B + kvb * 32 * g.ROWB))
         return out
 
     def stream_vread(self, par):
         out = []
+        g = self.g
         for ks in range(4):
-            for dt in range(4):
-                off = V_BASE + par * SLOT_B + 16 * ks * 256
+            for dt in range(g.NDT):
+                off = g.V_BASE + par * g.SLOT_B + 16 * ks * g.ROWB
                 out.append(mk("ds_read_b64_tr_b16", self.vf(dt, ks).sub(0, 2), VR[dt], tag="lds", offset=off))
-                out.append(mk("ds_read_b64_tr_b16", self.vf(dt, ks).sub(2, 2), VR[dt], tag="lds", offset=off + 8 * 256))
+                out.append(mk("ds_read_b64_tr_b16", self.vf(dt, ks).sub(2, 2), VR[dt], tag="lds", offset=off + 8 * g.ROWB))
         return out
 
     def dma_group(self, which, slot_par, guarded, ahead):
@@ -372,7 +418,8 @@ class Gen:
         registers are idle by then), and the end-of-body wait stops draining vmcnt."""
         out = []
         rs, vd, soff = (A_KRS, KD, S_KOFF) if which == "k" else (A_VRS, VD, S_VOFF)
-        base = (K_SLOT if which == "k" else V_BASE) + slot_par * SLOT_B
+        g = self.g
+        base = (g.K_SLOT if which == "k" else g.V_BASE) + slot_par * g.SLOT_B
         skip = None
         if guarded:
             skip = self.p.fresh("dma_skip")
@@ -388,27 +435,27 @@ class Gen:
             r.append(mk("s_cbranch_scc0", Label(skip)))
             r.append(mk("s_mov_b32", S_NOVM, 1))
             nrs = A_NKRS if which == "k" else A_NVRS
-            nbase = K_SLOT if which == "k" else V_BASE
+            nbase = g.K_SLOT if which == "k" else g.V_BASE
             r.append(mk("s_add_u32", M0, A_LDSW, nbase))
             r.append(mk("s_nop", 0))
-            for i in range(4):
+            for i in range(g.NP):
                 r.append(mk("buffer_load_dwordx4", vd[i], nrs, 0, offen=True, offset=1024 * i, lds=True))
             if which == "k":
                 one = self.p.fresh("dma_next_one")
                 r.append(mk("s_bitcmp1_b32", A_FLAGS, 2))        # the next item has a second tile (causal items differ in length)
                 r.append(mk("s_cbranch_scc0", Label(one)))
-                r.append(mk("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B))
+                r.append(mk("s_add_u32", M0, A_LDSW, g.K_SLOT + g.SLOT_B))
                 r.append(mk("s_nop", 0))
-                for i in range(4):
+                for i in range(g.NP):
                     r.append(mk("buffer_load_dwordx4", vd[i], nrs, A_KTILE, offen=True, offset=1024 * i, lds=True))
                 r.append(Ins("label", (Label(one),)))
                 for qb in range(2):
-                    for ks in range(8):
+                    for ks in range(g.NKS):
                         r.append(mk("global_load_dwordx4", self.qf(qb, ks), A_NQO0 if qb == 0 else A_NQO1, A_NQB, offset=32 * ks))
             r.append(mk("s_branch", Label(skip)))
             self.rare.append(r)
         out.append([mk("s_add_u32", M0, A_LDSW, base, tag="salu"), mk("s_nop", 0, tag="salu")])
-        for i in range(4):
+        for i in range(g.NP):
             out.append(mk("buffer_load_dwordx4", vd[i], rs, soff, tag="dma", offen=True, offset=1024 * i, lds=True))
         if guarded:
             out.append(Ins("label", (Label(skip),)))
@@ -432,12 +479,11 @@ class Gen:
         fast = name.startswith("F")
         abl = set(cfg["abl"]) if fast else set()
         ng = self.ng
-        sc = (ng - 32) / 32.0                 # QK-phase windows are given for 32 gaps: stretch them for the folded-scale kernels
         def W(w):
-            return tuple(32.0 + (x - 32.0) * sc if x > 32.0 else x for x in w)
+            return tuple(w)
         mf = []
-        mf += self.pv_mfmas(par, 0) if pv else [None] * 16
-        mf += self.pv_mfmas(par, 1) if pv else [None] * 16
+        mf += self.pv_mfmas(par, 0) if pv else [None] * (self.npv // 2)
+        mf += self.pv_mfmas(par, 1) if pv else [None] * (self.npv // 2)
         mf += self.qk_mfmas(par) if s2 else [None] * self.nqk
         if "mfma" in abl:
             mf = [None] * ng
@@ -534,7 +580,7 @@ class Gen:
         # emit: gap g fillers come AFTER mfma g
         body_start = len(p.ins)
         for g in range(ng):
-            if g == 32:
+            if g == self.npv:
                 # phase boundary: all of PV(t) is issued.  Rare O rescale, then K(t+2) fragments must have landed.
                 lab = p.fresh("rare_r")
                 p.emit("s_cmp_lg_u32", S_FLAG, 0)
@@ -593,8 +639,8 @@ class Gen:
             skip = self.p.fresh("rr_skip")
             r.append(mk("s_bitcmp1_b32", S_FLAG, qb))
             r.append(mk("s_cbranch_scc0", Label(skip)))
-            for dt in range(4):
-                acc = OACC(qb, dt)
+            for dt in range(self.g.NDT):
+                acc = self.oacc(qb, dt)
                 for i in range(0, 16, 8):
                     for j in range(8):
                         r.append(mk("v_accvgpr_read_b32", TMP[j], acc[i + j]))
@@ -604,6 +650,12 @@ class Gen:
                     r.append(mk("s_nop", 1))
                     for j in range(8):
                         r.append(mk("v_accvgpr_write_b32", acc[i + j], TMP[j]))
+            if self.lmfma:
+                r.append(mk("v_accvgpr_read_b32", TMP[0], self.lacc(qb)[0]))
+                r.append(mk("s_nop", 1))
+                r.append(mk("v_mul_f32", TMP[0], TMP[0], FSC[qb]))
+                r.append(mk("s_nop", 1))
+                r.append(mk("v_accvgpr_write_b32", self.lacc(qb)[0], TMP[0]))
             r.append(Ins("label", (Label(skip),)))
         r.append(mk("s_mov_b32", S_FLAG, 0))
         r.append(mk("s_nop", 7))
@@ -618,9 +670,10 @@ class Gen:
         p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
         if tr:
             p.emit("s_memtime", S_MARK[0])
-        for ks in range(8):
+        g = self.g
+        for ks in range(g.NKS):
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
-        for dt in range(4):
+        for dt in range(g.NDT):
             p.emit("v_xor_b32", VR[dt], dt << 6, A_VR0)
         # Q fragments: 16 loads, unless the previous item of this persistent workgroup already fetched them (flag bit 0)
         p.emit("s_and_b32", S_PF, A_FLAGS, 1)
@@ -628,7 +681,7 @@ class Gen:
         p.emit("s_cbranch_scc1", Label("have_q"))
         if not self.fold:
             for qb in range(2):
-                for ks in range(8):
+                for ks in range(g.NKS):
                     p.emit("global_load_dwordx4", self.qf(qb, ks), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
             p.label("have_q")
         else:
@@ -650,7 +703,7 @@ class Gen:
         p.emit("v_mov_b32", VD[0], A_VD0)
         p.emit("s_mov_b32", S_TMP, 0)
         p.emit("s_mov_b32", S_TMP2, 0)
-        for i in range(1, 4):
+        for i in range(1, g.NP):
             p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
             p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
             p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
@@ -658,7 +711,7 @@ class Gen:
             p.emit("s_nop", 0)
             p.emit("v_add_u32", KD[i], S_TMP, KD[i])
         p.emit("s_mov_b32", S_T, -2)
-        p.emit("s_lshr_b32", S_WAVE, A_LDSW, 12)
+        p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mov_b32", S_FLAG, 0)
         for r in S_SUM:
             p.emit("s_mov_b32", r, 0)
@@ -668,23 +721,23 @@ class Gen:
         p.emit("s_cmp_eq_u32", S_PF, 1)
         p.emit("s_cbranch_scc1", Label("staged"))
         # K(0) -> K slot 0 (always exists)
-        p.emit("s_add_u32", M0, A_LDSW, K_SLOT)
+        p.emit("s_add_u32", M0, A_LDSW, g.K_SLOT)
         p.emit("s_nop", 0)
-        for i in range(4):
+        for i in range(g.NP):
             p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
         # ... and what body B(-2) would stage, V(0) and K(1), right behind it: all three tiles' latencies overlap (B(-2) then
         # stages nothing).  The running offsets are those of tile t+3 / t+2 of the body that uses them.
         early = True
         if early:
-            p.emit("s_add_u32", M0, A_LDSW, V_BASE)
+            p.emit("s_add_u32", M0, A_LDSW, g.V_BASE)
             p.emit("s_nop", 0)
-            for i in range(4):
+            for i in range(g.NP):
                 p.emit("buffer_load_dwordx4", VD[i], A_VRS, S_VOFF, offen=True, offset=1024 * i, lds=True)
             p.emit("s_cmp_lt_i32", A_NTWG, 2)
             p.emit("s_cbranch_scc1", Label("no_k1"))
-            p.emit("s_add_u32", M0, A_LDSW, K_SLOT + SLOT_B)
+            p.emit("s_add_u32", M0, A_LDSW, g.K_SLOT + g.SLOT_B)
             p.emit("s_nop", 0)
-            for i in range(4):
+            for i in range(g.NP):
                 p.emit("buffer_load_dwordx4", KD[i], A_KRS, A_KTILE, offen=True, offset=1024 * i, lds=True)
             p.label("no_k1")
         p.label("staged")
@@ -694,8 +747,19 @@ class Gen:
             p.emit("v_mov_b32", LA[qb], 0)
             p.emit("v_mov_b32", LB[qb], 0)
             p.emit("v_mov_b32", FSC[qb], 1.0)
-        for i in range(128):
+        for i in range(32 * g.NDT):
             p.emit("v_accvgpr_write_b32", A(i), 0)
+        if self.lmfma:
+            for i in range(32):
+                p.emit("v_accvgpr_write_b32", A(g.LA0 + i), 0)
+            # ONESF: 1.0 in all eight k-slots of MFMA row 0 (lanes 0 and 32: the epilogue address is row*EPI_ROWB + hi*16 above the base)
+            p.emit("s_mul_i32", S_TMP, S_WAVE, 64 * g.EPI_ROWB)
+            p.emit("s_add_u32", S_TMP, S_TMP, g.EPI_BASE)
+            p.emit("v_subrev_u32", TMP[0], S_TMP, A_EPI)               # l31 * EPI_ROWB + hi * 16
+            p.emit("v_mov_b32", TMP[1], 0x3f803f80 if self.bf16 else 0x3c003c00)
+            p.emit("v_cmp_gt_u32", VCC, g.EPI_ROWB, TMP[0])            # row 0 <=> the offset is below one row pitch
+            for i in range(4):
+                p.emit("v_cndmask_b32", ONESF[i], 0, TMP[1], VCC)
         if self.ct:
             for qb in range(2):
                 for i in range(16):
@@ -738,10 +802,10 @@ class Gen:
             # Q and K(0) are needed now; V(0) and K(1) (8 or 4 pieces issued behind them) may keep flying until the end of B(-2)
             p.emit("s_cmp_lt_i32", A_NTWG, 2)
             p.emit("s_cbranch_scc1", Label("wait4"))
-            p.emit("s_waitcnt", vmcnt=8)
+            p.emit("s_waitcnt", vmcnt=2 * g.NP)
             p.emit("s_branch", Label("waited"))
             p.label("wait4")
-            p.emit("s_waitcnt", vmcnt=4)
+            p.emit("s_waitcnt", vmcnt=g.NP)
             p.label("waited")
         p.emit("s_barrier")
 
@@ -827,7 +891,10 @@ class Gen:
         p.emit("s_nop", 15)
         for qb in range(2):
             lt, t, inv = EP_LT, EP_T, EP_INV
-            p.emit("v_add_f32", lt, LA[qb], LB[qb])
+            if self.lmfma:
+                p.emit("v_accvgpr_read_b32", lt, self.lacc(qb)[0])     # row 0 of the tile: lanes 0..31 hold their row's sum, lanes 32..63 a zero
+            else:
+                p.emit("v_add_f32", lt, LA[qb], LB[qb])
             p.emit("s_nop", 0)
             p.emit("v_mov_b32", t, lt)
             p.emit("s_nop", 1)
@@ -838,8 +905,8 @@ class Gen:
             p.emit("v_log_f32", t, lt)
             p.emit("s_nop", 0)
             p.emit("v_add_f32", KD[qb], MC[qb], t)            # (the outputs may share registers with inputs: written last)
-            for dt in range(4):
-                acc = OACC(qb, dt)
+            for dt in range(g.NDT):
+                acc = self.oacc(qb, dt)
                 for r4 in (0, 2):
                     for j in range(8):
                         p.emit("v_accvgpr_read_b32", TMP[j], acc[4 * r4 + j])
@@ -859,7 +926,7 @@ class Gen:
                     p.emit("v_permlane32_swap_b32", TMP[1], TMP[3])
                     p.emit("s_nop", 0)
                     # 16 bytes {x0[0], x1[0], x0[1], x1[1]} at row (32qb + l31), column 32dt + 8(r4 + hi)
-                    p.emit("ds_write_b128", A_EPI, d4, offset=32 * qb * EPI_ROWB + (32 * dt + 8 * r4) * 2)
+                    p.emit("ds_write_b128", A_EPI, d4, offset=32 * qb * g.EPI_ROWB + (32 * dt + 8 * r4) * 2)
                     p.emit("s_nop", 1)
         p.emit("s_waitcnt", lgkmcnt=0)
         p.emit("v_mov_b32", A_LSE0, KD[0])
@@ -951,12 +1018,15 @@ def main():
     cfg = parse_opts(a.opt)
     if is_probe(cfg) and not a.probe:
         sys.exit("fwd_d128_gen.py: %r contains timing-probe options; they need --probe and must not go into the product build" % a.opt)
-    for bf16 in (False, True):
-        g = Gen(bf16, **cfg)
-        prog = g.build()
-        path = os.path.join(out_dir, "fa2_fwd_d128_%s.inc" % ("bf16" if bf16 else "f16"))
-        write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))
-        print(path, len(prog.ins), "instructions")
+    for hd in (128, 64):
+        if hd == 64 and any(o in ("ct",) + PROBE_OPTS for o in cfg.get("opt", ())):
+            continue
+        for bf16 in (False, True):
+            g = Gen(bf16, hd=hd, **cfg)
+            prog = g.build()
+            path = os.path.join(out_dir, "fa2_fwd_d%d_%s.inc" % (hd, "bf16" if bf16 else "f16"))
+            write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))
+            print(path, len(prog.ins), "instructions")
     write_atomic(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"),
                  "// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.\n" + clobber_list() + "\n")
 

@@ -106,12 +106,18 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
 
 // Head dim exactly 128 with a positive scale runs the hand-scheduled 4-wave kernel (fa2_fwd_d128.hip.h) unless option "asm"
 // bit 0 is cleared (A/B measurements, tools/kbench.py).  The asm block addresses a head's Q rows with 32-bit byte offsets.
-bool d128_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + 128) * 2 < ((int64_t)1 << 32); }
+bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32); }
 
 int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     const int rows = pick_rows(p, causal);
-    if (HD == 128 && p.D == 128 && !p.negate_q && asm_fwd() && pick_rows(p) == 256 && d128_q_span_ok(p))
-        return fa2::launch_fwd_d128(bf16, p, causal, stream);
+    // Head dim exactly 128 with a positive scale: the hand-scheduled 4-wave kernel (256-row workgroups).  Head dim 64 has its generated
+    // body too (same generator, half the MFMAs per tile for the same softmax work, row sums on the matrix pipe), but a lone wave per SIMD
+    // issues that VALU-bound mix no faster than the two waves of the compiler-scheduled 8-wave kernel: same box (tools/fwd_ab.py) B2 H16
+    // N4096 933 vs 947 TF, B1 H24 N8192 1032 vs 1022, causal bf16 917 vs 869 — so it takes the causal launches (+5.5 %) only; option
+    // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
+    const bool d64_asm = HD == 64 && (causal || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p))
+        return fa2::launch_fwd_asm(HD, bf16, p, causal, stream);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
 }
 

@@ -186,7 +186,8 @@ int fa2_fwd_prescales_q(int D, float scale);
  * Initial values come from the environment variable named below, read once when the library is loaded.
  *   "rows"  FA2_ROWS   0 (default: heuristic on the grid size) | 128 | 256 — Q rows per forward (and dQ-pass) workgroup
  *   "asm"       FA2_ASM        bit 0: hand-scheduled forward bodies (head dims 64 and 128), bit 1: hand-scheduled backward
- *                              bodies (head dim 128), bits 2 / 3: ... except its dQ pass / its dK-dV pass; default 3.  0 = compiler-scheduled HIP kernels everywhere
+ *                              bodies (head dim 128), bits 2 / 3: ... except its dQ pass / its dK-dV pass, bit 4: the head-dim-64
+ *                              forward body for non-causal launches too (default: causal only); default 3.  0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)

@@ -29,6 +29,8 @@
  *                          reference's 16-bit LDS accumulator is (kernel_fp16.cu:223-228, :483-488),
  *                          and m, l kept in the I/O dtype as pure_torch_ver.py:54-58 does
  *   FA2_ORACLE_BF16_TRUNC  bf16 conversions truncate instead of RNE (kernel_bf16.cu:62-72)
+ *   FA2_ORACLE_LSUM_P16    the row sum l adds the ROUNDED P (the values the P.V product consumes) instead of the f32 P: the
+ *                          contract of the gfx950 head-dim-64 body, whose row sums ride the matrix pipe (csrc/gen/fwd_d128_gen.py "lmfma")
  *   FA2_ORACLE_PRESCALE_Q  Q is multiplied by scale*log2(e) and rounded back to the I/O dtype BEFORE the
  *                          product, as pure_torch_ver.py:61 does (`scale * q_frags[Tr_i]`); S = Q' K^T is then
  *                          not scaled again.  The gfx950 kernels use this contract where
@@ -50,6 +52,7 @@
 #define FA2_ORACLE_ROUND_O 2
 #define FA2_ORACLE_BF16_TRUNC 4
 #define FA2_ORACLE_PRESCALE_Q 8
+#define FA2_ORACLE_LSUM_P16 16
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -133,7 +136,7 @@ static int fwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint1
     const float c = scale * 1.4426950408889634f; /* kernel_fp16.cu:827 */
     const int Tr = (Nq + Br - 1) / Br, Tc = (Nkv + Bc - 1) / Bc;
     const int round_s = flags & FA2_ORACLE_ROUND_S, round_o = flags & FA2_ORACLE_ROUND_O;
-    const int prescale = flags & FA2_ORACLE_PRESCALE_Q;
+    const int prescale = flags & FA2_ORACLE_PRESCALE_Q, lsum16 = flags & FA2_ORACLE_LSUM_P16;
     const float cs = prescale ? 1.f : c; /* factor applied to the f32 dot product */
     int failed = 0;
 #ifdef _OPENMP
@@ -217,8 +220,8 @@ static int fwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint1
                             float rs = 0.f;
                             for (int j = 0; j < cols; ++j) {
                                 const float p = (m_new == -INFINITY) ? 0.f : exp2f(Si[j] - m_new);
-                                rs += p;                 /* row sum of the unrounded P (kernel_fp16.cu:455-479) */
                                 Si[j] = round16(cv, p);  /* P fed to the matrix unit in the I/O dtype */
+                                rs += lsum16 ? Si[j] : p; /* row sum of the unrounded P (kernel_fp16.cu:455-479), or of what P.V consumes */
                             }
                             float* Oi = O + (size_t)i * D;
                             l[i] = l[i] * alpha + rs;

@@ -79,6 +79,54 @@ def test_persistent_workgroup_seams(seam, variant):
         assert np.abs(lse - lse_ref).max() <= 1e-4
 
 
+D64_CASES = [
+    # Nq, Nkv, q block, causal, bf16, spike: the head-dim-64 body of the same generator (hd=64: 16 + 8 PV-phase MFMAs — the row sums
+    # ride the matrix pipe — and 16 QK-phase MFMAs per tile, 128-byte tile rows)
+    (256, 256, 0, False, False, False),
+    (256, 64, 0, False, False, False),
+    (256, 100, 0, False, True, False),
+    (256, 640, 0, False, False, False),
+    (200, 333, 0, False, False, False),
+    (512, 512, 1, True, False, False),
+    (256, 77, 0, True, True, False),
+    (256, 704, 0, False, False, True),        # the rescale branch: the row-sum accumulators are rescaled with O
+]
+
+
+@pytest.fixture
+def hd64():
+    saved = harness.HD
+    harness.HD = 64
+    yield
+    harness.HD = saved
+
+
+@pytest.mark.parametrize("case", D64_CASES)
+def test_generated_d64_block_matches_dense_attention(case, hd64):
+    nq, nkv, qblk, causal, bf16, spike = case
+    err, lse_err, m = harness.check(nq, nkv, qblk, causal, bf16=bf16, spike=spike, seed=nq + nkv, verbose=False)
+    assert not m.errors, m.errors[:5]
+    assert err <= (6e-3 if bf16 else (2e-3 if spike else 1e-3)), err
+    assert lse_err <= (4e-3 if bf16 else 1e-3), lse_err          # (the sums add the ROUNDED P: 2^-9 / 2^-11 relative noise per term)
+
+
+def test_d64_persistent_items_and_causal_pairs(hd64):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    items = [(rng.standard_normal((768, 64)), rng.standard_normal((nk, 64)), rng.standard_normal((nk, 64)), qb) for nk, qb in zip([640, 640, 600], [0, 2, 1])]
+    outs, m = harness.run_items(items, False)
+    assert not m.errors, m.errors[:5]
+    for (q, k, v, qb), (o, lse) in zip(items, outs):
+        o_ref, _ = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256)
+        assert np.abs(o - o_ref).max() <= 1e-3
+    q, k, v = (rng.standard_normal((1024, 64)) for _ in range(3))
+    outs, m = harness.run_items([(q, k, v, 3), (q, k, v, 0)], True)
+    assert not m.errors, m.errors[:5]
+    o_ref, _ = harness.dense(q, k, v, True)
+    for qb, (o, _) in zip([3, 0], outs):
+        assert np.abs(o - o_ref[qb * 256:qb * 256 + 256]).max() <= 1e-3
+
+
 CAUSAL_SEAMS = [
     # Nq = Nkv, [q block per item]: the pairs a causal launch hands to one workgroup — a long block, then its short partner
     (1024, [3, 0], False),            # 16 tiles, then 4: the ring parities and the per-wave tile counts differ across the seam
@@ -142,10 +190,10 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     subst = {0: "v0", 1: "v1", 2: "v2", 3: "v3", 4: "s[0:1]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
              12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
              23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]"}
-    for bf16 in (False, True):
-        text = "\n".join(gen.Gen(bf16, opt=opt).build().text_lines())
+    for bf16, hd in ((False, 128), (True, 128)) + (((False, 64), (True, 64)) if not opt else ()):
+        text = "\n".join(gen.Gen(bf16, hd=hd, opt=opt).build().text_lines())
         text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))
-        src = tmp_path / ("body_%d.s" % bf16)
+        src = tmp_path / ("body_%d_%d.s" % (bf16, hd))
         src.write_text(text + "\n")
         res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[:2000]

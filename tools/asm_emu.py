@@ -360,6 +360,9 @@ class Machine:
                 w.last_m0_write = w.issue_idx
             else:
                 w.s[d.idx] = val
+        elif op == "s_mul_i32":
+            d = R(0)
+            w.s[d.idx] = np.uint32((self.rds(w, ops[1]) * self.rds(w, ops[2])) & 0xffffffff)
         elif op in ("s_add_u32", "s_sub_u32", "s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
             x, y = self.rds(w, ops[1]), self.rds(w, ops[2])
             if op == "s_add_u32":
@@ -451,6 +454,8 @@ class Machine:
             self.wr32(w, ops[0], (old & np.uint32(0xffff0000)) | f32_to_f16_bits(self.rdf(w, ops[1])))
         elif op == "v_cmp_eq_u32":
             w.vcc = self.rd32(w, ops[1]) == self.rd32(w, ops[2])
+        elif op == "v_cmp_gt_u32":
+            w.vcc = self.rd32(w, ops[1]) > self.rd32(w, ops[2])
         elif op == "v_xor_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]) ^ self.rd32(w, ops[2]))
         elif op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32"):

@@ -15,12 +15,18 @@ from isa import Reg  # noqa: E402
 LOG2E = 1.4426950408889634
 _PROGS = {}
 OPT = ()                # generator options of the programs under test (default: the f32-scale body the library ships)
+HD = 128                # head dim of the programs under test (128 or 64)
 
 
 def program(bf16):
-    if bf16 not in _PROGS:
-        _PROGS[bf16] = gen.Gen(bf16, opt=OPT).build()
-    return _PROGS[bf16]
+    key = (bf16, HD) if HD != 128 else bf16
+    if key not in _PROGS:
+        _PROGS[key] = gen.Gen(bf16, hd=HD, opt=OPT).build()
+    return _PROGS[key]
+
+
+def geo():
+    return gen.Geo(HD)
 
 
 def to_bits(x, bf16):
@@ -32,9 +38,11 @@ def from_bits(b, bf16):
     return asm_emu.bf16_to_f32(b) if bf16 else asm_emu.f16_to_f32(b)
 
 
-def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=256, flags=0, nxt=None):
-    """The values fa2_fwd_d128.hip.h hands to the asm statement, for wave w of the workgroup working on Q block qblk.
-    nxt = (qblk, Nq, q_base, k_base, v_base, Nkv) of the workgroup's next item (flags bit 1) or None."""
+def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=None, flags=0, nxt=None):
+    """The values the forward shell (fa2_fwd_d128.hip.h) hands to the asm statement, for wave w of the workgroup working on Q block
+    qblk.  nxt = (qblk, Nq, q_base, k_base, v_base, Nkv) of the workgroup's next item (flags bit 1) or None."""
+    g = geo()
+    row_bytes = g.ROWB if row_bytes is None else row_bytes
     lane = np.arange(64)
     l31, hi = lane & 31, lane >> 5
     pp, g1 = lane & 15, (lane >> 4) & 1
@@ -64,18 +72,23 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         lim_c = qrow if causal else np.full(64, 0x3fffffff)
         lim = np.minimum(lim_c, Nkv - 1) - 64 * (ntw - 1) - 4 * hi
         v[11 + qb] = lim.astype(np.int32).view(np.uint32)
-    row = 16 * w + (lane >> 4)
-    slot = lane & 15
-    gk = slot ^ (row & 15)
+    # LDS images (fa2_fwd_kernel.hip.h Geo<HD>): K granule ^ ((row / RPB) & KMASK), V 64-byte chunk ^ ((row / RPB) & VMASK)
+    gran = g.ROWB // 16                                 # granules per row
+    rpb = max(1, 256 // g.ROWB)
+    kmask, vmask = min(gran, 16) - 1, min(g.ROWB // 64, 4) - 1
+    row = (64 // 4) * w + lane // gran                  # piece 0 of this wave: RPP rows, `gran` lanes per row
+    slot = lane % gran
+    gk = slot ^ ((row // rpb) & kmask)
     v[7] = (row * row_bytes + gk * 16).astype(np.uint32)
-    gv = (((slot >> 2) ^ (row & 3)) << 2) | (slot & 3)
+    gv = (((slot >> 2) ^ ((row // rpb) & vmask)) << 2) | (slot & 3)
     v[8] = (row * row_bytes + gv * 16).astype(np.uint32)
-    v[9] = (l31 * 256 + ((hi ^ (l31 & 15)) << 4)).astype(np.uint32)
-    v[10] = ((4 * hi + (pp >> 2)) * 256 + ((pp >> 2) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
-    v[13] = (gen.EPI_BASE + w * 64 * gen.EPI_ROWB + l31 * gen.EPI_ROWB + hi * 16).astype(np.uint32)
+    v[9] = (l31 * g.ROWB + ((hi ^ ((l31 // rpb) & kmask)) << 4)).astype(np.uint32)
+    trow = 4 * hi + (pp >> 2)
+    v[10] = (trow * g.ROWB + (((trow // rpb) & vmask) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
+    v[13] = (g.EPI_BASE + w * 64 * g.EPI_ROWB + l31 * g.EPI_ROWB + hi * 16).astype(np.uint32)
 
     def srd(base, nkv):
-        return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + 256, 0x00020000], dtype=np.uint32)
+        return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + g.ROWB, 0x00020000], dtype=np.uint32)
 
     def pair(base):
         return np.array([base & 0xffffffff, base >> 32], dtype=np.uint32)
@@ -89,8 +102,8 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     args[13] = int(np.float32(scale * LOG2E).view(np.uint32))
     args[14], args[15] = ntw, ntiles
     args[16] = args[17] = 64 * row_bytes
-    args[18] = args[19] = 4 * row_bytes - 1024
-    args[20] = w * 4096
+    args[18] = args[19] = g.RPP * row_bytes - 1024
+    args[20] = w * (g.SLOT_B // 4)
     args[21] = Reg("v", 13)
     args[22] = flags
     args[23], args[24] = Reg("v", 14), Reg("v", 15)
@@ -108,7 +121,7 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
     """One persistent workgroup works through `items` = [(q [Nq,128], k [Nkv,128], v [Nkv,128], qblk), ...]: the asm
     statement runs once per item, registers / LDS / loads in flight carry over, and between two statements this harness
     plays the HIP shell (reads the O tile out of the LDS image, rebinds v0..15).  Returns [(o, lse)], machine."""
-    scale = 128 ** -0.5 if scale is None else scale
+    scale = HD ** -0.5 if scale is None else scale
     pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)       # NaN guard bands around every matrix
     bufs, bases = [], []
     addr = 0x10000000
@@ -137,7 +150,7 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
         wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt)
               for w in range(4)]
         if m is None:
-            m = asm_emu.Machine(program(bf16), wa, gen.LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
+            m = asm_emu.Machine(program(bf16), wa, geo().LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
         else:
             m.reenter(wa)
         m.allow_vm_in_flight = nxt is not None
@@ -145,7 +158,8 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             w.v[:24] = a["vregs"]
         m.run()
         rows = min(256, Nq - qblk * 256)
-        img = m.lds[gen.EPI_BASE:gen.EPI_BASE + 4 * 64 * gen.EPI_ROWB].reshape(256, gen.EPI_ROWB)[:, :256].copy().view(np.uint16)
+        g = geo()
+        img = m.lds[g.EPI_BASE:g.EPI_BASE + 4 * 64 * g.EPI_ROWB].reshape(256, g.EPI_ROWB)[:, :g.ROWB].copy().view(np.uint16)
         o = from_bits(img, bf16)[:rows]
         lse = np.empty(256, dtype=np.float32)
         for w in range(4):
@@ -166,7 +180,7 @@ def dense(q, k, v, causal, scale=None, bf16=False, row0=0, pre=False):
     """float64 attention on the rounded inputs, log2-domain LSE.  pre: Q is multiplied by scale*log2(e) and rounded to the
     16-bit type first (the folded-scale contract), so the comparison isolates the kernel from that one rounding."""
     q, k, v = (from_bits(to_bits(t, bf16), bf16).astype(np.float64) for t in (q, k, v))
-    scale = 128 ** -0.5 if scale is None else scale
+    scale = q.shape[1] ** -0.5 if scale is None else scale
     if pre:
         c = np.float32(scale * LOG2E)
         qs = from_bits(to_bits((q.astype(np.float32) * c).astype(np.float32), bf16), bf16).astype(np.float64)
@@ -185,7 +199,7 @@ def dense(q, k, v, causal, scale=None, bf16=False, row0=0, pre=False):
 def check(Nq, Nkv, qblk, causal, bf16=False, seed=0, kind="randn", spike=False, verbose=True):
     rng = np.random.default_rng(seed)
     mk = (lambda s: rng.standard_normal(s)) if kind == "randn" else (lambda s: rng.random(s))
-    q, k, v = mk((Nq, 128)), mk((Nkv, 128)), mk((Nkv, 128))
+    q, k, v = mk((Nq, HD)), mk((Nkv, HD)), mk((Nkv, HD))
     if spike:
         q *= 3
         k *= 3

@@ -17,7 +17,7 @@ for v in sys.argv[1:]:
     for path in glob.glob("gpurun_out/clk/%s/**/*counter_collection.csv" % v, recursive=True):
         for r in csv.DictReader(open(path)):
             name, dur = kt.get(r["Dispatch_Id"], ("", 0))
-            if ("fwd_d128_kernel" in name or "fwd_kernel" in name) and dur > 150000:
+            if ("fwd_asm_kernel" in name or "fwd_kernel" in name) and dur > 150000:
                 acc[r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     if not acc:
         print(v, "no data"); continue

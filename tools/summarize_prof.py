@@ -30,7 +30,7 @@ for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), rec
 print("== PMC per launch, attention kernel only ==")
 acc = defaultdict(lambda: [0.0, 0])
 for path, r in rows("pmc_*/**/*counter_collection.csv"):
-    if "fwd_kernel" not in r.get("Kernel_Name", "") and "fwd_d128_kernel" not in r.get("Kernel_Name", ""):
+    if "fwd_kernel" not in r.get("Kernel_Name", "") and "fwd_asm_kernel" not in r.get("Kernel_Name", ""):
         continue
     name = r.get("Counter_Name")
     val = float(r.get("Counter_Value", 0) or 0)

@@ -89,6 +89,41 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     }
 }
 
+// Head dims above 256 (kernel head dim 512, the SD VAE attention block): 4-wave workgroups of 128 rows, one wave per SIMD with the 512-register
+// budget, single LDS stage; every workgroup produces a 128-column slab of its output (grid.y = 4) and recomputes S (and dP) over the whole
+// head dim.  Three launches: dQ (+ delta), dV, dK.  A correct path for a rare shape, not a tuned one.
+template <bool CAUSAL>
+int launch_bwd_512(fa2::BwdParams p, int parts, hipStream_t stream) {
+    constexpr int HD = 512, HDV = 128, NW = 4, kRows = NW * 32;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB, TILEBV = fa2::Geo<HDV, NW>::TILEB;
+    int rc;
+    if (parts & 1) {
+        constexpr int lds = 2 * TILEB + TILEBV;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HDV>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        p.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    if (!(parts & 2)) return 0;
+    p.nblk = (p.Nkv + kRows - 1) / kRows;
+    {
+        constexpr int lds = TILEB + TILEBV + 512;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HDV>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    {
+        constexpr int lds = 2 * TILEB + TILEBV + 512;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HDV>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    return 0;
+}
+
 template <int HD>
 int launch_bwd(const fa2::BwdParams& p, bool causal, int parts, hipStream_t stream) {
     return causal ? launch_bwd_t<HD, true>(p, parts, stream) : launch_bwd_t<HD, false>(p, parts, stream);
@@ -107,6 +142,7 @@ int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipSt
         case 64: return launch_bwd<64>(p, causal, parts, stream);
         case 128: return launch_bwd<128>(p, causal, parts, stream);
         case 256: return launch_bwd<256>(p, causal, parts, stream);
+        case 512: return causal ? launch_bwd_512<true>(p, parts, stream) : launch_bwd_512<false>(p, parts, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
 }

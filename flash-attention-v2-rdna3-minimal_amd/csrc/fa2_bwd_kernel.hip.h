@@ -98,7 +98,7 @@ struct BwdLane {
     uint32_t r_src[NPASS];       // DMA source byte offset (minus row pitch term) for a row-form image
     uint32_t t_src[NPASS];       // ... for a tr-form image
     int rowi[NPASS];             // tile row this lane's DMA piece belongs to
-    __device__ __forceinline__ void init(int tid, int lane, int D) {
+    __device__ __forceinline__ void init(int tid, int lane, int D, int col0 = 0) {      // col0: first column of the slab a "tr" image holds
         const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kr_off[ks] = G_::k_off(l31, 2 * ks + hi);
@@ -114,14 +114,14 @@ struct BwdLane {
             const int gr = slot ^ ((row / G_::RPB) & G_::KMASK);                                  // source granules
             const int gt = ((((slot >> 2) ^ ((row / G_::RPB) & G_::VMASK))) << 2) | (slot & 3);
             r_src[i] = gr * 8 < D ? gr * 16 : kOobOffset;       // columns >= D: out of range for the descriptor -> zeros
-            t_src[i] = gt * 8 < D ? gt * 16 : kOobOffset;
+            t_src[i] = col0 + gt * 8 < D ? col0 * 2 + gt * 16 : kOobOffset;
         }
     }
 };
 
 // 16-bit store of an O^T-layout accumulator (lane = column n = lane & 31, rows d) to row-major [n][d] memory
 template <bool BF16, int DT>
-__device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* rowp, int hi, float mul, int D) {
+__device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* rowp, int hi, float mul, int D, int col0 = 0) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -134,7 +134,7 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
             auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
             auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             const u32x4 w = {x0[0], x1[0], x0[1], x1[1]};
-            if (32 * dt + 8 * (r4 + hi) < D) *(u32x4*)(rowp + 32 * dt + 8 * (r4 + hi)) = w;
+            if (col0 + 32 * dt + 8 * (r4 + hi) < D) *(u32x4*)(rowp + col0 + 32 * dt + 8 * (r4 + hi)) = w;
         }
     }
 }
@@ -145,13 +145,19 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // NW = 8: two waves per SIMD, 256 VGPRs, two LDS stages (D <= 128).  NW = 4 (D = 256): one wave per SIMD with the
 // 512-register budget, 128 rows per workgroup, ONE LDS stage (three 32-KiB images do not fit twice) — a correct, simple
 // path for the rare large head dim (SD1.5's D = 160), not a tuned one.
-template <int HD, bool BF16, bool CAUSAL, int NW = 8>
+// HDV < HD (head dims above 256, HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dQ — S and dP are contracted over
+// the whole head dim (Q / dO fragments of all HD columns in registers: the 512-register budget of one wave per SIMD), only the K^T image
+// and the accumulator are slab-sized; every slab recomputes S and dP (a correct path for the SD-VAE-sized head dim, not a tuned one).
+template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_dq_kernel(const BwdParams p) {
     using L_ = BwdLane<HD, NW>;
+    using LV_ = BwdLane<HDV, NW>;             // geometry of the transposed-read image (the slab)
     constexpr int kRows = NW * 32;            // rows per workgroup (p.nblk = ceil(N / kRows))
     constexpr bool DBUF = NW == 8 || HD <= 128;   // (NW = 4 at head dims <= 128: the small-grid shape, 128 Q rows per workgroup, 256 registers, two stages)
-    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
-    constexpr int STAGEB = 3 * TILEB;
+    constexpr int NPASS = L_::NPASS, KS = L_::KS, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NPASSV = LV_::NPASS, DT = LV_::DT, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    constexpr int STAGEB = 2 * TILEB + TILEBV;
+    const int vcol0 = HDV == HD ? 0 : blockIdx.y * HDV;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const lds_char_ptr smem = (lds_char_ptr)smem_generic;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -172,6 +178,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
 
     L_ ln;
     ln.init(tid, lane, p.D);
+    LV_ lnv;                                  // (the same object when the slab is the whole head dim)
+    if constexpr (HDV != HD) lnv.init(tid, lane, p.D, vcol0);
     u32x4 qf[KS], gf[KS];
     {
         const uint16_t* qp = (const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1] + (int64_t)qr * p.qs[2];
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
             if (16 * ks + 8 * hi < p.D) part += dot8<BF16>(*(const u32x4*)(orow + 16 * ks + 8 * hi), gf[ks]);
         }
         Dq = half_swap_sum(part);
-        if (hi == 0 && qrow < p.Nq) p.delta[b * p.ls[0] + h * p.ls[1] + qrow] = Dq;
+        if (hi == 0 && qrow < p.Nq && vcol0 == 0) p.delta[b * p.ls[0] + h * p.ls[1] + qrow] = Dq;
     }
 
     const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
@@ -241,7 +249,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
                 const uint32_t vrow = (uint32_t)(tile * kKvTile + ln.rowi[i]) * v_rowb;
                 dma16_to_lds3(krs, dst, krow + ln.r_src[i], 0);
                 dma16_to_lds3(vrs, dst + TILEB, vrow + ln.r_src[i], 0);
-                dma16_to_lds3(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+                if constexpr (HDV == HD) dma16_to_lds3(krs, dst + 2 * TILEB, krow + ln.t_src[i], 0);
+            }
+        }
+        if constexpr (HDV != HD) {            // the slab's K^T image has its own (narrower) geometry
+#pragma unroll
+            for (int i = 0; i < NPASSV; ++i) {
+                const lds_char_ptr dst = base + 2 * TILEB + (wave * 64 + NW * 64 * i) * 16;
+                dma16_to_lds3(krs, dst, (uint32_t)(tile * kKvTile + lnv.rowi[i]) * k_rowb + lnv.t_src[i], 0);
             }
         }
     };
@@ -316,9 +331,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
             for (int ks = 0; ks < 4; ++ks)                         // dQ^T += K^T dS^T
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const lds_char_ptr va = kT3 + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const lds_char_ptr va = kT3 + (HDV == HD ? ln.vr_off[dt % L_::DT] : lnv.vr_off[dt]) + 16 * ks * ROWBV;
                     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
-                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWBV)));
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, df[ks], acc[dt]);
                 }
         }
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
     }
     if (qrow < p.Nq) {
         uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, scale, p.D);
+        store_acc_t<BF16, DT>(acc, op, hi, scale, p.D, vcol0);
     }
 }
 
@@ -344,15 +359,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
 // LDS per stage: Q row-form | (dK: dO row-form | Q tr-form)  (dV: dO tr-form) | L[64] | D[64]; two stages.
 // BOTH (WANT_DK and D = 64, where two accumulators fit): dK and dV in one sweep — S and P are formed once, the stage
 // additionally carries dO in tr-form (Q row | dO row | Q tr | dO tr).
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false>
+// HDV < HD (HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dK / dV; S (and dP) are contracted over the whole head
+// dim, only the transposed-read image and the accumulator are slab-sized (see bwd_dq_kernel).
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
     static_assert(!BOTH || WANT_DK, "the fused pass is the dK pass plus a dV accumulator");
+    static_assert(!BOTH || HDV == HD, "slabs exist for the separate passes only");
     using L_ = BwdLane<HD, NW>;
+    using LV_ = BwdLane<HDV, NW>;
     constexpr int kRows = NW * 32;
     constexpr bool DBUF = NW == 8;
-    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
-    constexpr int NT = BOTH ? 4 : WANT_DK ? 3 : 2;
-    constexpr int STAGEB = NT * TILEB + 512;
+    constexpr int NPASS = L_::NPASS, KS = L_::KS, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NPASSV = LV_::NPASS, DT = LV_::DT, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    constexpr int NT = BOTH ? 4 : WANT_DK ? 3 : 2;                 // images per stage; the last one is the transposed-read image
+    constexpr int TROFF = (NT - 1) * TILEB;                        // ... which starts here (BOTH: Q tr at 2, dO tr at 3 tiles)
+    constexpr int LOFF = HDV == HD ? NT * TILEB : TROFF + TILEBV;   // L | D values of the tile
+    constexpr int STAGEB = LOFF + 512;
+    const int vcol0 = HDV == HD ? 0 : blockIdx.y * HDV;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const lds_char_ptr smem = (lds_char_ptr)smem_generic;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -373,6 +396,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
 
     L_ ln;
     ln.init(tid, lane, p.D);
+    LV_ lnv;
+    if constexpr (HDV != HD) lnv.init(tid, lane, p.D, vcol0);
     u32x4 kf[KS], vf[WANT_DK ? KS : 1];
     {
         const uint16_t* kp = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1] + (int64_t)kr * p.ks[2];
@@ -431,15 +456,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                 dma16_to_lds3(qrs, dst, qrow_b + ln.r_src[i], 0);
                 if constexpr (WANT_DK) {
                     dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);
-                    dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);
+                    if constexpr (HDV == HD) dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);
                 } else {
-                    dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);
+                    if constexpr (HDV == HD) dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);
                 }
             }
         }
+        if constexpr (HDV != HD) {            // the slab's transposed-read image (Q for dK, dO for dV) has its own geometry
+#pragma unroll
+            for (int i = 0; i < NPASSV; ++i) {
+                const lds_char_ptr dst = base + TROFF + (wave * 64 + NW * 64 * i) * 16;
+                if constexpr (WANT_DK) dma16_to_lds3(qrs, dst, (uint32_t)(tile * kKvTile + lnv.rowi[i]) * q_rowb + lnv.t_src[i], 0);
+                else dma16_to_lds3(grs, dst, (uint32_t)(tile * kKvTile + lnv.rowi[i]) * g_rowb + lnv.t_src[i], 0);
+            }
+        }
         const uint32_t lsoff = (uint32_t)tile * kKvTile * 4u;
-        if (wave == 0) dma4_to_lds(lrs, base + NT * TILEB, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
-        if (WANT_DK && wave == 1) dma4_to_lds(drs, base + NT * TILEB + 256, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
+        if (wave == 0) dma4_to_lds(lrs, base + LOFF, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
+        if (WANT_DK && wave == 1) dma4_to_lds(drs, base + LOFF + 256, FA2_TILE_OFF((uint32_t)lane * 4u, lsoff));
     };
 
     f32x16 acc[DT], accv[BOTH ? DT : 1];
@@ -455,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {       // one body: see bwd_dq_kernel
         {
             const lds_char_ptr qR = smem + st * STAGEB;
-            const lds_char_ptr lt = qR + NT * TILEB;
+            const lds_char_ptr lt = qR + LOFF;
             f32x16 s0, s1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -545,9 +578,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
             for (int ks = 0; ks < 4; ++ks)                         // dK^T += Q^T dS   /   dV^T += dO^T P
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const lds_char_ptr va = tT + ln.vr_off[dt] + 16 * ks * ROWB;
+                    const lds_char_ptr va = tT + (HDV == HD ? ln.vr_off[dt % L_::DT] : lnv.vr_off[dt]) + 16 * ks * ROWBV;
                     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va)));
-                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB)));
+                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWBV)));
                     acc[dt] = mfma16<BF16>((u32x4){lo[0], lo[1], h2[0], h2[1]}, xf[ks], acc[dt]);
                 }
         }
@@ -565,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     if (kvrow < p.Nkv) {
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
                                : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
-        store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f, p.D);
+        store_acc_t<BF16, DT>(acc, op, hi, WANT_DK ? scale : 1.0f, p.D, vcol0);
         if constexpr (BOTH) {
             uint16_t* ov = (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
             store_acc_t<BF16, DT>(accv, ov, hi, 1.0f, p.D);

@@ -55,7 +55,7 @@ int device_cus() {
 namespace {
 
 constexpr int kHeadDims[] = {64, 128, 256, 512};
-constexpr int kMaxBwdHeadDim = 256;   // the backward kernels stop here
+constexpr int kMaxBwdHeadDim = 512;   // like the forward (above 256: slab kernels, bwd_hip.cpp)
 constexpr int kNumHeadDims = sizeof(kHeadDims) / sizeof(kHeadDims[0]);
 constexpr int kFwdRows = 256;         // Q rows per forward workgroup of the default shapes
 

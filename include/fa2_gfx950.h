@@ -30,7 +30,7 @@
  *   ("permute_NH", kernel_fp16.cu:328-333) layout is the same call with the head and row strides
  *   of the [B,N,H,D] tensor: strides = {N*H*D, D, H*D}.
  *   All base pointers must be 16-byte aligned and every stride a multiple of 8 elements.
- *   D is any multiple of 8 up to the largest kernel head dim (512 forward, 256 backward): the call runs on the
+ *   D is any multiple of 8 up to the largest kernel head dim (512, forward and backward): the call runs on the
  *   kernel of fa2_padded_head_dim(D) and columns >= D are masked in-kernel — read as zero, never stored — where
  *   the reference zero-pads D on the host (kernel_fp16.cu:763, :767-779).  One head's matrix must stay below 2 GiB.
  *
@@ -133,8 +133,8 @@ int fa2_fwd_bias(int dtype,
  * three above (dQ, dV, dK); deterministic: every output element has one owner — the
  * reference's dQ is an unsynchronised read-modify-write across KV blocks (kernel_fp16.cu:736).
  * Gradients are those of O = softmax(scale * Q K^T [+ causal mask]) V, i.e. what torch autograd returns.
- * Head dims: multiples of 8 up to 256 (the forward reaches 512; above 256 the backward returns FA2_ERR_HEAD_DIM).  D > 128 runs
- * 4-wave, single-LDS-stage kernels: correct, not tuned.
+ * Head dims: multiples of 8 up to 512, like the forward.  D > 128 runs 4-wave, single-LDS-stage kernels, D > 256 as 128-column slabs of
+ * the outputs that recompute S and dP per slab (three launches): correct, not tuned.
  */
 int fa2_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                 void* dq, void* dk, void* dv, float* delta_ws,

@@ -181,13 +181,31 @@ def test_full_size_config3_backward_sampled_heads():
     assert float((grads[2][:, :, -1].float() - want).abs().max()) <= 1.6e-2 * max(1.0, float(want.abs().max()))
 
 
-def test_backward_above_256_is_refused_not_wrong():
-    """The forward reaches D = 512; the backward kernels stop at 256 and say so (FA2_ERR_HEAD_DIM) instead of computing
-    something else.  (The reference's LoRA-training use, README.md:151-154, is on SD1.5/SDXL UNet attention: D <= 160.)"""
-    q, k, v = (torch.randn((1, 1, 64, 320), device=_dev(), dtype=torch.float16, requires_grad=True) for _ in range(3))
-    o = FlashAttentionFunction.apply(q, k, v, None, False)
-    with pytest.raises(RuntimeError, match="head dim"):
-        o.backward(torch.ones_like(o))
+@pytest.mark.parametrize("D", [264, 320, 384, 512])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_backward_head_dims_above_256(D, dt):
+    """Head dims above 256 (the forward reaches 512: the SD VAE attention block, the reference's D > 384 case, FlashAttn.py:65-67) run the
+    slab kernels: 128-column slabs of dQ / dK / dV per workgroup, S and dP recomputed per slab over the whole head dim — so that
+    o.backward() works on everything the forward accepts (reference: backward_fp16 pads D like the forward, kernel_fp16.cu:878-1028)."""
+    g = torch.Generator(device="cpu").manual_seed(300 + D)
+    mk = lambda n: (torch.randn((1, 2, n, D), generator=g) * 0.5).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(130), mk(203), mk(203), mk(130)
+    for causal in (False, True):
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+
+
+def test_autograd_at_head_dim_512_matches_torch():
+    """o.backward() through FlashAttentionFunction at the VAE-sized head dim against float64 autograd of the dense formula."""
+    g = torch.Generator(device="cpu").manual_seed(512)
+    q, k, v, do = (torch.randn((1, 1, 160, 512), generator=g) * 0.3 for _ in range(4))
+    qd, kd, vd = (t.half().to(_dev()).requires_grad_(True) for t in (q, k, v))
+    o = FlashAttentionFunction.apply(qd, kd, vd, None, False)
+    o.backward(do.half().to(_dev()))
+    want = grads_truth(q.half().double().numpy(), k.half().double().numpy(), v.half().double().numpy(), do.half().double().numpy(), False)
+    for name, got, w in zip("qkv", (qd.grad, kd.grad, vd.grad), want):
+        err = float(np.abs(got.float().cpu().numpy() - w).max())
+        assert err <= 2 * GRAD_TOL[0] * max(1.0, float(np.abs(w).max())), (name, err)
 
 
 PAIR_SHAPES = [(1, 2, 129, 127, 128), (2, 3, 200, 333, 96), (1, 8, 640, 640, 128), (1, 1, 64, 700, 72), (2, 2, 513, 255, 120)]

@@ -40,6 +40,8 @@ UNITS = [
     ("bwd_hip_f16", "bwd_hip.cpp", ["-DFA2_TU_BF16=0"]),
     ("bwd_hip_bf16", "bwd_hip.cpp", ["-DFA2_TU_BF16=1"]),
     ("bwd_asm", "bwd_asm.cpp", []),
+    ("bwd_bias_hip_f16", "bwd_bias_hip.cpp", ["-DFA2_TU_BF16=0"]),
+    ("bwd_bias_hip_bf16", "bwd_bias_hip.cpp", ["-DFA2_TU_BF16=1"]),
 ]
 FRONTEND_SRC = "frontend.cpp"                      # optional compiled front end of the operator (host-only C++, g++)
 FRONTEND_PATH = os.path.join(PKG_DIR, "rocwmma_fattn", "_fa2_frontend.so")

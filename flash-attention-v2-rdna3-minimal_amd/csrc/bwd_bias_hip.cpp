@@ -1,0 +1,70 @@
+// bwd_bias_hip.cpp — backward through a biased / masked forward (fa2_bwd_bias) for ONE dtype: the BIAS instantiations of the
+// compiler-scheduled dQ / dV / dK passes (fa2_bwd_kernel.hip.h), three launches.  build.py compiles this file twice (-DFA2_TU_BF16=0 / 1).
+// The reference has no counterpart: its `mask` argument is accepted and ignored (FlashAttn.py:49, :74; README.md:45 "to do").
+#include "fa2_launch.h"
+
+#include "fa2_gfx950.h"
+
+#ifndef FA2_TU_BF16
+#error "compile with -DFA2_TU_BF16=0 or 1"
+#endif
+
+namespace {
+
+constexpr bool kBF16 = FA2_TU_BF16 != 0;
+
+template <int HD, bool CAUSAL>
+int launch_t(fa2::BwdParams p, hipStream_t stream) {
+    constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
+    constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
+    int rc;
+    {
+        constexpr int lds = kStages * 3 * TILEB;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HD, true>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        p.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    p.nblk = (p.Nkv + kRows - 1) / kRows;
+    {
+        constexpr int lds = kStages * (2 * TILEB + 512);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HD, true>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    {
+        constexpr int lds = kStages * (3 * TILEB + 512);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HD, true>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    return 0;
+}
+
+template <int HD>
+int launch_hd(const fa2::BwdParams& p, bool causal, hipStream_t stream) {
+    return causal ? launch_t<HD, true>(p, stream) : launch_t<HD, false>(p, stream);
+}
+
+}  // namespace
+
+namespace fa2 {
+
+#if FA2_TU_BF16
+int launch_bwd_bias_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+#else
+int launch_bwd_bias_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream) {
+#endif
+    switch (HD) {
+        case 64: return launch_hd<64>(p, causal, stream);
+        case 128: return launch_hd<128>(p, causal, stream);
+        case 256: return launch_hd<256>(p, causal, stream);
+        default: return FA2_ERR_HEAD_DIM;       // (the slab kernels of head dims above 256 have no bias form)
+    }
+}
+
+}  // namespace fa2

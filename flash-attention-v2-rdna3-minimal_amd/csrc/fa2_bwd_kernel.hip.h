@@ -44,7 +44,25 @@ struct BwdParams {
     float scale, c;                                                      // scale, scale * log2(e)
     int nblk;                                                            // row blocks (of 256) of the swept-over owner
     uint32_t q_bytes, k_bytes, v_bytes, do_bytes, l_bytes;               // addressable bytes of one head's matrices
+    // attention bias / boolean mask of a biased forward (BIAS kernels only; fa2_bwd_bias): as FwdParams::bias / bs / bias_kind
+    const void* bias;
+    int64_t bs[3];
+    int bias_kind;
 };
+
+// log2-domain bias term of score (q, kv) of head (b, h): bias * log2(e), or -inf where a boolean keep-mask is zero.  One guarded load per
+// element (the bias may be broadcast with zero strides and have any alignment): a correct path for the SD hosts' masks, not a tuned one.
+template <bool BF16>
+__device__ __forceinline__ float bwd_bias_term(const BwdParams& p, int b, int h, int q, int kv) {
+    const int64_t idx = b * p.bs[0] + h * p.bs[1] + (int64_t)q * p.bs[2] + kv;
+    if (p.bias_kind == 1) {
+        const uint16_t raw = ((const uint16_t*)p.bias)[idx];
+        const float f = BF16 ? __uint_as_float((uint32_t)raw << 16) : (float)__builtin_bit_cast(_Float16, raw);
+        return f * 1.4426950408889634f;
+    }
+    if (p.bias_kind == 2) return ((const float*)p.bias)[idx] * 1.4426950408889634f;
+    return ((const uint8_t*)p.bias)[idx] ? 0.f : -__builtin_inff();
+}
 
 // The backward kernels address LDS through address-space-3 pointers only (no generic pointers into LDS): besides
 // sparing the aperture checks, this avoids a hipcc 7.2 miscompile of the generic<->LDS casts in the 4-wave kernels
@@ -148,7 +166,8 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // HDV < HD (head dims above 256, HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dQ — S and dP are contracted over
 // the whole head dim (Q / dO fragments of all HD columns in registers: the 512-register budget of one wave per SIMD), only the K^T image
 // and the accumulator are slab-sized; every slab recomputes S and dP (a correct path for the SD-VAE-sized head dim, not a tuned one).
-template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD>
+// BIAS: the forward was fa2_fwd_bias — P = 2^(S c + bias log2e - L); a fully masked row (L = -inf) has P = 0.
+template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_dq_kernel(const BwdParams p) {
     using L_ = BwdLane<HD, NW>;
     using LV_ = BwdLane<HDV, NW>;             // geometry of the transposed-read image (the slab)
@@ -191,7 +210,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
             gf[ks] = in ? *(const u32x4*)(gp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
         }
     }
-    const float Lq = p.lse[b * p.ls[0] + h * p.ls[1] + qr];
+    float Lq = p.lse[b * p.ls[0] + h * p.ls[1] + qr];
+    if (BIAS && Lq == -__builtin_inff()) Lq = __builtin_inff();        // fully masked row: every P below becomes 2^(-inf) = 0
     // D_i = sum_d dO[i,d] * O[i,d] (the reference's `Di`, kernel_fp16.cu:605-631) for the lane's own row, from the dO
     // fragments already in registers; stored to the delta workspace for the dK pass that follows on the stream.
     float Dq;
@@ -294,8 +314,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
             // P^T = 2^(S^T c - L); masked entries -> 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -Lq));
-                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -Lq));
+                float b0 = -Lq, b1 = -Lq;
+                if constexpr (BIAS) {
+                    const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kvi < p.Nkv) b0 += bwd_bias_term<BF16>(p, b, h, qr, kvi);
+                    if (kvi + 32 < p.Nkv) b1 += bwd_bias_term<BF16>(p, b, h, qr, kvi + 32);
+                }
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
             }
             if (masked) {
 #pragma unroll
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
 // additionally carries dO in tr-form (Q row | dO row | Q tr | dO tr).
 // HDV < HD (HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dK / dV; S (and dP) are contracted over the whole head
 // dim, only the transposed-read image and the accumulator are slab-sized (see bwd_dq_kernel).
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD>
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
     static_assert(!BOTH || WANT_DK, "the fused pass is the dK pass plus a dV accumulator");
     static_assert(!BOTH || HDV == HD, "slabs exist for the separate passes only");
@@ -518,8 +544,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -L0[e]));
-                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -L1[e]));
+                    float b0 = -L0[e], b1 = -L1[e];
+                    if constexpr (BIAS) {        // (a fully masked row, L = -inf: P = 0)
+                        const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        b0 = L0[e] == -__builtin_inff() ? -__builtin_inff() : b0 + (qi < p.Nq ? bwd_bias_term<BF16>(p, b, h, qi, kr) : 0.f);
+                        b1 = L1[e] == -__builtin_inff() ? -__builtin_inff() : b1 + (qi + 32 < p.Nq ? bwd_bias_term<BF16>(p, b, h, qi + 32, kr) : 0.f);
+                    }
+                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
+                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
                 }
             }
             if (CAUSAL && masked) {               // causal: pairs with kv > q contribute nothing (wave-uniform branch)

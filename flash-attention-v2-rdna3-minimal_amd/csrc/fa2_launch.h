@@ -48,6 +48,9 @@ FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// HIP backward through a biased / masked forward (bwd_bias_hip.cpp): dQ, dV, dK; head dims up to 256
+FA2_HIDDEN int launch_bwd_bias_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
+FA2_HIDDEN int launch_bwd_bias_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
 // hand-scheduled backward, head dim exactly 128 (bwd_asm.cpp); same `parts`
 // neg_delta: the dQ pass writes -delta (the hand-scheduled dK/dV pass reads it as such; the HIP dK/dV passes read +delta)
 FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, hipStream_t stream);

@@ -318,12 +318,19 @@ int fa2_fwd_bias(int dtype, const void* q, const void* k, const void* v, void* o
                     scale, causal, bias, bias_kind, bias_strides, hip_stream);
 }
 
-int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+static int bwd_impl(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
             void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
             const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
             const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
-            int causal, void* hip_stream) {
+            int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
+    if (bias_kind != FA2_BIAS_NONE) {
+        if (bias_kind != FA2_BIAS_IO_DTYPE && bias_kind != FA2_BIAS_F32 && bias_kind != FA2_BIAS_BOOL) return FA2_ERR_BIAS;
+        if (!bias || !bias_strides) return FA2_ERR_NULL_POINTER;
+        if (bias_strides[0] < 0 || bias_strides[1] < 0 || bias_strides[2] < 0) return FA2_ERR_BIAS;
+        const uintptr_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1;
+        if (reinterpret_cast<uintptr_t>(bias) % esize) return FA2_ERR_ALIGNMENT;
+    }
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !delta_ws || !q_strides || !k_strides ||
         !v_strides || !o_strides || !do_strides || !dq_strides || !dk_strides || !dv_strides || !lse_strides)
         return FA2_ERR_NULL_POINTER;
@@ -358,9 +365,34 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
     p.nblk = 0;
     p.q_bytes = (uint32_t)q_bytes; p.k_bytes = (uint32_t)k_bytes; p.v_bytes = (uint32_t)v_bytes;
     p.do_bytes = (uint32_t)do_bytes; p.l_bytes = (uint32_t)Nq * 4u;
+    p.bias = bias;
+    p.bias_kind = bias_kind;
+    for (int i = 0; i < 3; ++i) p.bs[i] = bias_kind != FA2_BIAS_NONE ? bias_strides[i] : 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool bf16 = dtype == FA2_DTYPE_BF16;
+    if (bias_kind != FA2_BIAS_NONE)
+        return bf16 ? fa2::launch_bwd_bias_hip_bf16(HD, p, causal != 0, stream) : fa2::launch_bwd_bias_hip_f16(HD, p, causal != 0, stream);
     return launch_bwd(HD, bf16, p, causal != 0, stream);
+}
+
+int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+            void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
+            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+            const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+            const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
+            int causal, void* hip_stream) {
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,
+                    do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream);
+}
+
+int fa2_bwd_bias(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                 const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                 const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
+                 int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,
+                    do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, bias, bias_kind, bias_strides, hip_stream);
 }
 
 #define FA2_BWD_ARGS                                                                                                    \

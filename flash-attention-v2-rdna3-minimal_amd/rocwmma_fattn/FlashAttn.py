@@ -138,7 +138,7 @@ class _FlashAttnWmma:
         return [O_fwd, q_pad, k_pad, v_pad, O, L]
 
     @staticmethod
-    def backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH):
+    def backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH, bias=None):
         """Returns [dQ, dK, dV] sliced to the actual sizes, like backward_fp16/backward_bf16
         (host.cpp:47-58, kernel_fp16.cu:878-1028).  Q, K, V, O, L are the tensors the forward returned
         (D a multiple of 8); the gfx950 kernels take the actual Nq / Nkv / D and mask in-kernel, so nothing is
@@ -170,12 +170,18 @@ class _FlashAttnWmma:
         args = (dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr(),
                 dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), delta.data_ptr(), b, h, act_n, act_nkv, dk,
                 s3(Q), s3(K), s3(V), s3(O), s3(dO), s3(dQ), s3(dK), s3(dV),
-                _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0, stream)
+                _fa2_lib.strides2(L.stride(0), L.stride(1)), float(scale), 1 if causal else 0)
+        fn = lib.fa2_bwd
+        if bias is not None:         # backward through forward_bias (extension, like the masked forward itself): same bias arguments
+            bias_t, kind, bstr = _prepare_bias(bias, b, h, act_n, act_nkv, Q.dtype, Q.device)
+            args += (bias_t.data_ptr(), kind, _fa2_lib.strides3(*bstr))
+            fn = lib.fa2_bwd_bias
+        args += (stream,)
         if Q.device.index != _current_device():
             with torch.cuda.device(Q.device):
-                rc = lib.fa2_bwd(*args)
+                rc = fn(*args)
         else:
-            rc = lib.fa2_bwd(*args)
+            rc = fn(*args)
         if rc:
             _fa2_lib.check(rc)
         if permute_NH:
@@ -320,18 +326,43 @@ def _apply(q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, *
 FlashAttentionFunction.apply = staticmethod(_apply)
 
 
+class _MaskedAttentionFunction(torch.autograd.Function):
+    """autograd node of flash_attention(mask=...): forward = fa2_fwd_bias, backward = fa2_bwd_bias (the mask is a constant: no gradient)."""
+
+    @staticmethod
+    @torch.no_grad()
+    def forward(ctx, q, k, v, mask, causal, scale, BNHD_fmt):
+        D = q.shape[3]
+        Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67
+        o, q_bwd, k_bwd, v_bwd, o_bwd, L = flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)
+        n_ax = 1 if BNHD_fmt else 2
+        ctx.args = (causal, scale, q.shape[n_ax], k.shape[n_ax], D, BNHD_fmt)
+        ctx.save_for_backward(q_bwd, k_bwd, v_bwd, o_bwd, L, mask)
+        return o
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, do):
+        causal, scale, N, Nkv, D, BNHD_fmt = ctx.args
+        q, k, v, o, L, mask = ctx.saved_tensors
+        dQ, dK, dV = flash_attn_wmma.backward(q, k, v, o, do, L, N, Nkv, D, 128, 128, causal, scale, BNHD_fmt, bias=mask)
+        return dQ, dK, dV, None, None, None, None
+
+
 def flash_attention(q, k, v, mask=None, causal=False, scale=None, BNHD_fmt=False):
     """Forward attention that HONOURS `mask` — the extension the reference lists as to do (README.md:45; its
     FlashAttentionFunction accepts the argument and ignores it, FlashAttn.py:49, :74, and `FlashAttentionFunction.apply` here
     keeps doing exactly that so that existing call sites see no change).  `mask` follows
     torch.nn.functional.scaled_dot_product_attention(attn_mask=...): broadcastable to [B, H, Nq, Nkv]; bool = True where
     attention is allowed, float = added to the scaled scores.  mask=None is FlashAttentionFunction.apply.  Rows whose every
-    position is masked return zeros.  Forward only: inputs that require a gradient are refused when a mask is given."""
+    position is masked return zeros.  Differentiable in q, k, v (C-ABI fa2_bwd_bias; head dims up to 256); the mask gets no gradient."""
     if mask is None:
         return FlashAttentionFunction.apply(q, k, v, None, causal, scale, BNHD_fmt)
-    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-        raise NotImplementedError("fa2: no backward through a masked / biased forward (the backward kernels recompute unbiased scores)")
     D = q.shape[3]
+    if scale is None:
+        scale = D ** -0.5
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _MaskedAttentionFunction.apply(q, k, v, mask, causal, scale, BNHD_fmt)
     if scale is None:
         scale = D ** -0.5
     Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67

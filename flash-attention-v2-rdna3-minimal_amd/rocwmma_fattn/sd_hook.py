@@ -30,9 +30,9 @@ def attention_bnhd(q, k, v, heads, mask=None, causal=False, scale=None, fallback
     """q [B, Nq, heads*D], k, v [B, Nkv, heads*D] (any float dtype; non-half inputs run and return as bf16,
     host.cpp:42-45) -> [B, Nq, heads*D].  `mask`: None, or a bool keep-mask / additive float bias of shape [Nq, Nkv],
     [B, Nq, Nkv] or [B, H | 1, Nq, Nkv].  `fallback(q, k, v, heads, mask)` is used when the head dim exceeds the largest
-    kernel, when a masked call needs a gradient (the masked forward has no backward: LoRA training through a masked
-    cross-attention goes to the host's own attention) and when the mask does not broadcast to [B, H, Nq, Nkv]; without a
-    fallback those cases raise."""
+    kernel, when a masked call needs a gradient at a head dim above 256 (the masked backward stops there) and when the mask does not
+    broadcast to [B, H, Nq, Nkv]; without a fallback those cases raise.  (LoRA training through a masked cross-attention — head dims
+    40..160 — runs the kernels: fa2_fwd_bias / fa2_bwd_bias.)"""
     b, nq, inner = q.shape
     d = inner // heads
     if d > _MAX_HEAD_DIM or inner != heads * d:
@@ -41,7 +41,7 @@ def attention_bnhd(q, k, v, heads, mask=None, causal=False, scale=None, fallback
         return fallback(q, k, v, heads, mask)
     if mask is not None and fallback is not None:
         needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
-        if needs_grad or not _mask_broadcasts(mask, b, heads, nq, k.shape[1]):
+        if (needs_grad and d > 256) or not _mask_broadcasts(mask, b, heads, nq, k.shape[1]):
             return fallback(q, k, v, heads, mask)
     if mask is not None and mask.dim() == 3:
         mask = mask.unsqueeze(1)                      # [B, Nq, Nkv] -> [B, 1, Nq, Nkv] (comfy.ldm.modules.attention reads it so)

@@ -108,7 +108,7 @@ int fa2_fwd(int dtype,
  *   causal       : may be combined with the bias (both masks apply).
  *   fully masked rows (every score -inf) produce O = 0 and lse = -inf (torch's math path returns NaN there).
  * Runs the compiler-scheduled HIP kernels as 4-wave, 128-row workgroups for every head dim (the hand-scheduled D = 128 body
- * has no bias stream).  Forward only: there is no backward through a biased forward (fa2_bwd recomputes unbiased scores).
+ * has no bias stream).  Its backward is fa2_bwd_bias (fa2_bwd recomputes unbiased scores).
  */
 int fa2_fwd_bias(int dtype,
                  const void* q, const void* k, const void* v, void* o, float* lse,
@@ -160,6 +160,23 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
             const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
             float scale, int causal, void* hip_stream);
+
+/*
+ * Backward through fa2_fwd_bias: the gradients of O = softmax(scale * Q K^T + bias [+ causal mask]) V with respect to Q, K, V (the bias /
+ * mask itself is a constant of the call: it receives no gradient).  o and lse are the outputs of the fa2_fwd_bias call with the SAME bias
+ * arguments; fully masked rows (lse = -inf) contribute nothing.  Arguments as fa2_bwd plus the bias triple of fa2_fwd_bias.
+ * Three launches of the compiler-scheduled passes (dQ, dV, dK) with one guarded bias load per score: correct, not tuned.  Head dims up
+ * to 256 (FA2_ERR_HEAD_DIM above).  The reference has no counterpart (its `mask` is ignored, FlashAttn.py:49/:74).
+ */
+int fa2_bwd_bias(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 void* dq, void* dk, void* dv, float* delta_ws,
+                 int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                 const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                 const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
+                 float scale, int causal,
+                 const void* bias, int bias_kind, const int64_t bias_strides[3],
+                 void* hip_stream);
 
 /* Head dims the forward kernels are instantiated for (ascending).  Writes up to `cap` entries into `dims`, returns
  * the total count.  Any D that is a multiple of 8 runs on the next of these with its tail columns masked; only a D

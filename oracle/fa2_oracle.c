@@ -292,12 +292,12 @@ int fa2_oracle_fwd_bias(int dtype, const uint16_t* q, const uint16_t* k, const u
  * reference kernels and the gfx950 kernels feed 16-bit operands to the matrix unit); one final rounding of
  * dQ, dK, dV.  Layouts as fa2_oracle_fwd; lse = the forward's output (log2 domain), length >= Nq per head.
  */
-int fa2_oracle_bwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* o,
+static int bwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* o,
                    const uint16_t* dout, const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv,
                    int B, int H, int Nq, int Nkv, int D,
                    const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* dos,
                    const int64_t* ls, const int64_t* dqs, const int64_t* dks, const int64_t* dvs,
-                   float scale, int causal, int flags, int nthreads) {
+                   float scale, int causal, int flags, int nthreads, const float* bias, const int64_t* bs) {
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return -1;
     if (dtype != FA2_ORACLE_DTYPE_F16 && dtype != FA2_ORACLE_DTYPE_BF16) return -1;
     const cvt_t cv = {dtype, (flags & FA2_ORACLE_BF16_TRUNC) != 0};
@@ -354,7 +354,11 @@ int fa2_oracle_bwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
                     float s = 0.f, dp = 0.f;
 #pragma omp simd reduction(+ : s, dp)
                     for (int d = 0; d < D; ++d) { s += qi[d] * kj[d]; dp += gi[d] * vj[d]; }
-                    const float p = exp2f(s * c - lb[i]);
+                    /* attention bias (fa2_bwd_bias): P = 2^(s c + bias log2e - L) with the L of the BIASED forward; a fully masked row
+                       (L = -inf) and a masked position (bias = -inf) have P = 0.  The bias itself receives no gradient. */
+                    float x = s * c;
+                    if (bias) x += bias[b * bs[0] + h * bs[1] + (int64_t)i * bs[2] + j] * 1.4426950408889634f;
+                    const float p = (lb[i] == -INFINITY || x == -INFINITY) ? 0.f : exp2f(x - lb[i]);
                     const float p16 = round16(cv, p);
                     const float ds16 = round16(cv, scale * p * (dp - delta[i]));
                     float* dvj = dva + (size_t)j * D;
@@ -380,6 +384,29 @@ int fa2_oracle_bwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16
         free(qf); free(dof); free(kf); free(vf); free(dqa); free(dka); free(dva); free(delta);
     }
     return failed ? -1 : 0;
+}
+
+int fa2_oracle_bwd(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* o,
+                   const uint16_t* dout, const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv,
+                   int B, int H, int Nq, int Nkv, int D,
+                   const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* dos,
+                   const int64_t* ls, const int64_t* dqs, const int64_t* dks, const int64_t* dvs,
+                   float scale, int causal, int flags, int nthreads) {
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, B, H, Nq, Nkv, D, qs, ks, vs, os, dos, ls, dqs, dks, dvs, scale, causal, flags,
+                    nthreads, NULL, NULL);
+}
+
+/* Backward through a biased / masked forward (the counterpart of fa2_oracle_fwd_bias; C-ABI fa2_bwd_bias).  The reference has neither
+ * (its `mask` argument is ignored, FlashAttn.py:49/:74): pinned on float64 autograd of the dense formula (tests/test_oracle.py). */
+int fa2_oracle_bwd_bias(int dtype, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* o,
+                        const uint16_t* dout, const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv,
+                        int B, int H, int Nq, int Nkv, int D,
+                        const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, const int64_t* dos,
+                        const int64_t* ls, const int64_t* dqs, const int64_t* dks, const int64_t* dvs,
+                        float scale, int causal, int flags, int nthreads, const float* bias, const int64_t* bs) {
+    if (!bias || !bs) return -1;
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, B, H, Nq, Nkv, D, qs, ks, vs, os, dos, ls, dqs, dks, dvs, scale, causal, flags,
+                    nthreads, bias, bs);
 }
 
 int fa2_oracle_max_threads(void) {

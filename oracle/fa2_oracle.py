@@ -62,6 +62,8 @@ def _load():
         lib.fa2_oracle_bwd.restype = ctypes.c_int
         lib.fa2_oracle_bwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [i64p] * 9 + \
             [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.fa2_oracle_bwd_bias.restype = ctypes.c_int
+        lib.fa2_oracle_bwd_bias.argtypes = lib.fa2_oracle_bwd.argtypes + [ctypes.c_void_p, i64p]
         lib.fa2_oracle_max_threads.restype = ctypes.c_int
         lib.fa2_oracle_f32_to_f16.restype = ctypes.c_uint16
         lib.fa2_oracle_f32_to_f16.argtypes = [ctypes.c_float]
@@ -136,9 +138,10 @@ def fwd_c(q_bits, k_bits, v_bits, dtype, causal=False, scale=None, Br=32, Bc=64,
     return o, lse
 
 
-def bwd_c(q_bits, k_bits, v_bits, o_bits, do_bits, lse, dtype, causal=False, scale=None, flags=0, nthreads=0):
-    """Backward oracle (fa2_oracle.c: fa2_oracle_bwd).  All *_bits are uint16 [B,H,N,D]; lse float32 [B,H,>=Nq]
-    in the log2 domain (the forward's output).  Returns (dq_bits, dk_bits, dv_bits)."""
+def bwd_c(q_bits, k_bits, v_bits, o_bits, do_bits, lse, dtype, causal=False, scale=None, flags=0, nthreads=0, bias=None):
+    """Backward oracle (fa2_oracle.c: fa2_oracle_bwd / fa2_oracle_bwd_bias).  All *_bits are uint16 [B,H,N,D]; lse float32 [B,H,>=Nq]
+    in the log2 domain (the forward's output); bias: None or a float array broadcastable to [B,H,Nq,Nkv] (the biased forward's).
+    Returns (dq_bits, dk_bits, dv_bits)."""
     lib = _load()
     q, k, v, o, do = (np.ascontiguousarray(t, dtype=np.uint16) for t in (q_bits, k_bits, v_bits, o_bits, do_bits))
     lse = np.ascontiguousarray(lse, dtype=np.float32)
@@ -152,28 +155,38 @@ def bwd_c(q_bits, k_bits, v_bits, o_bits, do_bits, lse, dtype, causal=False, sca
         return (ctypes.c_int64 * 3)(H * n * D, n * D, D)
 
     ls = (ctypes.c_int64 * 2)(H * lse.shape[2], lse.shape[2])
-    rc = lib.fa2_oracle_bwd(dtype, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, do.ctypes.data,
-                            lse.ctypes.data, dq.ctypes.data, dk.ctypes.data, dv.ctypes.data, B, H, Nq, Nkv, D,
-                            s3(Nq), s3(Nkv), s3(Nkv), s3(Nq), s3(Nq), ls, s3(Nq), s3(Nkv), s3(Nkv),
-                            float(scale), int(bool(causal)), int(flags), int(nthreads))
+    args = (dtype, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, do.ctypes.data,
+            lse.ctypes.data, dq.ctypes.data, dk.ctypes.data, dv.ctypes.data, B, H, Nq, Nkv, D,
+            s3(Nq), s3(Nkv), s3(Nkv), s3(Nq), s3(Nq), ls, s3(Nq), s3(Nkv), s3(Nkv),
+            float(scale), int(bool(causal)), int(flags), int(nthreads))
+    if bias is None:
+        rc = lib.fa2_oracle_bwd(*args)
+    else:
+        bf = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, dtype=np.float32), (B, H, Nq, Nkv)))
+        rc = lib.fa2_oracle_bwd_bias(*args, bf.ctypes.data, (ctypes.c_int64 * 3)(H * Nq * Nkv, Nq * Nkv, Nkv))
     if rc != 0:
         raise RuntimeError("fa2_oracle_bwd failed (%d)" % rc)
     return dq, dk, dv
 
 
-def bwd_numpy(q, k, v, do, causal=False, scale=None):
-    """Dense float64 gradients of O = softmax(Q K^T scale [+mask]) V contracted with dO (pure_torch_ver.py:92-153
-    without the tiling): returns (dq, dk, dv)."""
+def bwd_numpy(q, k, v, do, causal=False, scale=None, bias=None):
+    """Dense float64 gradients of O = softmax(Q K^T scale [+ bias] [+mask]) V contracted with dO (pure_torch_ver.py:92-153
+    without the tiling): returns (dq, dk, dv).  Fully masked rows (bias only) contribute nothing."""
     q, k, v, do = (np.asarray(t, dtype=np.float64) for t in (q, k, v, do))
     D = q.shape[-1]
     if scale is None:
         scale = D ** -0.5
     s = np.einsum("bhid,bhjd->bhij", q, k) * scale
+    if bias is not None:
+        s = s + np.asarray(bias, dtype=np.float64)
     if causal:
         nq, nk = s.shape[-2:]
         s = np.where(np.triu(np.ones((nq, nk), dtype=bool), 1), -np.inf, s)
-    p = np.exp(s - s.max(-1, keepdims=True))
-    p /= p.sum(-1, keepdims=True)
+    mx = s.max(-1, keepdims=True)
+    dead = ~np.isfinite(mx)
+    with np.errstate(invalid="ignore"):
+        p = np.where(dead, 0.0, np.exp(s - np.where(dead, 0.0, mx)))
+    p = p / np.where(dead, 1.0, p.sum(-1, keepdims=True))
     o = np.einsum("bhij,bhjd->bhid", p, v)
     dv = np.einsum("bhij,bhid->bhjd", p, do)
     dp = np.einsum("bhid,bhjd->bhij", do, v)

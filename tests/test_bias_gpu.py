@@ -181,8 +181,8 @@ def test_operator_flash_attention_matches_sdpa(kind):
     assert torch.equal(flash_attention(q, k, v, None), FlashAttentionFunction.apply(q, k, v, None, False))
     # the reference's operator keeps ignoring the argument (FlashAttn.py:49, :74)
     assert torch.equal(FlashAttentionFunction.apply(q, k, v, mask, False), FlashAttentionFunction.apply(q, k, v, None, False))
-    with pytest.raises(NotImplementedError):
-        flash_attention(q.clone().requires_grad_(True), k, v, mask)
+    og = flash_attention(q.clone().requires_grad_(True), k, v, mask)          # inputs that need a gradient: the autograd node, same forward
+    assert og.requires_grad and torch.equal(og.detach(), o)
     with pytest.raises(RuntimeError, match="broadcast"):
         flash_attention(q, k, v, mask[:, :, :5])
 
@@ -242,3 +242,92 @@ def test_bias_memory_past_the_row_is_never_read(nkv, dtype):
     bias = buf[..., :nkv]                                                   # row pitch 128, last dim contiguous: passed as is
     o, lse = _cabi_forward_bias(q, k, v, bias, causal=False)
     _check(o, lse, q, k, v, bias, 0, False)
+
+
+# ---------------------------------------------------------------- backward through the masked forward (fa2_bwd_bias)
+BWD_BIAS_SHAPES = [
+    # B, H, Nq, Nkv, D, bias shape: SD cross-attention key-padding mask, a dense per-head bias, ragged tiles, D = 160 (the 4-wave kernels)
+    (2, 4, 256, 77, 64, (2, 1, 1, 77)),
+    (1, 3, 130, 203, 128, (1, 3, 130, 203)),
+    (2, 2, 96, 100, 40, (2, 1, 96, 100)),
+    (1, 2, 70, 140, 160, (140,)),
+]
+
+
+@pytest.mark.parametrize("shape", BWD_BIAS_SHAPES)
+@pytest.mark.parametrize("kind", ["bool", "io", "f32"])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_masked_backward_against_oracle_and_autograd(shape, kind, dt):
+    """flash_attention(mask=...) is differentiable in q, k, v: forward fa2_fwd_bias, backward fa2_bwd_bias (three HIP passes that add the
+    bias to the recomputed scores).  Gradients against the C oracle's masked backward (same contract) and float64 autograd."""
+    from rocwmma_fattn.FlashAttn import flash_attention
+    B, H, Nq, Nkv, D, bshape = shape
+    tdt = torch.float16 if dt == 0 else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(sum(shape[:5]) + dt)
+    q, k, v, do = (torch.randn((B, H, n, D), generator=g).to(tdt) for n in (Nq, Nkv, Nkv, Nq))
+    if len(bshape) == 1:
+        bshape = (1, 1, 1) + bshape
+    if kind == "bool":
+        mask = torch.rand(bshape, generator=g) > 0.35
+        mask[..., 0] = True
+        bias_f = torch.where(mask, 0.0, float("-inf")).float()
+    else:
+        mask = (torch.randn(bshape, generator=g) * 1.5).to(tdt if kind == "io" else torch.float32)
+        bias_f = mask.float()
+    dev = torch.device("cuda", 0)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    o = flash_attention(qd, kd, vd, mask.to(dev), False)
+    o.backward(do.to(dev))
+    torch.cuda.synchronize()
+    # same-contract oracle: forward (for o, lse) and backward with the bias
+    code = dt
+    bits = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    bnp = np.broadcast_to(bias_f.numpy(), (B, H, Nq, Nkv))
+    o_bits, lse = fo.fwd_c(bits(q), bits(k), bits(v), code, False, bias=bnp)
+    want = fo.bwd_c(bits(q), bits(k), bits(v), o_bits, bits(do), lse, code, False, bias=bnp)
+    truth = fo.bwd_numpy(q.float().numpy(), k.float().numpy(), v.float().numpy(), do.float().numpy(), False, bias=bnp)
+    tol = 2e-3 if dt == 0 else 1.6e-2
+    for name, got_t, w_bits, t64 in zip("qkv", (qd.grad, kd.grad, vd.grad), want, truth):
+        got = got_t.float().cpu().numpy()
+        w = fo.bits_to_f32(w_bits, code)
+        assert np.isfinite(got).all(), name
+        assert np.abs(got - w).max() <= tol * max(1.0, np.abs(w).max()), (name, np.abs(got - w).max())
+        assert np.abs(got - t64).max() <= 2 * tol * max(1.0, np.abs(t64).max()), (name, np.abs(got - t64).max())
+
+
+def test_masked_backward_causal_fully_masked_rows_and_hook():
+    """bias + causal, a row with every key masked (zero output, zero gradients), and the SD hook's masked call with gradients
+    (BNHD layout) against torch autograd through SDPA on fp32 inputs."""
+    from rocwmma_fattn.FlashAttn import flash_attention
+    from rocwmma_fattn.sd_hook import attention_bnhd
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    B, H, N, D = 1, 2, 192, 64
+    q, k, v, do = (torch.randn((B, H, N, D), generator=g).half() for _ in range(4))
+    keep = torch.rand((B, 1, N, N), generator=g) > 0.4
+    keep[..., 0] = True
+    keep[0, 0, 7, :] = False
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    o = flash_attention(qd, kd, vd, keep.to(dev), True)
+    o.backward(do.to(dev))
+    bias = np.broadcast_to(torch.where(keep, 0.0, float("-inf")).float().numpy(), (B, H, N, N))
+    truth = fo.bwd_numpy(q.float().numpy(), k.float().numpy(), v.float().numpy(), do.float().numpy(), True, bias=bias)
+    for got_t, t64 in zip((qd.grad, kd.grad, vd.grad), truth):
+        got = got_t.float().cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - t64).max() <= 4e-3 * max(1.0, np.abs(t64).max())
+    assert float(qd.grad[0, :, 7].abs().max()) == 0.0 and float(o.detach()[0, :, 7].abs().max()) == 0.0
+    # the hook: [B, N, heads*D] tensors, boolean [B, Nq, Nkv] mask, gradients flow through the kernels
+    x = torch.randn((2, 130, 4 * 40), generator=g).half()
+    ctx = torch.randn((2, 77, 4 * 40), generator=g).half()
+    m = torch.rand((2, 130, 77), generator=g) > 0.2
+    m[..., 0] = True
+    xd, cd = x.to(dev).requires_grad_(True), ctx.to(dev).requires_grad_(True)
+    out = attention_bnhd(xd, cd, cd, 4, mask=m.to(dev))
+    out.float().square().sum().backward()
+    xf, cf = x.float().to(dev).requires_grad_(True), ctx.float().to(dev).requires_grad_(True)
+    t = lambda a: a.reshape(2, a.shape[1], 4, 40).transpose(1, 2)  # noqa: E731
+    ref = torch.nn.functional.scaled_dot_product_attention(t(xf), t(cf), t(cf), attn_mask=m.to(dev).unsqueeze(1)).transpose(1, 2).reshape(2, 130, 160)
+    ref.square().sum().backward()
+    assert float((out.float() - ref).abs().max()) <= 4e-3
+    for got, want in ((xd.grad, xf.grad), (cd.grad, cf.grad)):
+        assert float((got.float() - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))

@@ -86,12 +86,32 @@ def test_validation_codes_without_a_gpu():
                                    kw.get("scale", 0.125), 0, None)
     assert bwd(q=None) == c["FA2_ERR_NULL_POINTER"] and bwd(ws=None) == c["FA2_ERR_NULL_POINTER"]
     assert bwd(dtype=3) == c["FA2_ERR_DTYPE"] and bwd(Nkv=0) == c["FA2_ERR_BAD_SHAPE"]
-    assert bwd(D=264) == c["FA2_ERR_HEAD_DIM"] and bwd(D=100) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]
+    assert bwd(D=520) == c["FA2_ERR_HEAD_DIM"] and bwd(D=100) == c["FA2_ERR_HEAD_DIM"] and bwd(scale=float("inf")) == c["FA2_ERR_SCALE"]      # the backward reaches 512 too
     assert bwd(dos=_fa2_lib.strides3(2048, 1024, 66)) == c["FA2_ERR_ALIGNMENT"]
     assert lib.fa2_bwd_f16(p, p, p, p, p, p, p, p, p, None, 1, 1, 1, 1, 64, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
         == c["FA2_ERR_NULL_POINTER"]
     assert lib.fa2_bwd_bf16(p, p, p, p, p, p, p, p, p, p, 1, 1, 1, 1, 7, s3, s3, s3, s3, s3, s3, s3, s3, s2, 1.0, 0, None) \
         == c["FA2_ERR_HEAD_DIM"]
+
+
+def test_backward_bias_entry_validation_codes_without_a_gpu():
+    """fa2_bwd_bias rejects bad bias arguments before any launch, like fa2_fwd_bias."""
+    lib = _fa2_lib.load()
+    c = _codes()
+    buf = ctypes.create_string_buffer(4096 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    s3 = _fa2_lib.strides3(2 * 16 * 64, 16 * 64, 64)
+    s2 = _fa2_lib.strides2(32, 16)
+    bs = _fa2_lib.strides3(0, 0, 16)
+
+    def call(bias=p, kind=_fa2_lib.FA2_BIAS_F32, strides=bs, D=64):
+        return lib.fa2_bwd_bias(0, p, p, p, p, p, p, p, p, p, p, 1, 2, 16, 16, D, s3, s3, s3, s3, s3, s3, s3, s3, s2, 0.125, 0,
+                                bias, kind, strides, None)
+
+    assert call(bias=None) == c["FA2_ERR_NULL_POINTER"] and call(strides=None) == c["FA2_ERR_NULL_POINTER"]
+    assert call(kind=9) == c["FA2_ERR_BIAS"] and call(strides=_fa2_lib.strides3(-1, 0, 16)) == c["FA2_ERR_BIAS"]
+    assert call(bias=p + 2) == c["FA2_ERR_ALIGNMENT"]
+    assert call(D=520) == c["FA2_ERR_HEAD_DIM"]
 
 
 def test_bias_entry_validation_codes_without_a_gpu():

@@ -265,3 +265,39 @@ def test_backward_oracle_against_dense(dt, causal, shape, nkv):
     for g_bits, a, b in zip(got, want_np, want_t):
         assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())       # numpy statement == torch autograd
         assert np.abs(_f32(g_bits, dt) - b).max() <= GRAD_TOL[dt] * max(1.0, np.abs(b).max())
+
+
+def test_backward_with_attention_bias_against_autograd():
+    """fa2_oracle_bwd_bias (the checker of C-ABI fa2_bwd_bias) and bwd_numpy(bias=...) against float64 torch autograd of
+    softmax(scale * Q K^T + bias) V — additive bias, a boolean mask as -inf, and a fully masked row.  The reference has no masked
+    backward to pin this on (its `mask` argument is ignored, FlashAttn.py:49/:74)."""
+    import torch
+    rng = np.random.default_rng(11)
+    B, H, Nq, Nkv, D = 1, 2, 70, 45, 64
+    q, k, v, do = (rng.standard_normal((B, H, n, D)).astype(np.float32) for n in (Nq, Nkv, Nkv, Nq))
+    add = rng.standard_normal((B, 1, Nq, Nkv)).astype(np.float32)
+    keep = rng.random((B, H, Nq, Nkv)) > 0.3
+    keep[..., 0] = True
+    keep[0, 1, 5, :] = False                                        # a fully masked row
+    for bias in (add, np.where(keep, 0.0, -np.inf).astype(np.float32)):
+        for causal in (False, True):
+            qd, kd, vd = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (q, k, v))
+            s = qd @ kd.transpose(-1, -2) * D ** -0.5 + torch.tensor(bias, dtype=torch.float64)
+            if causal:
+                s = s.masked_fill(torch.ones(Nq, Nkv, dtype=torch.bool).triu(1), float("-inf"))
+            dead = torch.isinf(s).all(-1, keepdim=True)
+            p = torch.where(dead, torch.zeros_like(s), torch.softmax(torch.where(dead, torch.zeros_like(s), s), -1))
+            (p @ vd).backward(torch.tensor(do, dtype=torch.float64))
+            want = [t.grad.numpy() for t in (qd, kd, vd)]
+            got = fo.bwd_numpy(q, k, v, do, causal, bias=bias)
+            for g, w in zip(got, want):
+                assert np.abs(g - w).max() <= 1e-9
+            # C oracle on fp16-rounded inputs, against the numpy formula on the same rounded inputs
+            bits = [fo.f32_to_bits(t, fo.DTYPE_F16) for t in (q, k, v, do)]
+            qr, kr, vr, dor = (fo.bits_to_f32(x, fo.DTYPE_F16) for x in bits)
+            o_bits, lse = fo.fwd_c(bits[0], bits[1], bits[2], fo.DTYPE_F16, causal, bias=bias)
+            dq, dk, dv = fo.bwd_c(bits[0], bits[1], bits[2], o_bits, bits[3], lse, fo.DTYPE_F16, causal, bias=bias)
+            ref = fo.bwd_numpy(qr, kr, vr, dor, causal, bias=bias)
+            for g_bits, w in zip((dq, dk, dv), ref):
+                g = fo.bits_to_f32(g_bits, fo.DTYPE_F16)
+                assert np.isfinite(g).all() and np.abs(g - w).max() <= 4e-3 * max(1.0, np.abs(w).max())

@@ -32,8 +32,6 @@ class _FakeFn:
 
 def _fake_flash_attention(q, k, v, mask, causal, scale, bnhd):
     _FakeFn.calls.append("masked")
-    if torch.is_grad_enabled() and q.requires_grad:
-        raise NotImplementedError("no backward through a masked forward")
     return _dense_bnhd(q, k, v, mask, causal, scale, bnhd)
 
 
@@ -109,18 +107,24 @@ def test_install_comfyui_fallbacks(hook, comfy_stub):
     big = torch.randn(1, 6, 1024, generator=g)
     attn_mod.optimized_attention(big, big, big, 1)
     assert calls[-1] == ("original", False, False)
-    # a masked call that needs a gradient (LoRA training through cross-attention): the masked forward has no backward
+    # a masked call that needs a gradient (LoRA training through cross-attention) runs the kernels too (fa2_fwd_bias / fa2_bwd_bias) ...
     q = torch.randn(2, 12, 32, generator=g, requires_grad=True)
     k = torch.randn(2, 7, 32, generator=g)
     m = torch.ones(2, 12, 7, dtype=torch.bool)
     n_before = len(calls)
     out = attn_mod.optimized_attention(q, k, k, 2, mask=m)
     out.sum().backward()
-    assert len(calls) == n_before + 1 and calls[-1] == ("original", False, True) and q.grad is not None
-    # the same call without a gradient goes to the kernels
+    assert len(calls) == n_before and _FakeFn.calls[-1] == "masked" and q.grad is not None
+    # ... except above head dim 256, where the masked backward stops: the host's own attention
+    qb = torch.randn(1, 5, 320, generator=g, requires_grad=True)
+    kb = torch.randn(1, 3, 320, generator=g)
+    out = attn_mod.optimized_attention(qb, kb, kb, 1, mask=torch.ones(1, 5, 3, dtype=torch.bool))
+    out.sum().backward()
+    assert len(calls) == n_before + 1 and calls[-1] == ("original", False, True) and qb.grad is not None
+    n_before += 1
     with torch.no_grad():
         attn_mod.optimized_attention(q, k, k, 2, mask=m)
-    assert _FakeFn.calls[-1] == "masked" and len(calls) == n_before + 1
+    assert _FakeFn.calls[-1] == "masked" and len(calls) == n_before
     # a mask that does not broadcast to [B, H, Nq, Nkv] (batch 3 against batch 2) is the host's problem, not an exception here
     bad = torch.ones(3, 12, 7, dtype=torch.bool)
     with torch.no_grad(), pytest.raises(Exception):
@@ -132,9 +136,6 @@ def test_attention_bnhd_without_fallback_raises(hook):
     q = torch.randn(1, 4, 1024)
     with pytest.raises(NotImplementedError):
         hook.attention_bnhd(q, q, q, 1)
-    q = torch.randn(1, 4, 16, requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        hook.attention_bnhd(q, q, q, 2, mask=torch.ones(4, 4, dtype=torch.bool))
 
 
 def test_install_webui_patches_cross_attention(hook, monkeypatch):
@@ -164,9 +165,9 @@ def test_install_webui_patches_cross_attention(hook, monkeypatch):
     try:
         assert torch.allclose(self_layer(x), want_self, atol=1e-5) and torch.allclose(layer(x, context=ctx), want_cross, atol=1e-5)
         assert _FakeFn.calls == ["apply", "apply"]
-        xg = x.clone().requires_grad_(True)              # masked + gradient -> torch SDPA inside the replacement forward
+        xg = x.clone().requires_grad_(True)              # masked + gradient: the kernels (head dim 8)
         layer(xg, context=ctx, mask=torch.ones(2, 30, 11, dtype=torch.bool)).sum().backward()
-        assert xg.grad is not None and _FakeFn.calls == ["apply", "apply"]
+        assert xg.grad is not None and _FakeFn.calls == ["apply", "apply", "masked"]
     finally:
         CrossAttention.forward = originals["ldm.modules.attention"]
 

@@ -74,6 +74,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -108,7 +109,23 @@ struct FwdParams {
     int64_t bs[3];
     int bias_kind;                       // 1: the I/O 16-bit dtype, 2: f32, 3: uint8 (non-zero = attend)
     int bias_vec;                        // host: base pointer, strides and Nkv allow one aligned load per group of four kv
+    // KV-split tail (fa2_fwd_ws; non-causal, no bias, head dims <= 128, 256-row workgroups): B*H*nqblk equal items on the CUs take
+    // ceil(items / CUs) rounds however empty the last one is.  The items of that last round — the last `split_items` of the item
+    // order, after `full_items` whole ones — are each swept by `nsplit` workgroups ("parts") over disjoint KV ranges, which leave
+    // normalised f32 partial O tiles and partial log2 LSEs in `ws`; fwd_combine_kernel merges them into o / lse.
+    int full_items, split_items, nsplit; // nsplit <= 1: no split
+    int blk0;                            // added to blockIdx.x (a launch that covers only the parts: blk0 = full_items)
+    int item_cap;                        // hand-scheduled kernels: the launch covers items [0, item_cap) only (0 = all)
+    float* ws;                           // [split_items * nsplit] partial O tiles of kSplitRows x HD floats, then as many LSE rows of kSplitRows
 };
+
+constexpr int kSplitRows = 256;          // rows of a split item (the 8-wave workgroup shape)
+constexpr int kMaxSplit = 8;
+
+// bytes of the KV-split workspace: partial O tiles + partial LSE rows
+__host__ __device__ inline int64_t split_ws_bytes(int split_items, int nsplit, int HD) {
+    return (int64_t)split_items * nsplit * kSplitRows * (HD + 1) * 4;
+}
 
 template <bool BF16>
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
@@ -251,10 +268,30 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
+    // KV-split tail: blocks [full_items, full_items + split_items * nsplit) are parts; part-major order, so that with split_items a
+    // multiple of 8 a part lands on the XCD (block index % 8) its item's head is mapped to
+    int bid = blockIdx.x + p.blk0;
+    int part = -1, sidx = 0;
+    if constexpr (!CAUSAL && !BIAS && HD == HDV && NW * QB * 32 == kSplitRows) {
+        if (p.nsplit > 1 && bid >= p.full_items) {
+            const int j = bid - p.full_items;
+            part = j / p.split_items;
+            sidx = j % p.split_items;
+            bid = p.full_items + sidx;
+        }
+    }
     int bh, qblk;
-    block_to_head_qblock<CAUSAL>(p, blockIdx.x, bh, qblk);
+    block_to_head_qblock<CAUSAL>(p, bid, bh, qblk);
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * kRowsPerBlock;
+    // this workgroup's KV range [kv_first, kv_first + nkv): everything, or a part's whole tiles
+    int kv_first = 0, nkv = p.Nkv;
+    if (part >= 0) {
+        const int nt = (p.Nkv + kKvTile - 1) / kKvTile;
+        const int t0 = part * nt / p.nsplit, t1 = (part + 1) * nt / p.nsplit;
+        kv_first = t0 * kKvTile;
+        nkv = (t1 * kKvTile < p.Nkv ? t1 * kKvTile : p.Nkv) - kv_first;
+    }
     const int qw0 = q0 + wave * kRowsPerWave;   // first Q row of this wave
     int qrow[QB];                               // this lane's Q row in each of its blocks (may be >= Nq)
 #pragma unroll
@@ -277,11 +314,11 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     }
 
     // ---- K/V staging: buffer descriptors of this head's matrices (out-of-range rows read 0)
-    const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
-    const uint16_t* vbase = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1];
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
     const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
+    const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1] + (int64_t)kv_first * p.ks[2];
+    const uint16_t* vbase = (const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1] + (int64_t)kv_first * p.vs[2];
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes - (uint32_t)kv_first * k_rowb, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes - (uint32_t)kv_first * v_rowb, 0x00020000);
     uint32_t kg_off[NPASS], vg_off[VNPASS];  // per-lane byte offsets into the head matrix, tile 0
     int kw_off[NPASS], vw_off[VNPASS];       // per-lane LDS byte offsets inside a tile image
 #pragma unroll
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     }
 
     // ---- KV sweep bounds
-    int ntiles = (p.Nkv + kKvTile - 1) / kKvTile;
+    int ntiles = (nkv + kKvTile - 1) / kKvTile;
     if (CAUSAL) {
         const int qmax = (q0 + kRowsPerBlock < p.Nq ? q0 + kRowsPerBlock : p.Nq) - 1;
         const int nt_c = qmax / kKvTile + 1;
@@ -608,10 +645,10 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
             if constexpr (decltype(masked)::value) {
                 const int kv0 = tile * kKvTile;
                 const bool need_causal = CAUSAL && (kv0 + kKvTile - 1 > qw0 + 32 * qb);
-                const bool need_tail = kv0 + kKvTile > p.Nkv;
+                const bool need_tail = kv0 + kKvTile > nkv;
                 if (need_causal || need_tail) {
                     const int lim_c = CAUSAL ? qrow[qb] : 0x7fffffff;  // kv index must be <= lim_c
-                    int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;
+                    int lim = lim_c < nkv - 1 ? lim_c : nkv - 1;
                     int kvb = kv0 + 4 * hi;
                     // opaque (D = 64, 256; measured neutral-to-negative at D = 128): the tail comparison of the non-causal
                     // build does not depend on the tile, so LICM hoists all 32 lane masks (64 SGPRs) or the 32
@@ -747,7 +784,7 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     // steady-state tiles [0, n_fast): tile+2 < ntiles, tile+1 < ntiles_w, tile+1 unmasked
     int n_fast = ntiles - 2 < ntiles_w - 1 ? ntiles - 2 : ntiles_w - 1;
     {
-        const int unmasked_kv = p.Nkv / kKvTile;                           // tiles fully inside Nkv
+        const int unmasked_kv = nkv / kKvTile;                             // tiles fully inside this workgroup's KV range
         const int unmasked_c = CAUSAL ? (qw0 + 1) / kKvTile : 0x7fffffff;  // tiles fully below the diagonal
         const int unmasked = unmasked_kv < unmasked_c ? unmasked_kv : unmasked_c;
         n_fast = n_fast < unmasked - 1 ? n_fast : unmasked - 1;            // tile+1 <= unmasked-1
@@ -775,6 +812,28 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     // row-major, so that every global store instruction writes whole contiguous rows (64 lanes x 16 B = 4 rows of
     // 256 B) instead of 32 B of each of 32 rows.  The K/V buffers are free by now; rows are padded by 16 B so both the
     // column-wise writes and the row-wise reads are bank-conflict free.
+    if constexpr (!CAUSAL && !BIAS && HD == HDV && NW * QB * 32 == kSplitRows) {
+        if (part >= 0) {
+            // a part: normalised f32 partial tile + partial LSE -> workspace.  Layout of a tile: float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e)
+            // for d = 32dt + 8g + 4hi + e — one store instruction of the wave writes 1 KiB of consecutive bytes.
+            const int slot = sidx * p.nsplit + part;
+            float* wo = p.ws + (int64_t)slot * kSplitRows * HD;
+            float* wl = p.ws + (int64_t)p.split_items * p.nsplit * kSplitRows * HD + (int64_t)slot * kSplitRows;
+            const int row = wave * 32 + l31;
+            const float l_tot = half_swap_sum(l_run[0]);
+            const float inv_l = 1.0f / l_tot;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& a = acc[0][dt];
+                    const f32x4 w = {a[4 * g] * inv_l, a[4 * g + 1] * inv_l, a[4 * g + 2] * inv_l, a[4 * g + 3] * inv_l};
+                    *(f32x4*)(wo + ((dt * 4 + g) * kSplitRows + row) * 8 + 4 * hi) = w;
+                }
+            if (hi == 0) wl[row] = m_run[0] * c + __builtin_amdgcn_logf(l_tot);
+            return;
+        }
+    }
     if constexpr (QB == 1) {
         constexpr int EROW = HDV * 2 + 16;                       // bytes per staged row
         constexpr int LPR = HDV * 2 / 16;                        // lanes (16-B pieces) per row
@@ -838,6 +897,46 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
                 p.lse[b * p.ls[0] + h * p.ls[1] + qrow[qb]] = m_run[qb] * c + __builtin_amdgcn_logf(l_tot);
         }
     }
+}
+
+// Merge of the KV-split parts (fa2_fwd_ws): for every row of a split item, lse = log2 sum_i 2^lse_i and O = sum_i 2^(lse_i - lse) O_i
+// over the item's nsplit partial results, rounded once to the I/O dtype.  One thread per (row, 8 output columns): the two float4 reads
+// per part are 32 consecutive bytes of the layout the parts wrote, the 16-byte stores of 16 (or 8) consecutive threads one output row.
+template <int HD, bool BF16>
+__global__ __launch_bounds__(256) void fwd_combine_kernel(const FwdParams p) {
+    constexpr int CPR = HD / 8;                                  // threads per row
+    const int t = blockIdx.x * 256 + threadIdx.x;                // over split_items * kSplitRows * CPR
+    const int sidx = t / (kSplitRows * CPR), rem = t % (kSplitRows * CPR);
+    const int row = rem / CPR, c8 = rem % CPR;
+    if (sidx >= p.split_items) return;
+    int bh, qblk;
+    block_to_head_qblock<false>(p, p.full_items + sidx, bh, qblk);
+    const int b = bh / p.H, h = bh % p.H;
+    const int qr = qblk * kSplitRows + row;
+    if (qr >= p.Nq || 8 * c8 >= p.D) return;
+    const float* wl = p.ws + (int64_t)p.split_items * p.nsplit * kSplitRows * HD + (int64_t)sidx * p.nsplit * kSplitRows + row;
+    float li[kMaxSplit], m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kMaxSplit; ++i)
+        if (i < p.nsplit) { li[i] = wl[i * kSplitRows]; m = __builtin_fmaxf(m, li[i]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxSplit; ++i)
+        if (i < p.nsplit) { li[i] = __builtin_amdgcn_exp2f(li[i] - m); sum += li[i]; }
+    const float inv = 1.0f / sum;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* wo = p.ws + (int64_t)sidx * p.nsplit * kSplitRows * HD + (c8 * kSplitRows + row) * 8;
+#pragma unroll
+    for (int i = 0; i < kMaxSplit; ++i)
+        if (i < p.nsplit) {
+            const f32x4 lo = *(const f32x4*)(wo + (int64_t)i * kSplitRows * HD), hi4 = *(const f32x4*)(wo + (int64_t)i * kSplitRows * HD + 4);
+            const float w = li[i] * inv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] += w * lo[e]; o[4 + e] += w * hi4[e]; }
+        }
+    const u32x4 w16 = {pack2<BF16>(o[0], o[1]), pack2<BF16>(o[2], o[3]), pack2<BF16>(o[4], o[5]), pack2<BF16>(o[6], o[7])};
+    *(u32x4*)((uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qr * p.os[2] + 8 * c8) = w16;
+    if (c8 == 0) p.lse[b * p.ls[0] + h * p.ls[1] + qr] = m + __builtin_amdgcn_logf(sum);
 }
 
 }  // namespace fa2

@@ -21,6 +21,7 @@ struct Options {
     std::atomic<int> asm_mask{3};      // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
+    std::atomic<int> split{1};         // FA2_SPLIT: KV-split of the last, partly filled round of forward workgroups (fa2_fwd_ws)
 };
 FA2_HIDDEN Options& options();
 FA2_HIDDEN int device_cus();           // compute units of the current device (cached per device index)
@@ -43,6 +44,9 @@ int set_lds(int bytes) {
 // generic HIP forward (fwd_hip.cpp): rows = 256 (8 waves) or 128 (4 waves) per workgroup; bias: the BIAS kernels (always 128 rows)
 FA2_HIDDEN int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
+// merge of the KV-split parts a forward launch left in p.ws (fwd_hip.cpp)
+FA2_HIDDEN int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t stream);
+FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream);
 // hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
 FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)

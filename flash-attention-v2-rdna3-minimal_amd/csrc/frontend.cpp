@@ -81,8 +81,13 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     s3(O, os);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream();
-    const int rc = fa2_fwd(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
-                           (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, causal ? 1 : 0, (void*)stream);
+    // scratch for the KV-split of a partly filled last round of workgroups (fa2_fwd_ws): from the caching allocator, per call
+    at::Tensor ws;
+    const size_t ws_bytes = causal ? 0 : fa2_fwd_workspace_bytes(dtype_code, (int)b, (int)h, (int)n, (int)n_kv, (int)d_kernel, 0);
+    if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, q.options().dtype(at::kByte));
+    const int rc = fa2_fwd_ws(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
+                              (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, causal ? 1 : 0,
+                              ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);
     TORCH_CHECK(rc == 0, "fa2 call failed (", rc, "): ", fa2_error_string(rc));
     at::Tensor O_fwd = O;
     if (nq_pad) O_fwd = O_fwd.narrow(n_ax, 0, n);

@@ -28,6 +28,7 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
     // work units: non-causal one per (head, q block); causal one per PAIR of q blocks of a head (fa2_fwd_d128.hip.h)
     const int64_t per_head = (CAUSAL && p.persist) ? (p.nqblk + 1) / 2 : p.nqblk;
     int64_t grid = (int64_t)p.nbh * per_head;
+    if (!CAUSAL && p.item_cap > 0) grid = p.item_cap;
     if (p.persist && pg > 0 && grid > pg) grid = pg;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
     return (int)hipGetLastError();

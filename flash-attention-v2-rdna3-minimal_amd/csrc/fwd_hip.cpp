@@ -25,7 +25,14 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + NW * 32 - 1) / (NW * 32);
     if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
-    const dim3 grid((unsigned)((int64_t)p.nbh * p.nqblk), HD / HDV);
+    int64_t nblk = (int64_t)p.nbh * p.nqblk;
+    if constexpr (NW == 8 && !BIAS && !CAUSAL && HD == HDV) {
+        // KV-split tail (host.cpp: plan_split): the whole items from blk0 on, then split_items * nsplit parts
+        if (p.nsplit > 1) nblk = (int64_t)p.full_items - p.blk0 + (int64_t)p.split_items * p.nsplit;
+    } else {
+        p.nsplit = 0;
+    }
+    const dim3 grid((unsigned)nblk, HD / HDV);
     constexpr auto kern = fa2::fwd_kernel<HD, HDV, kBF16, CAUSAL, NW, 1, BIAS>;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
@@ -53,9 +60,25 @@ int launch_hd(const fa2::FwdParams& p, bool causal, int rows, bool bias, hipStre
     return causal ? launch_t<HD, true>(p, rows, bias, stream) : launch_t<HD, false>(p, rows, bias, stream);
 }
 
+template <int HD>
+int launch_combine(const fa2::FwdParams& p, hipStream_t stream) {
+    const int64_t threads = (int64_t)p.split_items * fa2::kSplitRows * (HD / 8);
+    hipLaunchKernelGGL((fa2::fwd_combine_kernel<HD, kBF16>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 namespace fa2 {
+
+// merge of the KV-split parts (fwd_combine_kernel); p as handed to the launch that produced them (nqblk in 256-row blocks)
+#if FA2_TU_BF16
+int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream) {
+#else
+int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t stream) {
+#endif
+    return HD == 64 ? launch_combine<64>(p, stream) : HD == 128 ? launch_combine<128>(p, stream) : FA2_ERR_HEAD_DIM;
+}
 
 #if FA2_TU_BF16
 int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {

@@ -30,6 +30,7 @@ Options& options() {
         if (const char* e = std::getenv("FA2_ROWS")) o.rows = std::atoi(e);
         if (const char* e = std::getenv("FA2_ASM")) o.asm_mask = std::atoi(e);
         if (const char* e = std::getenv("FA2_PERSIST")) o.persist = std::atoi(e);
+        if (const char* e = std::getenv("FA2_SPLIT")) o.split = std::atoi(e) != 0;
         return true;
     }();
     (void)init;
@@ -121,7 +122,70 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
 }
 
-int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream) {
+// KV-split tail (fa2_fwd_ws).  B*H*ceil(Nq/256) equal workgroups on the CUs take ceil(x / CUs) rounds however empty the last one is: SDXL's
+// 64x64 self-attention (B2 H10 N4096 D64) is 320 workgroups — two rounds for 1.25 rounds of work —, the reference harness's own sweep
+// (B1 H24 D64, bench_with_sdpa.py:201-224) saw-tooths between 670 and 930 TF with N for the same reason.  With a workspace from the caller the r
+// items of the last round are swept by S workgroups each over disjoint KV ranges (r * S parts fill the CUs again) and a small kernel merges the
+// partial results (fa2_fwd_kernel.hip.h).  S minimises rounds(r * S) / S plus the fixed cost of the scheme, in units of one whole item:
+//   an item sweeps nt KV tiles at ~0.9 us * HD / 64 each (measured: D = 64 N4096 60 us, D = 128 112 us per 256-row item);
+//   the merge kernel, its launch and a part's own prologue / epilogue cost ~10 us (+ ~4 us for the extra launch of the D = 128 path);
+//   the f32 partial tiles cross memory twice.  The workspace never exceeds 64 MiB.
+struct SplitPlan { int full_items = 0, split_items = 0, nsplit = 0; };
+constexpr int64_t kMaxSplitWsBytes = 64ll << 20;
+
+SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool causal) {
+    SplitPlan none;
+    if (causal || p.bias_kind != FA2_BIAS_NONE || HD > 128 || !fa2::options().split.load(std::memory_order_relaxed)) return none;
+    const int f = forced_rows();
+    if (f == 128 || p.rows_hint == 128) return none;
+    const int64_t cus = fa2::device_cus(), nq = (p.Nq + kFwdRows - 1) / kFwdRows, items = (int64_t)p.nbh * nq;
+    if (items <= cus || items > 0x7fffffffLL) return none;
+    const int64_t r = items % cus;
+    if (r == 0) return none;
+    const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
+    const double t_item = nt * 0.9 * HD / 64.0, fixed = (HD == 128 ? 14.0 : 10.0) / t_item;
+    double best = 0.93;          // the plain launch's last round costs 1.0; a split must win at least 7 %
+    int best_s = 0;
+    for (int S = 2; S <= fa2::kMaxSplit; ++S) {
+        if (nt / S < 8) break;   // parts of fewer than 8 tiles are mostly prologue
+        const int64_t bytes = fa2::split_ws_bytes((int)r, S, HD);
+        if (bytes > kMaxSplitWsBytes) break;
+        // + the partial tiles' trip through memory (written by the parts, read by the merge; ~4 TB/s effective through L2 / Infinity Cache)
+        const double cost = (double)((r * S + cus - 1) / cus) / S + fixed + 2.0 * bytes / 4.0e6 / t_item;
+        if (cost < best) { best = cost; best_s = S; }
+    }
+    if (!best_s) return none;
+    SplitPlan pl;
+    pl.full_items = (int)(items - r);
+    pl.split_items = (int)r;
+    pl.nsplit = best_s;
+    return pl;
+}
+
+bool asm_d128_ok(int HD, const fa2::FwdParams& p) { return HD == 128 && p.D == 128 && !p.negate_q && asm_fwd() && asm_q_span_ok(p); }
+
+int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
+    if (ws) {
+        const SplitPlan pl = plan_split(p0, HD, causal);
+        if (pl.nsplit > 1 && (int64_t)ws_bytes >= fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD) && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
+            fa2::FwdParams p = p0;
+            p.rows_hint = 256;
+            p.full_items = pl.full_items; p.split_items = pl.split_items; p.nsplit = pl.nsplit;
+            p.ws = (float*)ws;
+            int rc;
+            if (asm_d128_ok(HD, p) && pick_rows(p, causal) == 256) {
+                // whole rounds on the hand-scheduled persistent kernel (every workgroup gets the same number of items), then the parts
+                fa2::FwdParams pa = p;
+                pa.item_cap = pl.full_items;
+                pa.nsplit = 0;
+                if ((rc = fa2::launch_fwd_asm(HD, bf16, pa, false, stream))) return rc;
+                p.blk0 = pl.full_items;
+            }
+            rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
+            if (rc) return rc;
+            return bf16 ? fa2::launch_fwd_combine_bf16(HD, p, stream) : fa2::launch_fwd_combine_f16(HD, p, stream);
+        }
+    }
     if (HD <= 64) {     // (measured at D = 128, B1 H24 N4096: 188 -> 194 us — the 128-row shape is too slow there)
         const int main_heads = tail_split_heads(p0, causal);
         if (main_heads < p0.nbh) {
@@ -197,6 +261,7 @@ int fa2_set_option(const char* name, int value) {
     if (!std::strcmp(name, "rows")) { if (value != 0 && value != 128 && value != 256) return FA2_ERR_BAD_SHAPE; o.rows = value; }
     else if (!std::strcmp(name, "asm")) o.asm_mask = value;
     else if (!std::strcmp(name, "persist")) o.persist = value != 0;
+    else if (!std::strcmp(name, "split")) o.split = value != 0;
     else if (!std::strcmp(name, "bwd_parts")) { if (value < 1 || value > 3) return FA2_ERR_BAD_SHAPE; o.bwd_parts = value; }
     else return FA2_ERR_BAD_SHAPE;
     return FA2_OK;
@@ -208,6 +273,7 @@ int fa2_get_option(const char* name) {
     if (!std::strcmp(name, "rows")) return o.rows.load();
     if (!std::strcmp(name, "asm")) return o.asm_mask.load();
     if (!std::strcmp(name, "persist")) return o.persist.load();
+    if (!std::strcmp(name, "split")) return o.split.load();
     if (!std::strcmp(name, "bwd_parts")) return o.bwd_parts.load();
     return FA2_ERR_BAD_SHAPE;
 }
@@ -229,12 +295,14 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.6 (D=128: hand-scheduled 4-wave 256x64 asm body; other head dims up to 512: 8-wave HIP kernels; mfma32x32x16, lds-dma; fwd+bwd; attention bias / mask)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.8 (D=128 forward + backward and D=64 causal forward: hand-scheduled 4-wave asm bodies; other head dims up to 512: HIP kernels; mfma32x32x16, lds-dma; KV-split tail rounds; attention bias / mask, forward + backward)"; }
 
 static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
                     int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
                     const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
-                    float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
+                    float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
+                    void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr) {
+    if (ws_need) *ws_need = 0;
     if (!q || !k || !v || !o || !lse || !q_strides || !k_strides || !v_strides || !o_strides || !lse_strides)
         return FA2_ERR_NULL_POINTER;
     if (bias_kind != FA2_BIAS_NONE) {
@@ -274,6 +342,8 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     p.nbh = B * H;
     p.rows_hint = 0;
     p.persist = 1;
+    p.full_items = p.split_items = p.nsplit = p.blk0 = p.item_cap = 0;
+    p.ws = nullptr;
     p.k_bytes = (uint32_t)k_bytes;
     p.v_bytes = (uint32_t)v_bytes;
     p.bias = bias;
@@ -297,9 +367,15 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     const bool bf16 = dtype == FA2_DTYPE_BF16;
     if (bias_kind != FA2_BIAS_NONE) {
         if ((int64_t)B * H * ((Nq + 127) / 128) > 0x7fffffffLL) return FA2_ERR_GRID;
+        if (ws_need) return FA2_OK;
         return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal != 0, 128, true, stream) : fa2::launch_fwd_hip_f16(HD, p, causal != 0, 128, true, stream);
     }
-    return launch_fwd(HD, bf16, p, causal != 0, stream);
+    if (ws_need) {      // fa2_fwd_workspace_bytes: validate and plan only
+        const SplitPlan pl = plan_split(p, HD, causal != 0);
+        if (pl.nsplit > 1) *ws_need = (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD);
+        return FA2_OK;
+    }
+    return launch_fwd(HD, bf16, p, causal != 0, stream, ws, ws_bytes);
 }
 
 int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
@@ -308,6 +384,26 @@ int fa2_fwd(int dtype, const void* q, const void* k, const void* v, void* o, flo
             float scale, int causal, void* hip_stream) {
     return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides, lse_strides,
                     scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream);
+}
+
+int fa2_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+               int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+               const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
+               float scale, int causal, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    return fwd_impl(dtype, q, k, v, o, lse, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides, lse_strides,
+                    scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream, workspace, workspace_bytes);
+}
+
+size_t fa2_fwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal) {
+    // the plan depends on the shape and the device's CU count only: run the validation + planning half of the call on stand-in arguments
+    static const int64_t one[3] = {8, 8, 8};
+    alignas(16) static char dummy[16];
+    size_t need = 0;
+    const int64_t ls[2] = {0, 0};
+    if (fwd_impl(dtype, dummy, dummy, dummy, dummy, (float*)dummy, B, H, Nq, Nkv, D, one, one, one, one, ls, 1.0f, causal, nullptr, FA2_BIAS_NONE,
+                 nullptr, nullptr, nullptr, 0, &need) != FA2_OK)
+        return 0;
+    return need;
 }
 
 int fa2_fwd_bias(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,

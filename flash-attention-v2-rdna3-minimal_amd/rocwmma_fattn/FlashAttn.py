@@ -121,12 +121,11 @@ class _FlashAttnWmma:
             bias_t, kind, bstr = _prepare_bias(bias, b, h, n, n_kv, q_pad.dtype, q.device)
             args += (bias_t.data_ptr(), kind, _fa2_lib.strides3(*bstr))
             fn = lib.fa2_fwd_bias
-        args += (_raw_stream(dev),)
         if dev != _current_device():
             with torch.cuda.device(dev):
-                rc = fn(*args)
+                rc = _launch_fwd(lib, fn, args, dev, q.device, bias is None and not causal)
         else:
-            rc = fn(*args)
+            rc = _launch_fwd(lib, fn, args, dev, q.device, bias is None and not causal)
         if rc:
             _fa2_lib.check(rc)
 
@@ -187,6 +186,18 @@ class _FlashAttnWmma:
         if permute_NH:
             return [dQ[:, :act_n, :, :act_d], dK[:, :act_nkv, :, :act_d], dV[:, :act_nkv, :, :act_d]]
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
+
+
+def _launch_fwd(lib, fn, args, dev, device, may_split):
+    """The C-ABI call on torch's current stream.  Non-causal, unbiased launches go through fa2_fwd_ws when the library can use a
+    workspace for this shape (KV-split of the last, partly filled round of workgroups: include/fa2_gfx950.h): scratch memory from
+    torch's caching allocator, taken per call — stream-ordered reuse and graph capture are then the allocator's business."""
+    if may_split:
+        need = lib.fa2_fwd_workspace_bytes(args[0], *args[6:11], 0)
+        if need:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            return lib.fa2_fwd_ws(*args, ws.data_ptr(), need, _raw_stream(dev))
+    return fn(*args, _raw_stream(dev))
 
 
 _FRONTEND = [False]      # False = not looked for yet, None = absent

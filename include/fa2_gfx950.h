@@ -45,6 +45,7 @@
 #ifndef FA2_GFX950_H
 #define FA2_GFX950_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -96,6 +97,29 @@ int fa2_fwd(int dtype,
             const int64_t v_strides[3], const int64_t o_strides[3],
             const int64_t lse_strides[2],
             float scale, int causal, void* hip_stream);
+
+/*
+ * Forward attention with a caller-owned workspace: the same call as fa2_fwd, plus scratch memory that lets the library balance the
+ * last, partly filled round of workgroups.  B*H*ceil(Nq/256) equal workgroups on the chip's CUs take ceil(x / CUs) rounds however
+ * empty the last one is (SDXL's 64x64 self-attention, B2 H10 N4096 D64, is 320 workgroups on 256 CUs: two rounds for 1.25 rounds of
+ * work; the reference's own N sweep, bench_with_sdpa.py:201-224, saw-tooths for the same reason).  With a workspace, the items of
+ * that last round are each swept by several workgroups over disjoint KV ranges and a small kernel merges the partial results
+ * (non-causal launches of head dims <= 128; every other call, and any call whose workspace is NULL or too small, is exactly fa2_fwd).
+ * The reference has no counterpart (its launcher pads the grid to its 96 CUs instead, kernel_fp16.cu:808-813).
+ *   fa2_fwd_workspace_bytes  bytes fa2_fwd_ws can use for this shape on the current device (0: it would not use any).  A function
+ *                            of the arguments, the device's CU count and the "split" option only; never more than 64 MiB.
+ *   workspace                >= that many bytes, 16-byte aligned, owned by the caller, free for reuse once the work queued on
+ *                            `hip_stream` by this call has run (calls on one stream may share it; concurrent streams may not).
+ * Results agree with fa2_fwd to f32 rounding of the merge (the parts are normalised in f32 and rounded to the I/O dtype once).
+ */
+int fa2_fwd_ws(int dtype,
+               const void* q, const void* k, const void* v, void* o, float* lse,
+               int B, int H, int Nq, int Nkv, int D,
+               const int64_t q_strides[3], const int64_t k_strides[3],
+               const int64_t v_strides[3], const int64_t o_strides[3],
+               const int64_t lse_strides[2],
+               float scale, int causal, void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t fa2_fwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal);
 
 /*
  * Forward attention with an attention bias / mask: S = (Q K^T) * scale + bias[b, h, i, j] before the softmax (additive kinds), or
@@ -206,6 +230,7 @@ int fa2_fwd_prescales_q(int D, float scale);
  *                              bodies (head dim 128), bits 2 / 3: ... except its dQ pass / its dK-dV pass, bit 4: the head-dim-64
  *                              forward body for non-causal launches too (default: causal only); default 3.  0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
+ *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws may split the last round of workgroups along KV (0: it is fa2_fwd)
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

@@ -1,0 +1,180 @@
+"""KV-split of the last, partly filled round of forward workgroups (C-ABI fa2_fwd_ws / fa2_fwd_workspace_bytes, include/fa2_gfx950.h).
+
+GPU tests (-m gpu): through the C-ABI against the oracle (oracle/, test infrastructure), against dense fp32 attention and against the
+plain fa2_fwd call of the same inputs.  The reference has no counterpart: its launcher pads the grid to a multiple of its 96 CUs
+(kernel_fp16.cu:808-813) and lets the padding blocks exit."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ATOL, FLOOR, LSE_TOL, RTOL
+from oracle import fa2_oracle as fo
+from rocwmma_fattn import _fa2_lib
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attn_wmma
+
+TORCH_DT = {0: torch.float16, 1: torch.bfloat16}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run the CPU suite with -m 'not gpu'"
+    return torch.device("cuda", 0)
+
+
+def _bits(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def _s3(t, bnhd=False):
+    return _fa2_lib.strides3(t.stride(0), t.stride(2), t.stride(1)) if bnhd else _fa2_lib.strides3(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _fwd(q, k, v, ws_mode, bnhd=False, scale=None):
+    """ws_mode: 'none' -> fa2_fwd; 'ws' -> fa2_fwd_ws with a workspace of exactly the advertised size (NaN-filled: every byte the
+    merge reads must have been written by a part); 'small' -> fa2_fwd_ws with a workspace one byte short (must behave as fa2_fwd)."""
+    lib = _fa2_lib.load(build_if_missing=False)
+    if bnhd:
+        B, N, H, D = q.shape
+        Nkv = k.shape[1]
+    else:
+        B, H, N, D = q.shape
+        Nkv = k.shape[2]
+    dt = 0 if q.dtype == torch.float16 else 1
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((B, H, N), float("nan"), dtype=torch.float32, device=q.device)
+    args = (dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, Nkv, D,
+            _s3(q, bnhd), _s3(k, bnhd), _s3(v, bnhd), _s3(o, bnhd), _fa2_lib.strides2(lse.stride(0), lse.stride(1)),
+            float(D ** -0.5 if scale is None else scale), 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    need = lib.fa2_fwd_workspace_bytes(dt, B, H, N, Nkv, D, 0)
+    if ws_mode == "none":
+        rc = lib.fa2_fwd(*args, stream)
+    else:
+        nbytes = need if ws_mode == "ws" else max(need - 1, 1)
+        ws = torch.full(((nbytes + 3) // 4 + 4,), float("nan"), dtype=torch.float32, device=q.device)
+        rc = lib.fa2_fwd_ws(*args, ws.data_ptr(), nbytes, stream)
+    _fa2_lib.check(rc)
+    torch.cuda.synchronize()
+    return o, lse, need
+
+
+def _check_heads(o, lse, q, k, v, dt, heads, bnhd=False):
+    for (b, h) in heads:
+        if bnhd:
+            sl = lambda t: t[b:b + 1, :, h:h + 1].transpose(1, 2).contiguous()  # noqa: E731
+        else:
+            sl = lambda t: t[b:b + 1, h:h + 1].contiguous()  # noqa: E731
+        o_ref_bits, lse_ref = fo.fwd_c(_bits(sl(q)), _bits(sl(k)), _bits(sl(v)), dt, False)
+        o_ref = fo.bits_to_f32(o_ref_bits, dt)
+        got = sl(o).float().cpu().numpy()
+        assert np.isfinite(got).all()
+        bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
+        assert not bad.any(), "head %s: max diff %.3e" % ((b, h), np.abs(got - o_ref).max())
+        assert np.abs(lse[b:b + 1, h:h + 1].cpu().numpy() - lse_ref).max() <= LSE_TOL
+
+
+# shapes whose B*H*ceil(Nq/256) leaves a partly filled last round on 256 CUs:
+#   (B, H, Nq, Nkv, D, dtype code, BNHD)
+SPLIT_SHAPES = [
+    (2, 10, 4096, 4096, 64, 0, False),      # SDXL 64x64 self-attention: 320 items -> 64 items x 4 parts; heads not a multiple of 8
+    (1, 24, 3072, 3072, 64, 0, False),      # the reference harness's shape (bench_with_sdpa.py:52) at N = 3072: 288 items -> 32 x 6 parts
+    (1, 24, 4096, 4096, 64, 1, False),      # 384 items -> 128 x 2, bf16
+    (1, 24, 4096, 4096, 128, 0, False),     # D = 128: whole rounds on the hand-scheduled kernel, parts on the HIP kernel
+    (1, 24, 4096, 4096, 128, 1, True),      # ... bf16, BNHD (zero-copy strides)
+    (2, 10, 4000, 3990, 64, 0, False),      # ragged Nq (last q block partly empty) and ragged Nkv (the last part's last tile is masked)
+    (2, 10, 4096, 4096, 40, 0, False),      # SD1.5's head dim on the D = 64 kernel (columns 40..63 masked in-kernel)
+    (3, 9, 3072, 2048, 96, 0, False),       # D = 96 on the D = 128 HIP kernel (no hand-scheduled body: everything in one launch), 324 items
+    (1, 40, 2048, 8192, 64, 0, True),       # cross-attention-like: Nkv != Nq, 320 items, BNHD
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SPLIT_SHAPES)
+def test_split_launches_against_oracle_dense_and_plain_call(shape):
+    B, H, N, Nkv, D, dt, bnhd = shape
+    g = torch.Generator(device="cpu").manual_seed(1000 + H + D)
+    mk = lambda n: torch.randn(((B, n, H, D) if bnhd else (B, H, n, D)), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v = mk(N), mk(Nkv), mk(Nkv)
+    o_ws, lse_ws, need = _fwd(q, k, v, "ws", bnhd)
+    assert need > 0, "the shape is meant to be split on a 256-CU device"
+    o_pl, lse_pl, _ = _fwd(q, k, v, "none", bnhd)
+    assert torch.isfinite(o_ws.float()).all() and torch.isfinite(lse_ws).all()
+    # against the plain call: the merge normalises the parts in f32 and rounds once, so results agree to one ulp of the I/O dtype
+    ulp = 2.0 ** -10 if dt == 0 else 2.0 ** -7
+    scale_o = max(1.0, float(o_pl.float().abs().max()))
+    assert float((o_ws.float() - o_pl.float()).abs().max()) <= ulp * scale_o
+    assert float((lse_ws - lse_pl).abs().max()) <= 1e-4
+    # a fair share of the elements must be bit-identical (the unsplit items are the same launch geometry)
+    same = (o_ws.view(torch.int16) == o_pl.view(torch.int16)).float().mean().item()
+    assert same > 0.5, same
+    # against the oracle on heads from the unsplit rounds and from the split tail (the last items of the order)
+    heads = {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2), (B - 1, max(H - 8, 0))}
+    _check_heads(o_ws, lse_ws, q, k, v, dt, heads, bnhd)
+    # against dense fp32 attention on the whole tensor
+    qf, kf, vf = (t.float().transpose(1, 2) if bnhd else t.float() for t in (q, k, v))
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * (D ** -0.5)
+    truth = torch.matmul(torch.softmax(s, -1), vf)
+    got = o_ws.float().transpose(1, 2) if bnhd else o_ws.float()
+    assert float((got - truth).abs().max()) <= FLOOR[dt] * 2
+    lse_true = torch.logsumexp(s, -1) * fo.LOG2E
+    assert float((lse_ws - lse_true).abs().max()) <= 2e-3
+
+
+@pytest.mark.gpu
+def test_short_workspace_and_disabled_option_are_the_plain_call():
+    B, H, N, D = 2, 10, 4096, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q, k, v = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(3))
+    o_pl, lse_pl, need = _fwd(q, k, v, "none")
+    assert need > 0
+    o_sm, lse_sm, _ = _fwd(q, k, v, "small")
+    assert torch.equal(o_sm.view(torch.int16), o_pl.view(torch.int16)) and torch.equal(lse_sm, lse_pl)
+    lib = _fa2_lib.load(build_if_missing=False)
+    with _fa2_lib.options(split=0):
+        assert lib.fa2_fwd_workspace_bytes(0, B, H, N, N, D, 0) == 0
+        o_off, lse_off, _ = _fwd(q, k, v, "ws")
+    assert torch.equal(o_off.view(torch.int16), o_pl.view(torch.int16)) and torch.equal(lse_off, lse_pl)
+    # shapes that never split: causal, exactly whole rounds, fewer items than CUs
+    assert lib.fa2_fwd_workspace_bytes(0, B, H, N, N, D, 1) == 0
+    assert lib.fa2_fwd_workspace_bytes(0, 2, 16, 4096, 4096, 128, 0) == 0
+    assert lib.fa2_fwd_workspace_bytes(0, 2, 20, 1024, 1024, 64, 0) == 0
+
+
+@pytest.mark.gpu
+def test_operator_and_compiled_front_end_take_the_split_path():
+    """FlashAttentionFunction.apply (compiled front end and Python front end) allocates the workspace itself; the result must be the
+    C-ABI's split result bit for bit, forward only and with a backward on top (the saved LSE is the merged one)."""
+    B, H, N, D = 2, 10, 4096, 64
+    g = torch.Generator(device="cpu").manual_seed(6)
+    q, k, v = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(3))
+    o_ws, lse_ws, need = _fwd(q, k, v, "ws")
+    assert need > 0
+    o_op = FlashAttentionFunction.apply(q, k, v, None, False)
+    assert torch.equal(o_op.view(torch.int16), o_ws.view(torch.int16))
+    ret = flash_attn_wmma.forward_py(q, k, v, 64, 128, False, D ** -0.5, False)
+    assert torch.equal(ret[0].view(torch.int16), o_ws.view(torch.int16)) and torch.equal(ret[5], lse_ws)
+    # backward through the split forward against float64 autograd on two heads
+    qg, kg, vg = (t[:1, :2].clone().requires_grad_(True) for t in (q, k, v))
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    oa = FlashAttentionFunction.apply(qa, ka, va, None, False)
+    do = torch.randn(oa.shape, generator=torch.Generator(device="cpu").manual_seed(7)).half().to(_dev())
+    oa.backward(do)
+    ref = torch.nn.functional.scaled_dot_product_attention(qg.double(), kg.double(), vg.double())
+    ref.backward(do[:1, :2].double())
+    for got, want in ((qa.grad, qg.grad), (ka.grad, kg.grad), (va.grad, vg.grad)):
+        err = float((got[:1, :2].double() - want.double()).abs().max())
+        assert err <= 2e-3 * max(1.0, float(want.abs().max())), err
+
+
+def test_workspace_query_validates_like_the_call():
+    """(CPU) the planning half of the call runs without a GPU: bad arguments give 0, and the size is what the header promises —
+    never more than 64 MiB, a function of the shape only."""
+    lib = _fa2_lib.load()
+    assert lib.fa2_fwd_workspace_bytes(7, 2, 10, 4096, 4096, 64, 0) == 0          # bad dtype
+    assert lib.fa2_fwd_workspace_bytes(0, 2, 10, 4096, 4096, 63, 0) == 0          # D not a multiple of 8
+    assert lib.fa2_fwd_workspace_bytes(0, 0, 10, 4096, 4096, 64, 0) == 0
+    for shape in [(2, 10, 4096, 4096, 64), (1, 24, 3072, 3072, 64), (1, 24, 4096, 4096, 128), (64, 16, 4096, 4096, 128), (1, 1, 70000, 4096, 64)]:
+        n = lib.fa2_fwd_workspace_bytes(0, *shape, 0)
+        assert n == lib.fa2_fwd_workspace_bytes(1, *shape, 0)
+        assert 0 <= n <= 64 * 2 ** 20 and n % 16 == 0

@@ -22,6 +22,29 @@ int launch_bwd_pair(const fa2::BwdParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// sum of the parts a split pass left in p.ws (bwd_merge_kernel): which = 1: dQ, 2: dK and dV
+template <int HD>
+int launch_merge(const fa2::BwdParams& p, int which, hipStream_t stream) {
+    if constexpr (HD <= 128) {
+        fa2::BwdMergeParams m;
+        m.ws = p.ws;
+        m.H = p.H; m.nbh = p.B * p.H; m.nblk = p.nblk; m.D = p.D;
+        m.full_items = p.full_items; m.split_items = p.split_items; m.nsplit = p.nsplit;
+        if (which == 1) {
+            m.out[0] = p.dq; m.out[1] = nullptr; m.mul[0] = p.scale; m.mul[1] = 0.f; m.nrows = p.Nq;
+            for (int i = 0; i < 3; ++i) { m.os[0][i] = p.dqs[i]; m.os[1][i] = 0; }
+        } else {
+            m.out[0] = p.dk; m.out[1] = p.dv; m.mul[0] = p.scale; m.mul[1] = 1.0f; m.nrows = p.Nkv;
+            for (int i = 0; i < 3; ++i) { m.os[0][i] = p.dks[i]; m.os[1][i] = p.dvs[i]; }
+        }
+        const int64_t threads = (int64_t)p.split_items * fa2::kSplitRows * (HD / 8);
+        hipLaunchKernelGGL((fa2::bwd_merge_kernel<HD, kBF16>), dim3((unsigned)((threads + 255) / 256), which == 1 ? 1 : 2), dim3(256), 0, stream, m);
+        return (int)hipGetLastError();
+    } else {
+        return FA2_ERR_HEAD_DIM;
+    }
+}
+
 // parts: bit 0 = the dQ pass (which also fills the delta workspace), bit 1 = the dK / dV pass(es)
 template <int HD, bool CAUSAL>
 int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
@@ -29,13 +52,26 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
     constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
     int rc;
+    // split of a partly filled last round (fa2_bwd_ws: the caller handed over scratch memory; fa2_launch.h has the plan)
+    fa2::SplitPlan sp_dq, sp_dkv;
+    if (p.ws && (reinterpret_cast<uintptr_t>(p.ws) & 15u) == 0) {
+        fa2::plan_bwd_split(HD, p, CAUSAL, &sp_dq, &sp_dkv);
+        if ((size_t)sp_dq.bytes > p.ws_bytes) sp_dq = fa2::SplitPlan();
+        if ((size_t)sp_dkv.bytes > p.ws_bytes) sp_dkv = fa2::SplitPlan();
+    }
+    p.nsplit = 0;
     // dQ: one workgroup per kRows Q rows; also writes D_i = rowsum(dO * O) to the delta workspace for the dK pass.
     // Grids that would cover at most half of the CUs with 256-row workgroups (SD-size training shapes) run as 128-row,
     // 4-wave workgroups instead — twice as many, one wave per SIMD each.
     bool dq_small = false;
     if constexpr (NW == 8) {
         const int forced = fa2::options().rows.load(std::memory_order_relaxed);      // option "rows" pins this shape too
-        dq_small = forced == 128 || (forced != 256 && (int64_t)p.B * p.H * ((p.Nq + 255) / 256) <= fa2::device_cus() / 2);
+        const int64_t w = (int64_t)p.B * p.H * ((p.Nq + 255) / 256), cus = fa2::device_cus();
+        // ... and, at head dims <= 64, grids of one to one and a half rounds of 256-row workgroups (the forward's short_second_round): measured
+        // (tools/bwd_rows_ab.py, whole backward) SDXL 64x64 B2 H10 N4096 428 -> 396 us, B1 H24 N3072 328 -> 300, N4096 430 -> 410, SD1.5 B3 H8 395 -> 371;
+        // at exactly one round (SD1.5 B2 H8: 218 vs 229) and at D = 80 (349 vs 365) the 8-wave shape stays ahead
+        dq_small = forced == 128 || (forced != 256 && (w <= cus / 2 || (HD <= 64 && w > cus && w <= cus + cus / 2)));
+        if (sp_dq.nsplit > 1) dq_small = false;      // the split last round balances better than smaller workgroups
     }
     if (!(parts & 1)) {
     } else if (dq_small) {
@@ -52,8 +88,17 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW>;
         if ((rc = fa2::set_lds<kern>(lds))) return rc;
         p.nblk = (p.Nq + kRows - 1) / kRows;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        int64_t grid = (int64_t)p.B * p.H * p.nblk;
+        if constexpr (NW == 8 && !CAUSAL) {
+            if (sp_dq.nsplit > 1) {
+                p.full_items = sp_dq.full_items; p.split_items = sp_dq.split_items; p.nsplit = sp_dq.nsplit;
+                grid = (int64_t)p.full_items + (int64_t)p.split_items * p.nsplit;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
+        if (p.nsplit > 1 && (rc = launch_merge<HD>(p, 1, stream))) return rc;
+        p.nsplit = 0;
     }
     if (!(parts & 2)) return 0;
     if constexpr (HD == 128) {
@@ -67,8 +112,16 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         constexpr int lds = kStages * (4 * TILEB + 512);
         constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true>;
         if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
-        return (int)hipGetLastError();
+        int64_t grid = (int64_t)p.B * p.H * p.nblk;
+        if constexpr (!CAUSAL) {
+            if (sp_dkv.nsplit > 1) {
+                p.full_items = sp_dkv.full_items; p.split_items = sp_dkv.split_items; p.nsplit = sp_dkv.nsplit;
+                grid = (int64_t)p.full_items + (int64_t)p.split_items * p.nsplit;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+        return p.nsplit > 1 ? launch_merge<HD>(p, 2, stream) : 0;
     } else {
         p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows, two sweeps
         {

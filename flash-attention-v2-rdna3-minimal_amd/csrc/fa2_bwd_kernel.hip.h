@@ -48,7 +48,26 @@ struct BwdParams {
     const void* bias;
     int64_t bs[3];
     int bias_kind;
+    // split of a partly filled last round of 256-row workgroups (fa2_bwd_ws; non-causal, unbiased, 8-wave kernels; FwdParams has the
+    // forward's twin): the last `split_items` workgroups of the pass being launched are each replaced by `nsplit` parts that sweep disjoint
+    // tile ranges and leave f32 partial accumulators in `ws`; bwd_merge_kernel sums them.  The launcher fills these per pass.
+    int full_items, split_items, nsplit;
+    float* ws;            // [split_items * nsplit] tiles of 256 x HD floats (the fused dK / dV pass: all dK tiles, then as many dV tiles)
+    size_t ws_bytes;      // what the caller handed over
 };
+
+// f32 partial accumulator tile of a part -> workspace.  Layout of a tile: float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e) for
+// d = 32dt + 8g + 4hi + e (the forward's partial O tiles: a wave's store instruction writes 1 KiB of consecutive bytes).
+template <int DT>
+__device__ __forceinline__ void store_partial_t(const f32x16 (&acc)[DT], float* tile, int row, int hi) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x16& a = acc[dt];
+            *(f32x4*)(tile + ((dt * 4 + g) * kSplitRows + row) * 8 + 4 * hi) = (f32x4){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        }
+}
 
 // log2-domain bias term of score (q, kv) of head (b, h): bias * log2(e), or -inf where a boolean keep-mask is zero.  One guarded load per
 // element (the bias may be broadcast with zero strides and have any alignment): a correct path for the SD hosts' masks, not a tuned one.
@@ -183,7 +202,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // block -> (head, q block): as in the forward kernel (causal: longest-first across heads)
-    const int nbh = p.B * p.H, bid = blockIdx.x;
+    const int nbh = p.B * p.H;
+    int bid = blockIdx.x;
+    // split last round: blocks [full_items, ...) are parts, part-major (fa2_fwd_kernel.hip.h has the forward's twin)
+    int part = -1, sidx = 0;
+    if constexpr (!CAUSAL && !BIAS && NW == 8 && HDV == HD) {
+        if (p.nsplit > 1 && bid >= p.full_items) {
+            const int j = bid - p.full_items;
+            part = j / p.split_items;
+            sidx = j % p.split_items;
+            bid = p.full_items + sidx;
+        }
+    }
     int bh, qblk;
     if ((nbh & 7) == 0) {
         const int slot = bid >> 3, hpx = nbh >> 3;
@@ -217,13 +247,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
     float Dq;
     {
         const uint16_t* orow = (const uint16_t*)p.o + b * p.os[0] + h * p.os[1] + (int64_t)qr * p.os[2];
-        float part = 0.f;
+        float dsum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (16 * ks + 8 * hi < p.D) part += dot8<BF16>(*(const u32x4*)(orow + 16 * ks + 8 * hi), gf[ks]);
+            if (16 * ks + 8 * hi < p.D) dsum += dot8<BF16>(*(const u32x4*)(orow + 16 * ks + 8 * hi), gf[ks]);
         }
-        Dq = half_swap_sum(part);
-        if (hi == 0 && qrow < p.Nq && vcol0 == 0) p.delta[b * p.ls[0] + h * p.ls[1] + qrow] = Dq;
+        Dq = half_swap_sum(dsum);
+        if (hi == 0 && qrow < p.Nq && vcol0 == 0 && part <= 0) p.delta[b * p.ls[0] + h * p.ls[1] + qrow] = Dq;
     }
 
     const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
@@ -365,14 +395,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
         }
     };
 
-    stage_load(0, 0);
+    int t_begin = 0;                       // a part sweeps its share of the whole KV tiles
+    if (part >= 0) { t_begin = part * ntiles / p.nsplit; ntiles = (part + 1) * ntiles / p.nsplit; }
+    stage_load(t_begin, 0);
     __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int st = DBUF ? tile & 1 : 0;
+    for (int tile = t_begin; tile < ntiles; ++tile) {
+        const int st = DBUF ? (tile - t_begin) & 1 : 0;
         if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);   // destination stage was last read before the previous barrier
         if (!CAUSAL || tile < ntiles_w) tile_body(tile, st, tile >= n_plain);   // (causal: a wave past its diagonal only keeps the barriers)
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
+    }
+    if constexpr (!CAUSAL && !BIAS && NW == 8 && HDV == HD) {
+        if (part >= 0) {                   // unscaled f32 partial dQ tile; bwd_merge_kernel sums the parts, scales and rounds once
+            store_partial_t<DT>(acc, p.ws + (int64_t)(sidx * p.nsplit + part) * kSplitRows * HD, 32 * wave + l31, hi);
+            return;
+        }
     }
     if (qrow < p.Nq) {
         uint16_t* op = (uint16_t*)p.dq + b * p.dqs[0] + h * p.dqs[1] + (int64_t)qrow * p.dqs[2];
@@ -408,7 +446,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // block -> (head, kv block); causal: the FIRST kv block sweeps the most Q tiles -> ascending kv block, across heads
-    const int nbh = p.B * p.H, bid = blockIdx.x;
+    const int nbh = p.B * p.H;
+    int bid = blockIdx.x;
+    int part = -1, sidx = 0;               // split last round (fused pass only): see bwd_dq_kernel
+    if constexpr (!CAUSAL && !BIAS && NW == 8 && BOTH) {
+        if (p.nsplit > 1 && bid >= p.full_items) {
+            const int j = bid - p.full_items;
+            part = j / p.split_items;
+            sidx = j % p.split_items;
+            bid = p.full_items + sidx;
+        }
+    }
     int bh, kblk;
     if ((nbh & 7) == 0) {
         const int slot = bid >> 3, hpx = nbh >> 3;
@@ -444,8 +492,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     const uint32_t q_rowb = (uint32_t)p.qs[2] * 2u, g_rowb = (uint32_t)p.dos[2] * 2u;
 
     // Q tiles that can touch this workgroup's KV rows: causal keeps only q >= kv (top-left aligned)
-    const int ntiles = (p.Nq + kKvTile - 1) / kKvTile;
-    const int tile0 = CAUSAL ? kv0 / kKvTile : 0;
+    int ntiles = (p.Nq + kKvTile - 1) / kKvTile;
+    int tile0 = CAUSAL ? kv0 / kKvTile : 0;
+    if (part >= 0) { tile0 = part * ntiles / p.nsplit; ntiles = (part + 1) * ntiles / p.nsplit; }   // a part sweeps its share of the Q tiles
     const int tile0_w = CAUSAL ? kvw0 / kKvTile : 0;     // this wave's first useful tile
 
     // per-lane source offsets of the staging loads within a tile (loop-invariant); the tile's own byte offset rides in soffset
@@ -626,6 +675,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
         if (!CAUSAL || tile >= tile0_w) tile_body(tile, st, CAUSAL && tile < first_plain);
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
+    }
+    if constexpr (!CAUSAL && !BIAS && NW == 8 && BOTH) {
+        if (part >= 0) {                   // unscaled f32 partial dK and dV tiles
+            const int64_t slot = sidx * p.nsplit + part, ntile = (int64_t)p.split_items * p.nsplit;
+            store_partial_t<DT>(acc, p.ws + slot * kSplitRows * HD, 32 * wave + l31, hi);
+            store_partial_t<DT>(accv, p.ws + (ntile + slot) * kSplitRows * HD, 32 * wave + l31, hi);
+            return;
+        }
     }
     if (kvrow < p.Nkv) {
         uint16_t* op = WANT_DK ? (uint16_t*)p.dk + b * p.dks[0] + h * p.dks[1] + (int64_t)kvrow * p.dks[2]
@@ -871,6 +928,43 @@ __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p)
                                : (uint16_t*)p.dv + b * p.dvs[0] + h * p.dvs[1] + (int64_t)kvrow * p.dvs[2];
         store_acc_t<BF16, DT>(acc, op, hi, ds_side ? p.scale : 1.0f, p.D);
     }
+}
+
+// Sum of the parts of a split backward pass (fa2_bwd_ws): out = round(mul * sum_i partial_i) for every row of a split item.  blockIdx.y
+// selects the tensor (the fused dK / dV pass leaves two sets of tiles).  One thread per (row, 8 output columns), as fwd_combine_kernel.
+struct BwdMergeParams {
+    const float* ws;
+    void* out[2];
+    int64_t os[2][3];        // element strides of the outputs: batch, head, row
+    float mul[2];
+    int H, nbh, nblk, nrows, D;
+    int full_items, split_items, nsplit;
+};
+
+template <int HD, bool BF16>
+__global__ __launch_bounds__(256) void bwd_merge_kernel(const BwdMergeParams p) {
+    constexpr int CPR = HD / 8;
+    const int t = blockIdx.x * 256 + threadIdx.x, which = blockIdx.y;
+    const int sidx = t / (kSplitRows * CPR), rem = t % (kSplitRows * CPR);
+    const int row = rem / CPR, c8 = rem % CPR;
+    if (sidx >= p.split_items) return;
+    const int bid = p.full_items + sidx;
+    int bh, blk;                         // the non-causal block order of bwd_dq_kernel / bwd_dkv_kernel
+    if ((p.nbh & 7) == 0) { const int slot = bid >> 3; bh = (bid & 7) + 8 * (slot / p.nblk); blk = slot % p.nblk; }
+    else { bh = bid / p.nblk; blk = bid % p.nblk; }
+    const int r = blk * kSplitRows + row;
+    if (r >= p.nrows || 8 * c8 >= p.D) return;
+    const float* w = p.ws + ((int64_t)which * p.split_items * p.nsplit + (int64_t)sidx * p.nsplit) * kSplitRows * HD + (c8 * kSplitRows + row) * 8;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < p.nsplit; ++i) {
+        const f32x4 lo = *(const f32x4*)(w + (int64_t)i * kSplitRows * HD), hi4 = *(const f32x4*)(w + (int64_t)i * kSplitRows * HD + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] += lo[e]; o[4 + e] += hi4[e]; }
+    }
+    const float m = p.mul[which];
+    const u32x4 w16 = {pack2<BF16>(o[0] * m, o[1] * m), pack2<BF16>(o[2] * m, o[3] * m), pack2<BF16>(o[4] * m, o[5] * m), pack2<BF16>(o[6] * m, o[7] * m)};
+    const int b = bh / p.H, h = bh % p.H;
+    *(u32x4*)((uint16_t*)p.out[which] + b * p.os[which][0] + h * p.os[which][1] + (int64_t)r * p.os[which][2] + 8 * c8) = w16;
 }
 
 }  // namespace fa2

@@ -26,6 +26,37 @@ struct Options {
 FA2_HIDDEN Options& options();
 FA2_HIDDEN int device_cus();           // compute units of the current device (cached per device index)
 
+// KV-split (forward, dQ pass) / Q-split (dK-dV pass) of a partly filled last round of 256-row workgroups: `items` equal workgroups on
+// `cus` CUs take ceil(items / cus) rounds however empty the last one is.  With scratch memory from the caller the r = items % cus items of
+// that round are swept by S workgroups each ("parts") over disjoint tile ranges, which leave f32 partial tiles that a small kernel merges.
+// S in 2..kMaxSplit minimises rounds(r * S) / S + the scheme's fixed costs, in units of one whole item:
+//   an item sweeps `nt` tiles at `us_per_tile` each; the merge kernel, its launch and a part's own prologue / epilogue cost `fixed_us`;
+//   the partial tiles (`tile_bytes` per part) cross memory twice at ~4 TB/s through L2 / Infinity Cache.
+// Parts get at least 8 tiles, the workspace never exceeds 64 MiB, and a split must win at least 7 % of the last round.
+struct SplitPlan { int full_items = 0, split_items = 0, nsplit = 0; int64_t bytes = 0; };
+constexpr int64_t kMaxSplitWsBytes = 64ll << 20;
+
+inline SplitPlan plan_tail_split(int64_t items, int nt, double us_per_tile, double fixed_us, int64_t tile_bytes, int64_t cus) {
+    SplitPlan none;
+    if (items <= cus || items > 0x7fffffffLL || cus <= 0) return none;
+    const int64_t r = items % cus;
+    if (r == 0) return none;
+    const double t_item = nt * us_per_tile, fixed = fixed_us / t_item;
+    double best = 0.93;
+    SplitPlan pl;
+    for (int S = 2; S <= kMaxSplit; ++S) {
+        if (nt / S < 8) break;
+        const int64_t bytes = r * S * tile_bytes;
+        if (bytes > kMaxSplitWsBytes) break;
+        const double cost = (double)((r * S + cus - 1) / cus) / S + fixed + 2.0 * bytes / 4.0e6 / t_item;
+        if (cost < best) { best = cost; pl.nsplit = S; pl.bytes = bytes; }
+    }
+    if (!pl.nsplit) return none;
+    pl.full_items = (int)(items - r);
+    pl.split_items = (int)r;
+    return pl;
+}
+
 // Kernels that need more than 64 KiB of dynamic LDS must be opted in once per (kernel, device).  The cache is keyed on
 // the kernel itself (a non-type template parameter: one flag array per instantiation, not per function-pointer type).
 template <auto Kernel>
@@ -49,6 +80,20 @@ FA2_HIDDEN int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t st
 FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream);
 // hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
 FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
+// Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
+// dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).
+// Tile costs (us per 64-row tile of a 256-row workgroup, 8-wave HIP kernels): dQ pass 3 GEMMs, fused dK / dV pass 4 — 1.5x / 2x the forward's 0.9 * HD / 64.
+inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan* dq, SplitPlan* dkv) {
+    *dq = SplitPlan();
+    *dkv = SplitPlan();
+    if (causal || p.bias_kind != 0 || HD > 128 || !options().split.load(std::memory_order_relaxed)) return 0;
+    if (options().rows.load(std::memory_order_relaxed) == 128) return 0;
+    if (HD == 128 && p.D == 128 && (options().asm_mask.load(std::memory_order_relaxed) & 2)) return 0;      // the hand-scheduled passes
+    const int64_t cus = device_cus(), bh = (int64_t)p.B * p.H, tile_bytes = (int64_t)kSplitRows * HD * 4;
+    *dq = plan_tail_split(bh * ((p.Nq + 255) / 256), (p.Nkv + kKvTile - 1) / kKvTile, 1.35 * HD / 64.0, 10.0, tile_bytes, cus);
+    if (HD <= 64) *dkv = plan_tail_split(bh * ((p.Nkv + 255) / 256), (p.Nq + kKvTile - 1) / kKvTile, 1.8 * HD / 64.0, 10.0, 2 * tile_bytes, cus);
+    return dq->bytes > dkv->bytes ? dq->bytes : dkv->bytes;
+}
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);

@@ -129,44 +129,22 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
 // partial results (fa2_fwd_kernel.hip.h).  S minimises rounds(r * S) / S plus the fixed cost of the scheme, in units of one whole item:
 //   an item sweeps nt KV tiles at ~0.9 us * HD / 64 each (measured: D = 64 N4096 60 us, D = 128 112 us per 256-row item);
 //   the merge kernel, its launch and a part's own prologue / epilogue cost ~10 us (+ ~4 us for the extra launch of the D = 128 path);
-//   the f32 partial tiles cross memory twice.  The workspace never exceeds 64 MiB.
-struct SplitPlan { int full_items = 0, split_items = 0, nsplit = 0; };
-constexpr int64_t kMaxSplitWsBytes = 64ll << 20;
-
-SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool causal) {
-    SplitPlan none;
+//   the f32 partial tiles cross memory twice.  The workspace never exceeds 64 MiB (fa2::plan_tail_split, fa2_launch.h).
+fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool causal) {
+    fa2::SplitPlan none;
     if (causal || p.bias_kind != FA2_BIAS_NONE || HD > 128 || !fa2::options().split.load(std::memory_order_relaxed)) return none;
     const int f = forced_rows();
     if (f == 128 || p.rows_hint == 128) return none;
-    const int64_t cus = fa2::device_cus(), nq = (p.Nq + kFwdRows - 1) / kFwdRows, items = (int64_t)p.nbh * nq;
-    if (items <= cus || items > 0x7fffffffLL) return none;
-    const int64_t r = items % cus;
-    if (r == 0) return none;
+    const int64_t items = (int64_t)p.nbh * ((p.Nq + kFwdRows - 1) / kFwdRows);
     const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
-    const double t_item = nt * 0.9 * HD / 64.0, fixed = (HD == 128 ? 14.0 : 10.0) / t_item;
-    double best = 0.93;          // the plain launch's last round costs 1.0; a split must win at least 7 %
-    int best_s = 0;
-    for (int S = 2; S <= fa2::kMaxSplit; ++S) {
-        if (nt / S < 8) break;   // parts of fewer than 8 tiles are mostly prologue
-        const int64_t bytes = fa2::split_ws_bytes((int)r, S, HD);
-        if (bytes > kMaxSplitWsBytes) break;
-        // + the partial tiles' trip through memory (written by the parts, read by the merge; ~4 TB/s effective through L2 / Infinity Cache)
-        const double cost = (double)((r * S + cus - 1) / cus) / S + fixed + 2.0 * bytes / 4.0e6 / t_item;
-        if (cost < best) { best = cost; best_s = S; }
-    }
-    if (!best_s) return none;
-    SplitPlan pl;
-    pl.full_items = (int)(items - r);
-    pl.split_items = (int)r;
-    pl.nsplit = best_s;
-    return pl;
+    return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, HD == 128 ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
 }
 
 bool asm_d128_ok(int HD, const fa2::FwdParams& p) { return HD == 128 && p.D == 128 && !p.negate_q && asm_fwd() && asm_q_span_ok(p); }
 
 int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
     if (ws) {
-        const SplitPlan pl = plan_split(p0, HD, causal);
+        const fa2::SplitPlan pl = plan_split(p0, HD, causal);
         if (pl.nsplit > 1 && (int64_t)ws_bytes >= fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD) && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
             fa2::FwdParams p = p0;
             p.rows_hint = 256;
@@ -371,7 +349,7 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal != 0, 128, true, stream) : fa2::launch_fwd_hip_f16(HD, p, causal != 0, 128, true, stream);
     }
     if (ws_need) {      // fa2_fwd_workspace_bytes: validate and plan only
-        const SplitPlan pl = plan_split(p, HD, causal != 0);
+        const fa2::SplitPlan pl = plan_split(p, HD, causal != 0);
         if (pl.nsplit > 1) *ws_need = (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD);
         return FA2_OK;
     }
@@ -419,7 +397,9 @@ static int bwd_impl(int dtype, const void* q, const void* k, const void* v, cons
             const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
             const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
-            int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream) {
+            int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
+            void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr) {
+    if (ws_need) *ws_need = 0;
     if (bias_kind != FA2_BIAS_NONE) {
         if (bias_kind != FA2_BIAS_IO_DTYPE && bias_kind != FA2_BIAS_F32 && bias_kind != FA2_BIAS_BOOL) return FA2_ERR_BIAS;
         if (!bias || !bias_strides) return FA2_ERR_NULL_POINTER;
@@ -464,6 +444,14 @@ static int bwd_impl(int dtype, const void* q, const void* k, const void* v, cons
     p.bias = bias;
     p.bias_kind = bias_kind;
     for (int i = 0; i < 3; ++i) p.bs[i] = bias_kind != FA2_BIAS_NONE ? bias_strides[i] : 0;
+    p.full_items = p.split_items = p.nsplit = 0;
+    p.ws = (float*)ws;
+    p.ws_bytes = ws_bytes;
+    if (ws_need) {      // fa2_bwd_workspace_bytes: validate and plan only
+        fa2::SplitPlan a, b2;
+        *ws_need = (size_t)fa2::plan_bwd_split(HD, p, causal != 0, &a, &b2);
+        return FA2_OK;
+    }
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool bf16 = dtype == FA2_DTYPE_BF16;
     if (bias_kind != FA2_BIAS_NONE)
@@ -479,6 +467,28 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
             int causal, void* hip_stream) {
     return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,
                     do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream);
+}
+
+int fa2_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+               void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
+               const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+               const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+               const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
+               int causal, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,
+                    do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream,
+                    workspace, workspace_bytes);
+}
+
+size_t fa2_bwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal) {
+    static const int64_t one[3] = {8, 8, 8};
+    alignas(16) static char dummy[16];
+    const int64_t ls[2] = {0, 0};
+    size_t need = 0;
+    if (bwd_impl(dtype, dummy, dummy, dummy, dummy, dummy, (const float*)dummy, dummy, dummy, dummy, (float*)dummy, B, H, Nq, Nkv, D, one, one, one, one,
+                 one, one, one, one, ls, 1.0f, causal, nullptr, FA2_BIAS_NONE, nullptr, nullptr, nullptr, 0, &need) != FA2_OK)
+        return 0;
+    return need;
 }
 
 int fa2_bwd_bias(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

@@ -186,6 +186,22 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
             float scale, int causal, void* hip_stream);
 
 /*
+ * Backward with a caller-owned workspace: fa2_bwd plus scratch memory, the backward's twin of fa2_fwd_ws.  With it the last, partly filled
+ * round of 256-row workgroups of the dQ pass (head dims <= 128, compiler-scheduled kernels) and of the fused dK / dV pass (head dims <= 64)
+ * is split into parts that sweep disjoint tile ranges and leave f32 partial accumulators in the workspace; a small kernel sums them, applies
+ * `scale` and rounds once (the split changes the f32 summation order of those rows, nothing else).  Non-causal calls; everything else, and any
+ * call whose workspace is NULL or too small, is exactly fa2_bwd.  fa2_bwd_workspace_bytes: as fa2_fwd_workspace_bytes (<= 64 MiB, 0 for most shapes).
+ */
+int fa2_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+               void* dq, void* dk, void* dv, float* delta_ws,
+               int B, int H, int Nq, int Nkv, int D,
+               const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+               const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+               const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
+               float scale, int causal, void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t fa2_bwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal);
+
+/*
  * Backward through fa2_fwd_bias: the gradients of O = softmax(scale * Q K^T + bias [+ causal mask]) V with respect to Q, K, V (the bias /
  * mask itself is a constant of the call: it receives no gradient).  o and lse are the outputs of the fa2_fwd_bias call with the SAME bias
  * arguments; fully masked rows (lse = -inf) contribute nothing.  Arguments as fa2_bwd plus the bias triple of fa2_fwd_bias.
@@ -230,7 +246,7 @@ int fa2_fwd_prescales_q(int D, float scale);
  *                              bodies (head dim 128), bits 2 / 3: ... except its dQ pass / its dK-dV pass, bit 4: the head-dim-64
  *                              forward body for non-causal launches too (default: causal only); default 3.  0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
- *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws may split the last round of workgroups along KV (0: it is fa2_fwd)
+ *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws / fa2_bwd_ws may split the last round of workgroups (0: they are fa2_fwd / fa2_bwd)
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

@@ -178,3 +178,100 @@ def test_workspace_query_validates_like_the_call():
         n = lib.fa2_fwd_workspace_bytes(0, *shape, 0)
         assert n == lib.fa2_fwd_workspace_bytes(1, *shape, 0)
         assert 0 <= n <= 64 * 2 ** 20 and n % 16 == 0
+
+
+# ---------------------------------------------------------------- backward: fa2_bwd_ws
+
+def _fwd_bwd(q, k, v, do, ws_mode, bnhd=False):
+    """forward (plain) + backward through the C-ABI; ws_mode 'none' -> fa2_bwd, 'ws' -> fa2_bwd_ws with a NaN-filled workspace of the advertised size."""
+    lib = _fa2_lib.load(build_if_missing=False)
+    if bnhd:
+        B, N, H, D = q.shape
+        Nkv = k.shape[1]
+    else:
+        B, H, N, D = q.shape
+        Nkv = k.shape[2]
+    dt = 0 if q.dtype == torch.float16 else 1
+    scale = float(D ** -0.5)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    delta = torch.empty_like(lse)
+    dq, dk, dv = (torch.full_like(t, float("nan")) for t in (q, k, v))
+    s2 = _fa2_lib.strides2(lse.stride(0), lse.stride(1))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _fa2_lib.check(lib.fa2_fwd(dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, Nkv, D,
+                               _s3(q, bnhd), _s3(k, bnhd), _s3(v, bnhd), _s3(o, bnhd), s2, scale, 0, stream))
+    args = (dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+            delta.data_ptr(), B, H, N, Nkv, D, _s3(q, bnhd), _s3(k, bnhd), _s3(v, bnhd), _s3(o, bnhd), _s3(do, bnhd), _s3(dq, bnhd), _s3(dk, bnhd),
+            _s3(dv, bnhd), s2, scale, 0)
+    need = lib.fa2_bwd_workspace_bytes(dt, B, H, N, Nkv, D, 0)
+    if ws_mode == "none":
+        rc = lib.fa2_bwd(*args, stream)
+    else:
+        ws = torch.full(((need + 3) // 4 + 4,), float("nan"), dtype=torch.float32, device=q.device)
+        rc = lib.fa2_bwd_ws(*args, ws.data_ptr(), need, stream)
+    _fa2_lib.check(rc)
+    torch.cuda.synchronize()
+    return o, lse, (dq, dk, dv), need
+
+
+BWD_SPLIT_SHAPES = [
+    (2, 10, 4096, 4096, 64, 0, False),      # SDXL 64x64: dQ pass and fused dK / dV pass both 320 workgroups
+    (1, 24, 3072, 3072, 64, 1, False),      # bf16, 288 workgroups
+    (3, 8, 4096, 4096, 40, 0, False),       # SD1.5's head dim on the D = 64 kernels, 384 workgroups
+    (2, 20, 2048, 2048, 80, 0, False),      # D = 80 on the D = 128 HIP kernels: only the dQ pass splits (dK / dV run as wave pairs)
+    (2, 10, 4000, 3990, 64, 0, False),      # ragged Nq and Nkv
+    (1, 40, 2048, 4096, 64, 0, True),       # Nkv != Nq: the passes get different plans; BNHD
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", BWD_SPLIT_SHAPES)
+def test_split_backward_against_oracle_autograd_and_plain_call(shape):
+    from conftest import GRAD_TOL
+    B, H, N, Nkv, D, dt, bnhd = shape
+    g = torch.Generator(device="cpu").manual_seed(2000 + H + D)
+    mk = lambda n: torch.randn(((B, n, H, D) if bnhd else (B, H, n, D)), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(N), mk(Nkv), mk(Nkv), mk(N)
+    o, lse, gw, need = _fwd_bwd(q, k, v, do, "ws", bnhd)
+    assert need > 0, "the shape is meant to be split on a 256-CU device"
+    _, _, gp, _ = _fwd_bwd(q, k, v, do, "none", bnhd)
+    for name, a, b_ in zip("qkv", gw, gp):
+        assert torch.isfinite(a.float()).all(), "d%s has non-finite values (a part of the workspace was read before it was written?)" % name
+        # the split changes the f32 summation order of the split rows only: one rounding of the I/O dtype at the gradient's scale
+        tol = (2.0 ** -10 if dt == 0 else 2.0 ** -7) * max(1.0, float(b_.float().abs().max()))
+        assert float((a.float() - b_.float()).abs().max()) <= tol, name
+    # the oracle and float64 autograd on heads of the unsplit rounds and of the split tail
+    for (b, h) in {(0, 0), (B - 1, H - 1), (B - 1, H - 2)}:
+        sl = (lambda t: t[b:b + 1, :, h:h + 1].transpose(1, 2).contiguous()) if bnhd else (lambda t: t[b:b + 1, h:h + 1].contiguous())  # noqa: E731
+        qs, ks, vs, dos, os_ = (sl(t) for t in (q, k, v, do, o))
+        want = fo.bwd_c(_bits(qs), _bits(ks), _bits(vs), _bits(os_), _bits(dos), lse[b:b + 1, h:h + 1].cpu().numpy(), dt, False)
+        for name, gt, w_bits in zip("qkv", gw, want):
+            w = fo.bits_to_f32(w_bits, dt)
+            got = sl(gt).float().cpu().numpy()
+            assert np.abs(got - w).max() <= GRAD_TOL[dt] * max(1.0, np.abs(w).max()), (name, (b, h), np.abs(got - w).max())
+        qd, kd, vd = (sl(t).double().requires_grad_(True) for t in (q, k, v))
+        torch.nn.functional.scaled_dot_product_attention(qd, kd, vd).backward(dos.double())
+        for name, gt, w in zip("qkv", gw, (qd.grad, kd.grad, vd.grad)):
+            err = float((sl(gt).double() - w).abs().max())
+            assert err <= GRAD_TOL[dt] * max(1.0, float(w.abs().max())), (name, (b, h), err)
+
+
+@pytest.mark.gpu
+def test_operator_backward_takes_the_split_path_and_option_turns_it_off():
+    B, H, N, D = 2, 10, 4096, 64
+    g = torch.Generator(device="cpu").manual_seed(8)
+    q, k, v, do = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(4))
+    _, _, gw, need = _fwd_bwd(q, k, v, do, "ws")
+    assert need > 0
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    with _fa2_lib.options(split=0):         # the same forward for both (the split forward's O differs by f32 rounding of the merge)
+        oa = FlashAttentionFunction.apply(qa, ka, va, None, False)
+    oa.backward(do)
+    for a, b_ in zip(gw, (qa.grad, ka.grad, va.grad)):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+    lib = _fa2_lib.load(build_if_missing=False)
+    with _fa2_lib.options(split=0):
+        assert lib.fa2_bwd_workspace_bytes(0, B, H, N, N, D, 0) == 0
+    assert lib.fa2_bwd_workspace_bytes(0, B, H, N, N, D, 1) == 0                  # causal
+    assert lib.fa2_bwd_workspace_bytes(0, 2, 16, 4096, 4096, 128, 0) == 0         # the hand-scheduled passes

@@ -178,6 +178,10 @@ def VF_CT(dt, ks):
     return V(144 + 16 * ks + 4 * dt, 4) if ks < 2 else A(224 + 16 * (ks - 2) + 4 * dt, 4)
 
 
+def VF64(dt, ks):                                  # head dim 64 with "ct": two d blocks per k-step, packed (v[144:175]) so that v[176:207] hold the C tuples
+    return V(144 + 8 * ks + 4 * dt, 4)
+
+
 WEIGHT = sched.WEIGHT
 _weight = sched.weight
 set_weights = sched.set_weights
@@ -211,9 +215,12 @@ class Gen:
         self.ct = "ct" in self.opt        # folded scale: Q * c rounded once, -m enters the first QK^T k-step as its C operand (no extra MFMAs)
         self.fold = self.ct               # prescaled Q, S leaves the MFMA as (score - reference)
         g = self.g
-        assert hd == 128 or not (self.opt & {"ct", "vagpr", "ctk64"}), "the folded-scale / probe register maps exist for head dim 128 only"
-        self.kf = KF_POOL if (self.ct and "ctk64" not in self.opt) else (lambda kvb, ks: KF(kvb, ks, g))      # ctk64: timing probe (K and V^T fragments collide)
-        self.vf = VF_CT if self.ct else VF
+        assert hd == 128 or not (self.opt & {"vagpr", "ctk64"}), "the probe register maps exist for head dim 128 only"
+        # head dim 128 + "ct": the C tuples take v[176:207], so V^T k-steps 2-3 move to a[224:255] and the K fragments shrink to a 32-register pool;
+        # head dim 64 has the room (half the V^T fragments, half the accumulator file): only the V^T fragments are packed
+        self.pool = self.ct and hd == 128 and "ctk64" not in self.opt
+        self.kf = KF_POOL if self.pool else (lambda kvb, ks: KF(kvb, ks, g))      # ctk64: timing probe (K and V^T fragments collide)
+        self.vf = (VF_CT if hd == 128 else VF64) if self.ct else VF
         self.qf = lambda qb, ks: QF(qb, ks, g)
         self.oacc = lambda qb, dt: OACC(qb, dt, g)
         if "vagpr" in self.opt:
@@ -384,8 +391,9 @@ class Gen:
         if not first:
             r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
         r.append(mk("s_nop", 0))
-        r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
-        r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
+        if not self.lmfma:      # (with the row sums in the accumulator file they are rescaled with O, at the phase boundary)
+            r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
+            r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
         r.append(mk("v_mov_b32", FSC[qb], t2))
         r.append(mk("s_nop", 1))
         r.append(mk("s_branch", Label(lab + "_ret")))
@@ -514,7 +522,7 @@ class Gen:
         if dma and "dma" not in abl:
             grp = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
             self.place(load, slots, grp, cfg["dma"][0], cfg["dma"][1], 2)
-        if s2 and "kread" not in abl and self.ct and "ctk64" not in self.opt:
+        if s2 and "kread" not in abl and self.pool:
             # 32-register fragment pool: k-steps 0..3 are read during the PV phase, k-step ks >= 4 goes into the slot of ks - 4
             # as soon as the four MFMAs of that k-step are issued (12 MFMAs ahead of its own first use)
             kr = self.stream_kread(par)
@@ -595,7 +603,7 @@ class Gen:
                 p.ins.append(mf[g])
             for (_, _, item) in slots[g]:
                 p.ins.extend(item if isinstance(item, list) else [item])
-        if self.ct:
+        if self.pool:
             p.ins[body_start:] = self.lds_waits(p.ins[body_start:])
         # end of body: DMA landed, my LDS reads done, then everybody
         p.emit("s_add_u32", S_T, S_T, 1)
@@ -687,14 +695,15 @@ class Gen:
         else:
             # folded scale: Q comes through the (still unused) S banks, is multiplied by c in f32 and rounded back ONCE —
             # the reference oracle's contract `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file
-            qv = V(VBASE, 64)
+            nq = 4 * g.NKS              # registers of one q block's fragments
+            qv = V(VBASE, 2 * nq)
             for qb in range(2):
-                for ks in range(8):
-                    p.emit("global_load_dwordx4", qv.sub(32 * qb + 4 * ks, 4), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
+                for ks in range(g.NKS):
+                    p.emit("global_load_dwordx4", qv.sub(nq * qb + 4 * ks, 4), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
             p.emit("s_branch", Label("q_issued"))
             p.label("have_q")
-            for i in range(64):       # prefetched raw Q sits in the fragment registers: back through the S banks for the prescale
-                qreg = self.qf(i // 32, (i % 32) // 4)[i % 4]
+            for i in range(2 * nq):       # prefetched raw Q sits in the fragment registers: back through the S banks for the prescale
+                qreg = self.qf(i // nq, (i % nq) // 4)[i % 4]
                 p.emit("v_accvgpr_read_b32" if qreg.kind == "a" else "v_mov_b32", V(VBASE + i), qreg)
             p.label("q_issued")
         # DMA source offsets of piece i: rows 4*i further down, the K granule swizzle follows the row (xor i<<6), and the
@@ -769,14 +778,14 @@ class Gen:
                 # the 16 Q loads were issued first: K(0), V(0) and K(1) (12 or 8 pieces behind them) keep flying during the prescale
                 p.emit("s_cmp_lt_i32", A_NTWG, 2)
                 p.emit("s_cbranch_scc1", Label("qwait8"))
-                p.emit("s_waitcnt", vmcnt=12)
+                p.emit("s_waitcnt", vmcnt=3 * g.NP)
                 p.emit("s_branch", Label("qwaited"))
                 p.label("qwait8")
-                p.emit("s_waitcnt", vmcnt=8)
+                p.emit("s_waitcnt", vmcnt=2 * g.NP)
                 p.label("qwaited")
             else:
                 p.emit("s_waitcnt", vmcnt=0)                        # the 16 Q loads (and the staged tiles behind them)
-            for i in range(64):
+            for i in range(8 * g.NKS):
                 src, t0, t1 = V(VBASE + i), TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]
                 if self.bf16:
                     p.emit("v_lshlrev_b32", t0, 16, src)
@@ -790,7 +799,7 @@ class Gen:
                 p.emit("s_nop", 0)
                 p.emit(self.cvt, t0, t0, t1)
                 p.emit("s_nop", 0)
-                qreg = self.qf(i // 32, (i % 32) // 4)[i % 4]
+                qreg = self.qf(i // (4 * g.NKS), (i % (4 * g.NKS)) // 4)[i % 4]
                 p.emit("v_accvgpr_write_b32" if qreg.kind == "a" else "v_mov_b32", qreg, t0)
             if not (self.ct and early):
                 p.emit("s_waitcnt", vmcnt=0)
@@ -1019,10 +1028,19 @@ def main():
     if is_probe(cfg) and not a.probe:
         sys.exit("fwd_d128_gen.py: %r contains timing-probe options; they need --probe and must not go into the product build" % a.opt)
     for hd in (128, 64):
-        if hd == 64 and any(o in ("ct",) + PROBE_OPTS for o in cfg.get("opt", ())):
+        if hd == 64 and any(o in PROBE_OPTS for o in cfg.get("opt", ())):
             continue
         for bf16 in (False, True):
-            g = Gen(bf16, hd=hd, **cfg)
+            c = dict(cfg)
+            opts = tuple(o for o in cfg.get("opt", ()) if o != "f32scale64")
+            # Head dim 64, fp16: the shipped body folds the scale into Q ("ct": Q * scale*log2e rounded once to fp16 — the scaling contract of the
+            # reference's own oracle, pure_torch_ver.py:61 — and the running reference enters the first QK^T k-step as its C operand): the 66
+            # v_fma_f32 per tile leave a body that runs at its issue bound.  bf16 keeps the f32 scale (its 8-bit mantissa
+            # would cost 6e-3 of LSE); opt=f32scale64 builds the unfolded fp16 body (A/B runs, tools/kbench.py).
+            if hd == 64 and not bf16 and "f32scale64" not in cfg.get("opt", ()) and "ct" not in opts:
+                opts += ("ct",)
+            c["opt"] = opts
+            g = Gen(bf16, hd=hd, **c)
             prog = g.build()
             path = os.path.join(out_dir, "fa2_fwd_d%d_%s.inc" % (hd, "bf16" if bf16 else "f16"))
             write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))

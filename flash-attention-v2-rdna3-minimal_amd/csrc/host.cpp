@@ -116,7 +116,8 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     // issues that VALU-bound mix no faster than the two waves of the compiler-scheduled 8-wave kernel: same box (tools/fwd_ab.py) B2 H16
     // N4096 933 vs 947 TF, B1 H24 N8192 1032 vs 1022, causal bf16 917 vs 869 — so it takes the causal launches (+5.5 %) only; option
     // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
-    const bool d64_asm = HD == 64 && (causal || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    // (round 3) fp16: the generated body folds the scale into Q and then beats the 8-wave kernel non-causal too, so every fp16 launch takes it.
+    const bool d64_asm = HD == 64 && (causal || !bf16 || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
     if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p))
         return fa2::launch_fwd_asm(HD, bf16, p, causal, stream);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
@@ -130,28 +131,33 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
 //   an item sweeps nt KV tiles at ~0.9 us * HD / 64 each (measured: D = 64 N4096 60 us, D = 128 112 us per 256-row item);
 //   the merge kernel, its launch and a part's own prologue / epilogue cost ~10 us (+ ~4 us for the extra launch of the D = 128 path);
 //   the f32 partial tiles cross memory twice.  The workspace never exceeds 64 MiB (fa2::plan_tail_split, fa2_launch.h).
-fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool causal) {
+fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causal) {
     fa2::SplitPlan none;
     if (causal || p.bias_kind != FA2_BIAS_NONE || HD > 128 || !fa2::options().split.load(std::memory_order_relaxed)) return none;
     const int f = forced_rows();
     if (f == 128 || p.rows_hint == 128) return none;
     const int64_t items = (int64_t)p.nbh * ((p.Nq + kFwdRows - 1) / kFwdRows);
     const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
-    return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, HD == 128 ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
+    // whole rounds on the hand-scheduled persistent kernel (head dim 128; head dim 64 in fp16): the parts need a launch of their own
+    const bool asm_rounds = HD == 128 || (HD == 64 && !bf16 && p.D == 64);
+    return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, asm_rounds ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
 }
 
-bool asm_d128_ok(int HD, const fa2::FwdParams& p) { return HD == 128 && p.D == 128 && !p.negate_q && asm_fwd() && asm_q_span_ok(p); }
+// non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 in fp16 (launch_range)
+bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
+    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p);
+}
 
 int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
     if (ws) {
-        const fa2::SplitPlan pl = plan_split(p0, HD, causal);
+        const fa2::SplitPlan pl = plan_split(p0, HD, bf16, causal);
         if (pl.nsplit > 1 && (int64_t)ws_bytes >= fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD) && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
             fa2::FwdParams p = p0;
             p.rows_hint = 256;
             p.full_items = pl.full_items; p.split_items = pl.split_items; p.nsplit = pl.nsplit;
             p.ws = (float*)ws;
             int rc;
-            if (asm_d128_ok(HD, p) && pick_rows(p, causal) == 256) {
+            if (asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256) {
                 // whole rounds on the hand-scheduled persistent kernel (every workgroup gets the same number of items), then the parts
                 fa2::FwdParams pa = p;
                 pa.item_cap = pl.full_items;
@@ -229,8 +235,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 }
 
 int fa2_fwd_prescales_q(int D, float scale) {
-    (void)scale;
-    return fa2_padded_head_dim(D) < 0 ? -1 : 0;
+    if (fa2_padded_head_dim(D) < 0) return -1;
+    return D == 64 && scale > 0.f ? 1 : 0;      // the fp16 launches that take the hand-scheduled head-dim-64 body (launch_range)
 }
 
 int fa2_set_option(const char* name, int value) {
@@ -349,7 +355,7 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal != 0, 128, true, stream) : fa2::launch_fwd_hip_f16(HD, p, causal != 0, 128, true, stream);
     }
     if (ws_need) {      // fa2_fwd_workspace_bytes: validate and plan only
-        const fa2::SplitPlan pl = plan_split(p, HD, causal != 0);
+        const fa2::SplitPlan pl = plan_split(p, HD, dtype == FA2_DTYPE_BF16, causal != 0);
         if (pl.nsplit > 1) *ws_need = (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD);
         return FA2_OK;
     }

@@ -93,12 +93,16 @@ D64_CASES = [
 ]
 
 
-@pytest.fixture
-def hd64():
-    saved = harness.HD
-    harness.HD = 64
-    yield
-    harness.HD = saved
+@pytest.fixture(params=[(), ("ct",)], ids=["f32-scale", "folded-scale"])
+def hd64(request):
+    """Both head-dim-64 bodies: the library ships the folded-scale one for fp16 (Q * scale*log2e rounded once to fp16, pure_torch_ver.py:61;
+    the reference maximum enters the first QK^T k-step as its C operand) and the f32-scale one for bf16; either is a correct body in both dtypes."""
+    saved = harness.HD, harness.OPT
+    harness.HD, harness.OPT = 64, request.param
+    harness._PROGS.clear()
+    yield request.param
+    harness.HD, harness.OPT = saved
+    harness._PROGS.clear()
 
 
 @pytest.mark.parametrize("case", D64_CASES)
@@ -117,12 +121,12 @@ def test_d64_persistent_items_and_causal_pairs(hd64):
     outs, m = harness.run_items(items, False)
     assert not m.errors, m.errors[:5]
     for (q, k, v, qb), (o, lse) in zip(items, outs):
-        o_ref, _ = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256)
+        o_ref, _ = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256, pre=bool(hd64))
         assert np.abs(o - o_ref).max() <= 1e-3
     q, k, v = (rng.standard_normal((1024, 64)) for _ in range(3))
     outs, m = harness.run_items([(q, k, v, 3), (q, k, v, 0)], True)
     assert not m.errors, m.errors[:5]
-    o_ref, _ = harness.dense(q, k, v, True)
+    o_ref, _ = harness.dense(q, k, v, True, pre=bool(hd64))
     for qb, (o, _) in zip([3, 0], outs):
         assert np.abs(o - o_ref[qb * 256:qb * 256 + 256]).max() <= 1e-3
 
@@ -190,7 +194,7 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     subst = {0: "v0", 1: "v1", 2: "v2", 3: "v3", 4: "s[0:1]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
              12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
              23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]"}
-    for bf16, hd in ((False, 128), (True, 128)) + (((False, 64), (True, 64)) if not opt else ()):
+    for bf16, hd in ((False, 128), (True, 128), (False, 64), (True, 64)):
         text = "\n".join(gen.Gen(bf16, hd=hd, opt=opt).build().text_lines())
         text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))
         src = tmp_path / ("body_%d_%d.s" % (bf16, hd))

@@ -49,7 +49,8 @@ def _cabi_forward(q, k, v, causal, scale=None):
 
 
 def _oracle_flags(D, scale=None):
-    """The oracle mode that matches the kernel's scaling contract for this head dim and scale."""
+    """PRESCALE_Q if launches of this head dim may fold the scale into Q (fa2_fwd_prescales_q: head dim 64 with a positive scale — the fp16
+    launches that take the hand-scheduled body do), else 0."""
     lib = _fa2_lib.load(build_if_missing=False)
     pre = lib.fa2_fwd_prescales_q(D, float(D ** -0.5 if scale is None else scale))
     assert pre in (0, 1)
@@ -57,22 +58,31 @@ def _oracle_flags(D, scale=None):
 
 
 def _assert_close_to_oracle(o, lse, q, k, v, dt, causal, scale=None):
-    o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), dt, causal, scale=scale, flags=_oracle_flags(q.shape[-1], scale))
-    o_ref = fo.bits_to_f32(o_ref_bits, dt)
+    """Against the oracle run under the contract of the kernel that served the call.  Head dims other than 64 have one contract (scale applied to
+    the f32 product, row sums of the unrounded P).  At head dim 64 the library documents three, chosen by the launch geometry and dtype
+    (include/fa2_gfx950.h, fa2_fwd_prescales_q): the 8-wave / 128-row HIP kernels (the contract above); the hand-scheduled body (causal launches,
+    every fp16 launch of 256-row workgroups), whose row sums ride the matrix pipe, i.e. add the ROUNDED P (FA2_ORACLE_LSUM_P16); and, in fp16,
+    that body with the scale folded into Q (PRESCALE_Q: Q * scale*log2e rounded once, the reference oracle's own contract, pure_torch_ver.py:61).
+    The result must match ONE of them within the usual tolerance (bf16 row sums of rounded P: 4e-3 — the kernel rounds P against its deferred
+    reference maximum, the oracle against the running one: 2^-9 relative noise per term, a row with one to three visible keys shows all of it)."""
+    D = q.shape[-1]
+    contracts = [(0, LSE_TOL)]
+    if D == 64:
+        contracts.append((fo.LSUM_P16, LSE_TOL if dt == 0 else 4e-3))
+        if dt == 0 and _oracle_flags(D, scale):
+            contracts.append((fo.PRESCALE_Q | fo.LSUM_P16, LSE_TOL))
     got = o.float().cpu().numpy()
     assert np.isfinite(got).all()
-    bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
-    assert not bad.any(), "max diff %.3e at %s" % (np.abs(got - o_ref).max(), np.argwhere(bad)[:4])
-    lse_err = np.abs(lse.cpu().numpy() - lse_ref).max()
-    if lse_err > LSE_TOL:
-        # the head-dim-64 hand-scheduled body (causal launches of 256-row workgroups) forms its row sums on the matrix pipe, i.e. from the
-        # ROUNDED P the P.V product consumes: its LSE is held against the oracle run under that contract (FA2_ORACLE_LSUM_P16).
-        # (bf16: the kernel rounds P against its deferred reference maximum, the oracle against the running one, so the two sums differ
-        #  by the rounding noise of single P values, 2^-9 relative: a row with one to three visible keys shows all of it)
-        assert q.shape[-1] == 64, lse_err
-        _, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), dt, causal, scale=scale, flags=_oracle_flags(q.shape[-1], scale) | fo.LSUM_P16)
+    worst = []
+    for flags, lse_tol in contracts:
+        o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), dt, causal, scale=scale, flags=flags)
+        o_ref = fo.bits_to_f32(o_ref_bits, dt)
+        bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
         lse_err = np.abs(lse.cpu().numpy() - lse_ref).max()
-        assert lse_err <= (LSE_TOL if dt == 0 else 4e-3), lse_err
+        if not bad.any() and lse_err <= lse_tol:
+            return
+        worst.append((flags, float(np.abs(got - o_ref).max()), float(lse_err)))
+    raise AssertionError("no documented contract matches: (oracle flags, max |O diff|, max |LSE diff|) = %s" % worst)
 
 
 # ---------------------------------------------------------------- golden fixtures
@@ -136,7 +146,7 @@ def test_explicit_and_negative_scale():
     g = torch.Generator(device="cpu").manual_seed(3)
     q, k, v = (torch.randn((1, 2, 200, 64), generator=g).half().to(_dev()) for _ in range(3))
     lib = _fa2_lib.load(build_if_missing=False)
-    assert lib.fa2_fwd_prescales_q(64, 1.5) == 0 and lib.fa2_fwd_prescales_q(128, 1.5) == 0   # never folded when scale*log2e > 1
+    assert lib.fa2_fwd_prescales_q(64, 1.5) == 1 and lib.fa2_fwd_prescales_q(128, 1.5) == 0 and lib.fa2_fwd_prescales_q(64, -1.0) == 0
     for scale in (0.3, -0.2, 1.5, -2.0):
         for causal in (False, True):
             o, lse = _cabi_forward(q, k, v, causal, scale=scale)
@@ -729,3 +739,29 @@ def test_compiled_front_end_matches_python():
         assert a[0].data_ptr() == a[4].data_ptr()
     with pytest.raises(RuntimeError):
         fe.forward(q.cpu(), k.cpu(), v.cpu(), 64, 128, False, 0.1, False)
+
+
+def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
+    """fp16 launches of 256-row workgroups at head dim 64 run the hand-scheduled body that folds scale * log2(e) into Q (rounded once to fp16:
+    the scaling contract of the reference's own oracle, pure_torch_ver.py:61; fa2_fwd_prescales_q(64, scale) == 1).  Against the oracle under
+    THAT contract the usual tolerance holds whatever the logits; against float64 attention the rounding of Q shows in proportion to the logits:
+    ~2e-4 of log2 LSE on N(0,1) inputs (logits of a few units), ~1e-2 in O at logits of several hundred — the documented price of the fold."""
+    lib = _fa2_lib.load(build_if_missing=False)
+    assert lib.fa2_fwd_prescales_q(64, 0.125) == 1
+    B, H, N, D = 2, 16, 2048, 64                         # 256 workgroups of 256 rows: the hand-scheduled body
+    for amp, o_tol, lse_tol in ((1.0, 1e-3, 1e-3), (3.0, 3e-2, 0.3)):
+        g = torch.Generator(device="cpu").manual_seed(int(amp * 10))
+        q = (torch.randn((B, H, N, D), generator=g) * amp).half().to(_dev())
+        k = (torch.randn((B, H, N, D), generator=g) * amp).half().to(_dev())
+        v = torch.randn((B, H, N, D), generator=g).half().to(_dev())
+        o, lse = _cabi_forward(q, k, v, False)
+        for (b, h) in ((0, 0), (1, 15)):
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            o_ref_bits, lse_ref = fo.fwd_c(_bits(q[sl]), _bits(k[sl]), _bits(v[sl]), 0, False, flags=fo.PRESCALE_Q | fo.LSUM_P16)
+            o_ref = fo.bits_to_f32(o_ref_bits, 0)
+            got = o[sl].float().cpu().numpy()
+            assert np.all(np.abs(got - o_ref) <= ATOL[0] + RTOL[0] * np.abs(o_ref)), np.abs(got - o_ref).max()
+            assert np.abs(lse[sl].cpu().numpy() - lse_ref).max() <= LSE_TOL
+            o_true, lse_true = fo.fwd_numpy(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), False)
+            assert np.all(np.abs(got - o_true) <= o_tol + 4e-3 * np.abs(o_true)), (amp, np.abs(got - o_true).max())
+            assert np.abs(lse[sl].cpu().numpy() - lse_true).max() <= lse_tol, (amp, np.abs(lse[sl].cpu().numpy() - lse_true).max())

@@ -60,18 +60,27 @@ def _fwd(q, k, v, ws_mode, bnhd=False, scale=None):
 
 
 def _check_heads(o, lse, q, k, v, dt, heads, bnhd=False):
+    """sampled heads against the oracle under one of the contracts the library documents for the head dim (tests/test_parity_gpu.py
+    _assert_close_to_oracle has the list: head dim 64 in fp16 may fold the scale into Q and sums the rounded P)."""
     for (b, h) in heads:
         if bnhd:
             sl = lambda t: t[b:b + 1, :, h:h + 1].transpose(1, 2).contiguous()  # noqa: E731
         else:
             sl = lambda t: t[b:b + 1, h:h + 1].contiguous()  # noqa: E731
-        o_ref_bits, lse_ref = fo.fwd_c(_bits(sl(q)), _bits(sl(k)), _bits(sl(v)), dt, False)
-        o_ref = fo.bits_to_f32(o_ref_bits, dt)
         got = sl(o).float().cpu().numpy()
         assert np.isfinite(got).all()
-        bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
-        assert not bad.any(), "head %s: max diff %.3e" % ((b, h), np.abs(got - o_ref).max())
-        assert np.abs(lse[b:b + 1, h:h + 1].cpu().numpy() - lse_ref).max() <= LSE_TOL
+        contracts = [0] + ([fo.LSUM_P16, fo.PRESCALE_Q | fo.LSUM_P16] if (sl(q).shape[-1] == 64 and dt == 0) else [])
+        worst = []
+        for flags in contracts:
+            o_ref_bits, lse_ref = fo.fwd_c(_bits(sl(q)), _bits(sl(k)), _bits(sl(v)), dt, False, flags=flags)
+            o_ref = fo.bits_to_f32(o_ref_bits, dt)
+            bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
+            lse_err = np.abs(lse[b:b + 1, h:h + 1].cpu().numpy() - lse_ref).max()
+            if not bad.any() and lse_err <= LSE_TOL:
+                break
+            worst.append((flags, float(np.abs(got - o_ref).max()), float(lse_err)))
+        else:
+            raise AssertionError("head %s: no documented contract matches: %s" % ((b, h), worst))
 
 
 # shapes whose B*H*ceil(Nq/256) leaves a partly filled last round on 256 CUs:
@@ -104,10 +113,12 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     ulp = 2.0 ** -10 if dt == 0 else 2.0 ** -7
     scale_o = max(1.0, float(o_pl.float().abs().max()))
     assert float((o_ws.float() - o_pl.float()).abs().max()) <= ulp * scale_o
-    assert float((lse_ws - lse_pl).abs().max()) <= 1e-4
+    # (head dim 64, fp16: the whole rounds of the split launch run the folded-scale body, the plain call's 128-row kernels scale the f32 product)
+    assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if (D == 64 and dt == 0) else 1e-4)
     # a fair share of the elements must be bit-identical (the unsplit items are the same launch geometry)
+    # (not at head dim 64 in fp16, where the two calls run different scaling contracts: see the LSE bound above)
     same = (o_ws.view(torch.int16) == o_pl.view(torch.int16)).float().mean().item()
-    assert same > 0.5, same
+    assert same > (0.2 if (D == 64 and dt == 0) else 0.5), same
     # against the oracle on heads from the unsplit rounds and from the split tail (the last items of the order)
     heads = {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2), (B - 1, max(H - 8, 0))}
     _check_heads(o_ws, lse_ws, q, k, v, dt, heads, bnhd)

@@ -208,7 +208,12 @@ class Gen:
         self.cfg = dict(self.DEFAULTS)
         if hd == 64:
             self.cfg.update(self.DEFAULTS64)
-        self.cfg.update(cfg)
+        for k, v in cfg.items():          # "d64_<key>": a schedule tunable of the head-dim-64 body only (window sweeps, tools/kbench.py)
+            if k.startswith("d64_"):
+                if hd == 64:
+                    self.cfg[k[4:]] = v
+            else:
+                self.cfg[k] = v
         if "w1" in self.cfg and "w2" in self.cfg:     # scheduler weights: w1=trans:lds, w2=dma:salu
             set_weights(self.cfg["w1"][0], self.cfg["w1"][1], self.cfg["w2"][0], self.cfg["w2"][1])
         self.opt = set(self.cfg["opt"])

@@ -115,7 +115,7 @@ struct FwdParams {
     // normalised f32 partial O tiles and partial log2 LSEs in `ws`; fwd_combine_kernel merges them into o / lse.
     int full_items, split_items, nsplit; // nsplit <= 1: no split
     int blk0;                            // added to blockIdx.x (a launch that covers only the parts: blk0 = full_items)
-    int item_cap;                        // hand-scheduled kernels: the launch covers items [0, item_cap) only (0 = all)
+    int item_cap;                        // hand-scheduled kernels: the launch covers the list entries [0, item_cap): whole items, then parts (0 = all whole items)
     float* ws;                           // [split_items * nsplit] partial O tiles of kSplitRows x HD floats, then as many LSE rows of kSplitRows
 };
 

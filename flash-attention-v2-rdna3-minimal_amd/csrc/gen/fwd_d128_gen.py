@@ -70,11 +70,15 @@ A_LDSW = Arg(20, "s")                              # wave * 4096: this wave's qu
 A_EPI = Arg(21)                                    # per-lane LDS byte address of the epilogue image: row l31, half hi
 # persistent workgroups: the asm statement runs once per (head, q block) item of the workgroup's list; the last two bodies of
 # an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
-A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles
+A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles; bit 3: this item is a KV-split part
 A_NQO0, A_NQO1 = Arg(23), Arg(24)                  # the next item's Q offsets / head base / K and V descriptors
 A_NQB = Arg(25, "s", 2)
 A_NKRS, A_NVRS = Arg(26, "s", 4), Arg(27, "s", 4)
-N_ARGS = 28
+# KV-split parts (flag bit 3; fa2_fwd_ws): the item sweeps a KV range of its (head, q block) and leaves a normalised f32 partial tile in the
+# caller's workspace instead of the 16-bit tile in LDS — float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e) of the tile for d = 32dt + 8g + 4hi + e,
+# the layout of the HIP kernels' parts (fa2_fwd_kernel.hip.h): a store instruction of the wave writes 1 KiB of consecutive bytes
+A_WSB = Arg(28, "s", 2)                            # address of the part's tile
+N_ARGS = 29
 
 # ---- fixed registers (everything below is clobbered by the asm statement)
 VBASE = 16
@@ -92,6 +96,7 @@ KR = [V(208 + i) for i in range(8)]                # K fragment read addresses, 
 VR = [V(216 + i) for i in range(4)]                # V^T fragment read addresses, d block dt
 KD = [V(220 + i) for i in range(4)]                # LDS-DMA source offsets of this wave's 4 pieces of a K tile
 VD = [V(224 + i) for i in range(4)]
+WSO = VD[2]                                        # part epilogue (the DMA offsets are dead by then): per-lane byte offset of row 64*wave + l31, half hi in the tile
 LSUM = [V(228, 2), V(230, 2)]                      # running row sums, two chains (even / odd elements) per q block
 LA = [LSUM[0][0], LSUM[1][0]]
 LB = [LSUM[0][1], LSUM[1][1]]
@@ -903,6 +908,8 @@ class Gen:
         if tr:
             p.emit("s_memtime", S_MARK[2])
         p.emit("s_nop", 15)
+        p.emit("s_bitcmp1_b32", A_FLAGS, 3)
+        p.emit("s_cbranch_scc1", Label("epilogue_part"))
         for qb in range(2):
             lt, t, inv = EP_LT, EP_T, EP_INV
             if self.lmfma:
@@ -963,6 +970,53 @@ class Gen:
             p.emit("v_cvt_f32_u32", A_LSE0, a)
             p.emit("v_cvt_f32_u32", A_LSE1, b)
         # out-of-line blocks
+        p.emit("s_branch", Label("end"))
+        # ---- epilogue of a KV-split part: O / l in f32 straight to the workspace tile (see A_WSB), LSE out
+        p.label("epilogue_part")
+        # this lane's place in the tile: (64 * wave + l31) * 32 + hi * 16 bytes (the lane id from v_mbcnt: no operand register left for it)
+        p.emit("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
+        p.emit("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
+        p.emit("s_lshl_b32", S_TMP, S_WAVE, 6)
+        p.emit("v_and_b32", TMP[1], 31, TMP[0])
+        p.emit("v_lshrrev_b32", TMP[2], 5, TMP[0])
+        p.emit("v_add_u32", TMP[1], S_TMP, TMP[1])
+        p.emit("v_lshlrev_b32", TMP[2], 4, TMP[2])
+        p.emit("v_lshlrev_b32", TMP[1], 5, TMP[1])
+        p.emit("s_nop", 0)
+        p.emit("v_add_u32", WSO, TMP[1], TMP[2])
+        for qb in range(2):
+            lt, t, inv = EP_LT, EP_T, EP_INV
+            if self.lmfma:
+                p.emit("v_accvgpr_read_b32", lt, self.lacc(qb)[0])
+            else:
+                p.emit("v_add_f32", lt, LA[qb], LB[qb])
+            p.emit("s_nop", 0)
+            p.emit("v_mov_b32", t, lt)
+            p.emit("s_nop", 1)
+            p.emit("v_permlane32_swap_b32", lt, t)
+            p.emit("v_add_f32", lt, lt, t)
+            p.emit("s_nop", 0)
+            p.emit("v_rcp_f32", inv, lt)
+            p.emit("v_log_f32", t, lt)
+            p.emit("s_nop", 0)
+            p.emit("v_add_f32", KD[qb], MC[qb], t)
+            for dt in range(g.NDT):
+                acc = self.oacc(qb, dt)
+                for r4 in (0, 2):
+                    for j in range(8):
+                        p.emit("v_accvgpr_read_b32", TMP[j], acc[4 * r4 + j])
+                    p.emit("s_nop", 0)
+                    for j in range(8):
+                        p.emit("v_mul_f32", TMP[j], TMP[j], inv)
+                    for half in range(2):          # registers 4*r4 + 4*half .. +3  <->  g = r4 + half
+                        p.emit("v_add_u32", KD[2 + half], 1024 * qb + 8192 * (4 * dt + r4 + half), WSO)
+                    p.emit("s_nop", 0)
+                    for half in range(2):
+                        p.emit("global_store_dwordx4", KD[2 + half], V(TMP[4 * half].idx, 4), A_WSB)
+                    p.emit("s_nop", 3)             # (a store of more than 64 bits: its data registers must not be rewritten right behind it)
+        p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)     # the stores, and whatever the item seam prefetched: the next statement counts loads only
+        p.emit("v_mov_b32", A_LSE0, KD[0])
+        p.emit("v_mov_b32", A_LSE1, KD[1])
         p.emit("s_branch", Label("end"))
         for r in self.rare:
             p.extend(r)

@@ -158,14 +158,13 @@ int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStre
             p.ws = (float*)ws;
             int rc;
             if (asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256) {
-                // whole rounds on the hand-scheduled persistent kernel (every workgroup gets the same number of items), then the parts
-                fa2::FwdParams pa = p;
-                pa.item_cap = pl.full_items;
-                pa.nsplit = 0;
-                if ((rc = fa2::launch_fwd_asm(HD, bf16, pa, false, stream))) return rc;
-                p.blk0 = pl.full_items;
+                // the hand-scheduled persistent kernel: every workgroup works through its whole items, then its parts (the item seam hides a
+                // part's load phase like any other item's; the block stores a part's f32 tile itself)
+                p.item_cap = pl.full_items + pl.split_items * pl.nsplit;
+                rc = fa2::launch_fwd_asm(HD, bf16, p, false, stream);
+            } else {
+                rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
             }
-            rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
             if (rc) return rc;
             return bf16 ? fa2::launch_fwd_combine_bf16(HD, p, stream) : fa2::launch_fwd_combine_f16(HD, p, stream);
         }

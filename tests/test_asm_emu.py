@@ -193,7 +193,7 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
         pytest.skip("llvm-mc not available")
     subst = {0: "v0", 1: "v1", 2: "v2", 3: "v3", 4: "s[0:1]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
              12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
-             23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]"}
+             23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]", 28: "s[32:33]"}
     for bf16, hd in ((False, 128), (True, 128), (False, 64), (True, 64)):
         text = "\n".join(gen.Gen(bf16, hd=hd, opt=opt).build().text_lines())
         text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))
@@ -201,3 +201,36 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
         src.write_text(text + "\n")
         res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[:2000]
+
+
+@pytest.mark.parametrize("hd,opt", [(128, ()), (64, ("ct",)), (64, ())])
+def test_kv_split_part_epilogue(hd, opt):
+    """KV-split parts in the persistent workgroups (fa2_fwd_ws): an item flagged as a part (flag bit 3) sweeps a KV range and its epilogue stores
+    the NORMALISED f32 tile straight to the workspace (1-KiB stores in the layout of the HIP kernels' parts) instead of the 16-bit tile in LDS.
+    A whole item, then two parts of another item through the item seam: every output must match dense attention over its own KV range, the part
+    tiles must be fully written (the workspace starts NaN-filled), and the emulator must see no hazard (stores in flight at the seam)."""
+    import numpy as np
+    saved = harness.HD, harness.OPT
+    harness.HD, harness.OPT = hd, opt
+    harness._PROGS.clear()
+    try:
+        rng = np.random.default_rng(hd)
+        q, k, v = rng.standard_normal((512, hd)), rng.standard_normal((448, hd)), rng.standard_normal((448, hd))
+        items = [(q, k, v, 1), (q, k[:256], v[:256], 0, True), (q, k[256:], v[256:], 0, True)]      # parts: tiles [0, 4) and [4, 7) of q block 0
+        outs, m = harness.run_items(items, False)
+        assert not m.errors, m.errors[:5]
+        for (item, (o, lse)) in zip(items, outs):
+            qq, kk, vv, qb = item[:4]
+            o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre=bool(opt))
+            assert np.isfinite(o).all()
+            assert np.abs(o - o_ref).max() <= 1e-3
+            assert np.abs(lse - lse_ref).max() <= (1e-3 if hd == 64 else 1e-4)
+        # merged like fwd_combine_kernel, the two parts are the whole item
+        (o1, l1), (o2, l2) = outs[1], outs[2]
+        lse = np.logaddexp2(l1, l2)
+        o = o1 * np.exp2(l1 - lse)[:, None] + o2 * np.exp2(l2 - lse)[:, None]
+        o_ref, lse_ref = harness.dense(q[:256], k, v, False, pre=bool(opt))
+        assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-3
+    finally:
+        harness.HD, harness.OPT = saved
+        harness._PROGS.clear()

@@ -279,7 +279,7 @@ class Machine:
             return 4.5
         if op.startswith("buffer_load"):
             return 40.0
-        if op.startswith("global_load"):
+        if op.startswith("global_load") or op.startswith("global_store"):
             return 8.0
         if op == "s_nop":
             return 4.0 * (int(ins.ops[0]) + 1)
@@ -406,6 +406,11 @@ class Machine:
             if take:
                 nxt = self.labels[ops[0].name]
                 w.cycle += 16
+        elif op in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):      # with an all-ones mask: lanes below this one in the low / high half, + src1
+            lane = np.arange(64, dtype=np.uint32)
+            assert int(self.rd32(w, ops[1])[0]) == 0xffffffff
+            cnt = np.minimum(lane, 32) if op.startswith("v_mbcnt_lo") else np.maximum(lane, 32) - 32
+            self.wr32(w, ops[0], (cnt + self.rd32(w, ops[2])).astype(np.uint32))
         elif op == "v_mov_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]))
         elif op == "v_subrev_u32":
@@ -567,6 +572,17 @@ class Machine:
                 for i in range(4):
                     rf[dst.idx + i] = data[:, i]
             w.vm.append(land)
+        elif op == "global_store_dwordx4":           # saddr form: vaddr (32-bit offset), vdata[4], 64-bit scalar base
+            a, src, sb = R(0), R(1), R(2)
+            self.check_read(w, a.kind, a.idx, 1, "valu")
+            self.check_read(w, src.kind, src.idx, 4, "valu")
+            base = int(sb[0]) | (int(sb[1]) << 32)
+            addr = base + self.regfile(w, a.kind)[a.idx].astype(np.int64) + ins.mods.get("offset", 0)
+            data = np.ascontiguousarray(self.regfile(w, src.kind)[src.idx:src.idx + 4].T).view(np.uint8)      # [64, 16]
+            for lane in range(64):
+                arr, off = self._gfind(int(addr[lane]), 16)
+                arr[off:off + 16] = data[lane]
+            w.vm.append(lambda: None)
         elif op == "global_load_dword":
             dst, a, sb = R(0), R(1), R(2)
             self.check_read(w, a.kind, a.idx, 1, "valu")

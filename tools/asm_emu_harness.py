@@ -38,7 +38,7 @@ def from_bits(b, bf16):
     return asm_emu.bf16_to_f32(b) if bf16 else asm_emu.f16_to_f32(b)
 
 
-def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=None, flags=0, nxt=None):
+def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes=None, flags=0, nxt=None, ws_base=0):
     """The values the forward shell (fa2_fwd_d128.hip.h) hands to the asm statement, for wave w of the workgroup working on Q block
     qblk.  nxt = (qblk, Nq, q_base, k_base, v_base, Nkv) of the workgroup's next item (flags bit 1) or None."""
     g = geo()
@@ -113,6 +113,8 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         args[25], args[26], args[27] = pair(nq_base), srd(nk_base, nNkv), srd(nv_base, nNkv)
     else:
         args[25], args[26], args[27] = pair(q_base), args[5], args[6]
+    # KV-split parts (flag bit 3): workspace tile of the part, this lane's row 64*w + l31 and half hi
+    args[28] = pair(ws_base)
     args["vregs"] = v
     return args
 
@@ -125,7 +127,8 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
     pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)       # NaN guard bands around every matrix
     bufs, bases = [], []
     addr = 0x10000000
-    for (q, k, v, _) in items:
+    for item in items:
+        q, k, v = item[:3]
         b3 = []
         for t in (q, k, v):
             arr = np.concatenate([pad, to_bits(t, bf16).ravel(), pad]).view(np.uint8)
@@ -133,13 +136,22 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             b3.append(addr + pad.size * 2)
             addr += (arr.size + 0xffff) & ~0xffff
         bases.append(b3)
+    # workspace tiles of KV-split parts (items with a fifth element True): f32 [256 * HD], NaN-filled
+    ws_addr = {}
+    for it, item in enumerate(items):
+        if len(item) > 4 and item[4]:
+            arr = np.full(256 * HD, np.nan, dtype=np.float32).view(np.uint8)
+            bufs.append((addr, arr))
+            ws_addr[it] = addr
+            addr += (arr.size + 0xffff) & ~0xffff
     m = None
     outs = []
-    for it, (q, k, v, qblk) in enumerate(items):
+    for it, item in enumerate(items):
+        q, k, v, qblk = item[:4]
         Nq, Nkv = q.shape[0], k.shape[0]
         nxt = None
         if it + 1 < len(items):
-            nq_, nk_, _, nqblk = items[it + 1]
+            nq_, nk_, _, nqblk = items[it + 1][:4]
             nxt = (nqblk, nq_.shape[0], bases[it + 1][0], bases[it + 1][1], bases[it + 1][2], nk_.shape[0])
         flags = (1 if it > 0 else 0) | (2 if nxt is not None else 0)
         if nxt is not None:
@@ -147,7 +159,9 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             if causal:
                 n_nk = min(n_nk, (min(nxt[0] * 256 + 256, nxt[1]) - 1) // 64 + 1)
             flags |= 4 if n_nk >= 2 else 0
-        wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt)
+        if it in ws_addr:
+            flags |= 8
+        wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt, ws_base=ws_addr.get(it, 0))
               for w in range(4)]
         if m is None:
             m = asm_emu.Machine(program(bf16), wa, geo().LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
@@ -159,8 +173,12 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
         m.run()
         rows = min(256, Nq - qblk * 256)
         g = geo()
-        img = m.lds[g.EPI_BASE:g.EPI_BASE + 4 * 64 * g.EPI_ROWB].reshape(256, g.EPI_ROWB)[:, :g.ROWB].copy().view(np.uint16)
-        o = from_bits(img, bf16)[:rows]
+        if it in ws_addr:      # a part: the normalised f32 tile in the workspace, float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e) <-> d = 32dt + 8g + 4hi + e
+            arr = [a for (b_, a) in bufs if b_ == ws_addr[it]][0].view(np.float32).reshape(HD // 8, 256, 8)      # [4dt + g, row, 4hi + e]
+            o = arr.transpose(1, 0, 2).reshape(256, HD)[:rows].copy()
+        else:
+            img = m.lds[g.EPI_BASE:g.EPI_BASE + 4 * 64 * g.EPI_ROWB].reshape(256, g.EPI_ROWB)[:, :g.ROWB].copy().view(np.uint16)
+            o = from_bits(img, bf16)[:rows]
         lse = np.empty(256, dtype=np.float32)
         for w in range(4):
             for qb in range(2):

@@ -235,7 +235,7 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 
 int fa2_fwd_prescales_q(int D, float scale) {
     if (fa2_padded_head_dim(D) < 0) return -1;
-    return D == 64 && scale > 0.f ? 1 : 0;      // the fp16 launches that take the hand-scheduled head-dim-64 body (launch_range)
+    return (D == 64 || D == 128) && scale > 0.f ? 1 : 0;      // the fp16 launches that take the hand-scheduled bodies (launch_range)
 }
 
 int fa2_set_option(const char* name, int value) {

@@ -203,7 +203,7 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
         assert res.returncode == 0, res.stderr[:2000]
 
 
-@pytest.mark.parametrize("hd,opt", [(128, ()), (64, ("ct",)), (64, ())])
+@pytest.mark.parametrize("hd,opt", [(128, ("ct",)), (128, ()), (64, ("ct",)), (64, ())])
 def test_kv_split_part_epilogue(hd, opt):
     """KV-split parts in the persistent workgroups (fa2_fwd_ws): an item flagged as a part (flag bit 3) sweeps a KV range and its epilogue stores
     the NORMALISED f32 tile straight to the workspace (1-KiB stores in the layout of the HIP kernels' parts) instead of the 16-bit tile in LDS.

@@ -69,7 +69,8 @@ def _check_heads(o, lse, q, k, v, dt, heads, bnhd=False):
             sl = lambda t: t[b:b + 1, h:h + 1].contiguous()  # noqa: E731
         got = sl(o).float().cpu().numpy()
         assert np.isfinite(got).all()
-        contracts = [0] + ([fo.LSUM_P16, fo.PRESCALE_Q | fo.LSUM_P16] if (sl(q).shape[-1] == 64 and dt == 0) else [])
+        dh = sl(q).shape[-1]
+        contracts = [0] + ([fo.LSUM_P16, fo.PRESCALE_Q | fo.LSUM_P16] if (dh == 64 and dt == 0) else [fo.PRESCALE_Q] if (dh == 128 and dt == 0) else [])
         worst = []
         for flags in contracts:
             o_ref_bits, lse_ref = fo.fwd_c(_bits(sl(q)), _bits(sl(k)), _bits(sl(v)), dt, False, flags=flags)
@@ -114,7 +115,7 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     scale_o = max(1.0, float(o_pl.float().abs().max()))
     assert float((o_ws.float() - o_pl.float()).abs().max()) <= ulp * scale_o
     # (head dim 64, fp16: the whole rounds of the split launch run the folded-scale body, the plain call's 128-row kernels scale the f32 product)
-    assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if (D == 64 and dt == 0) else 1e-4)
+    assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if (D == 64 and dt == 0) else 1e-4)      # (at head dim 128 both calls fold)
     # a fair share of the elements must be bit-identical (the unsplit items are the same launch geometry)
     # (not at head dim 64 in fp16, where the two calls run different scaling contracts: see the LSE bound above)
     same = (o_ws.view(torch.int16) == o_pl.view(torch.int16)).float().mean().item()

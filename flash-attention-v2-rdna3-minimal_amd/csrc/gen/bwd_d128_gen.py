@@ -189,8 +189,11 @@ class GenDQ(BodyEmitter):
         lim = DQ.A_LIM0 if qb == 0 else DQ.A_LIM1
         out = []
         if masked:
+            # masked scores must come out of the fma below as -inf: -inf for c >= 0, +inf for a negative scale (found by the randomised sweep:
+            # -inf * c = +inf, P = inf, dQ non-finite on every call with a ragged or causal tile and scale < 0)
             t2 = DQ.TMP[4 * qb]
-            out.append(mk("v_mov_b32", t2, NEG_INF, tag="valu"))
+            out.append([mk("v_mov_b32", t2, DQ.A_C, tag="valu"), mk("v_and_b32", t2, 0x80000000, t2, tag="valu"),
+                        mk("v_xor_b32", t2, 0xff800000, t2, tag="valu")])
             for r in range(16):
                 kvl = (r & 3) + 8 * (r >> 2) - off
                 out.append([mk("v_cmp_le_i32", VCC, kvl, lim, tag="valu"), mk("v_cndmask_b32", s[r], t2, s[r], VCC, tag="valu")])
@@ -590,8 +593,9 @@ class GenDKV(BodyEmitter):
         s, L = KV.BK(par, kvb), KV.LR(par)
         out = []
         if masked:      # causal: q (tile-local: (r&3) + 8(r>>2), + 4*hi folded into the limit) must be >= this lane's kv row
-            t2 = KV.TMP[4 * kvb]
-            out.append(mk("v_mov_b32", t2, NEG_INF, tag="valu"))
+            t2 = KV.TMP[4 * kvb]         # (-inf, or +inf for a negative scale: see GenDQ.stream_valu)
+            out.append([mk("v_mov_b32", t2, KV.A_C, tag="valu"), mk("v_and_b32", t2, 0x80000000, t2, tag="valu"),
+                        mk("v_xor_b32", t2, 0xff800000, t2, tag="valu")])
             for r in range(16):
                 out.append([mk("v_cmp_ge_i32", VCC, (r & 3) + 8 * (r >> 2), KV.LIMT[kvb], tag="valu"),
                             mk("v_cndmask_b32", s[r], t2, s[r], VCC, tag="valu")])

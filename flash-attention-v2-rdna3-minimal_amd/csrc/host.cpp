@@ -107,6 +107,11 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
 
 // Head dim exactly 128 with a positive scale runs the hand-scheduled 4-wave kernel (fa2_fwd_d128.hip.h) unless option "asm"
 // bit 0 is cleared (A/B measurements, tools/kbench.py).  The asm block addresses a head's Q rows with 32-bit byte offsets.
+// ... and derives a wave's further LDS-DMA source offsets from its first by flipping granule bits of the byte offset (the K image's swizzle follows
+// the row), which is only the same as re-swizzling when a row's byte offset has those bits clear: K's row pitch must be a multiple of one tile
+// row (2 * HD bytes).  Contiguous BHND and BNHD tensors are; a column slice of a wider matrix is not and runs on the HIP kernels (found by the
+// randomised sweep, tools/fuzz_parity.py, once it drew grids wide enough for these kernels: profiles/r06_fuzz_parity_seed5.json).
+bool asm_pitch_ok(int64_t row_stride_elems, int HD) { return row_stride_elems % HD == 0; }
 bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32); }
 
 int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
@@ -118,7 +123,7 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
     // (round 3) fp16: the generated body folds the scale into Q and then beats the 8-wave kernel non-causal too, so every fp16 launch takes it.
     const bool d64_asm = HD == 64 && (causal || !bf16 || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
-    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p))
+    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD))
         return fa2::launch_fwd_asm(HD, bf16, p, causal, stream);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
 }
@@ -145,7 +150,7 @@ fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causa
 
 // non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 in fp16 (launch_range)
 bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
-    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p);
+    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD);
 }
 
 int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
@@ -191,6 +196,9 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     const int want = fa2::options().bwd_parts.load(std::memory_order_relaxed);      // 3 unless a profiling run asked for one pass only
     int asm_parts = 0;
     if (HD == 128 && p.D == 128 && (m & 2)) asm_parts = 3 & ~((m >> 2) & 3) & fa2::kBwdAsmParts;
+    // row pitches the generated bodies' LDS-DMA offset arithmetic holds for (asm_pitch_ok): the dQ pass stages K and V, the dK / dV pass Q and dO
+    if (!asm_pitch_ok(p.ks[2], 128) || !asm_pitch_ok(p.vs[2], 128)) asm_parts &= ~1;
+    if (!asm_pitch_ok(p.qs[2], 128) || !asm_pitch_ok(p.dos[2], 128)) asm_parts &= ~2;
     if (p.Nq % 32 != 0) asm_parts &= ~2;              // the hand-scheduled dK/dV pass sweeps whole 32-row Q tiles
     // the sign delta crosses the workspace with: the hand-scheduled dK/dV pass takes -delta (C operand of its dP product); a dQ pass
     // that is not the hand-scheduled one writes +delta, so the two only go together

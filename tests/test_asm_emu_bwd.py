@@ -105,3 +105,21 @@ def test_generated_backward_text_assembles_for_gfx950(kind, tmp_path):
         src.write_text(text + "\n")
         res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[:2000]
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_blocks_with_a_negative_scale(causal):
+    """scale < 0 (the reference takes any float, FlashAttn.py:61): scale * log2(e) is negative, so the masked scores of a ragged or causal tile must
+    enter the fma as +inf to come out as -inf (P = 0).  The randomised GPU sweep found them entering as -inf (P = inf, dQ non-finite); both
+    hand-scheduled passes, ragged Nkv and the causal diagonal."""
+    import numpy as np
+    import asm_emu_bwd as hb
+    rng = np.random.default_rng(11 + causal)
+    q, k, v, do = (rng.standard_normal((n, 128)) for n in (320, 300, 300, 320))
+    dq, delta, m, ref = hb.run_dq(q, k, v, do, 0, causal, scale=-0.11)
+    assert not m.errors, m.errors[:5]
+    assert np.isfinite(dq).all() and np.abs(dq - ref["dq"]).max() <= 1e-3 * max(1.0, float(np.abs(ref["dq"]).max()))
+    dk, dv, m, ref = hb.run_dkv(q, k[:256], v[:256], do, 1, causal, scale=-0.11)
+    assert not m.errors, m.errors[:5]
+    for got, want in ((dk, ref["dk"]), (dv, ref["dv"])):
+        assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * max(1.0, float(np.abs(want).max()))

@@ -250,3 +250,22 @@ def test_pinned_workgroup_shapes_and_kernel_families():
             for name in names:
                 n += _expand_and_call(getattr(mod, name))
     assert n >= 20, n
+
+
+@pytest.mark.parametrize("D,dt", [(128, 0), (128, 1), (64, 0), (80, 1)])
+def test_backward_with_a_negative_scale_on_ragged_and_causal_shapes(D, dt):
+    """Negative scales through every backward kernel family (the hand-scheduled D = 128 passes, the fused D <= 64 pass, the wave-pair pass),
+    with a ragged Nkv and with the causal mask: masked scores must stay masked whatever the sign of scale * log2(e)
+    (found by tools/fuzz_parity.py: the hand-scheduled passes turned them into +inf, profiles/r06_fuzz_parity_seed6.json)."""
+    for (N, Nkv, causal) in ((320, 300, False), (416, 416, True), (96, 77, False)):
+        g = torch.Generator(device="cpu").manual_seed(N + D)
+        q, do = (torch.randn((2, 3, N, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+        k, v = (torch.randn((2, 3, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+        scale = -(D ** -0.5)
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal, scale=scale)
+        truth = grads_truth(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), do.float().cpu().numpy(), causal, scale=scale)
+        for name, gt, g_true in zip("qkv", grads, truth):
+            got = gt.float().cpu().numpy()
+            assert np.isfinite(got).all(), (name, N, Nkv, causal)
+            assert np.abs(got - g_true).max() <= GRAD_TOL[dt] * max(1.0, np.abs(g_true).max()), (name, N, Nkv, causal, np.abs(got - g_true).max())
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal, scale=scale)

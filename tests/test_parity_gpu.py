@@ -770,3 +770,35 @@ def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
             o_true, lse_true = fo.fwd_numpy(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), False)
             assert np.all(np.abs(got - o_true) <= o_tol + 4e-3 * np.abs(o_true)), (amp, np.abs(got - o_true).max())
             assert np.abs(lse[sl].cpu().numpy() - lse_true).max() <= lse_tol, (amp, np.abs(lse[sl].cpu().numpy() - lse_true).max())
+
+
+@pytest.mark.parametrize("D,dt", [(128, 0), (128, 1), (64, 0)])
+def test_padded_row_pitch_on_grids_wide_enough_for_the_hand_scheduled_kernels(D, dt):
+    """Column slices of wider matrices (row pitch D + 8 / D + 16 elements) on a grid of 256 workgroups of 256 rows.  The hand-scheduled bodies
+    derive a wave's further LDS-DMA source offsets by flipping granule bits of the first, which only equals re-swizzling when the staged matrix's
+    row pitch is a multiple of a tile row; host.cpp (asm_pitch_ok) sends other pitches to the HIP kernels.  The randomised sweep found the
+    missing check once it drew grids this wide (profiles/r06_fuzz_parity_seed5.json: LSE off by 2e-2 with a padded K).  Forward against the
+    oracle and dense fp32, backward against float64 autograd, with every operand padded in turn."""
+    from conftest import GRAD_TOL
+    B, H, N = 2, 16, 2048
+    g = torch.Generator(device="cpu").manual_seed(77 + D + dt)
+    for pads in ((0, 8, 0, 0), (8, 0, 16, 0), (8, 8, 8, 8)):          # pitch padding of q, k, v, dO in elements
+        wide = lambda p: torch.randn((B, H, N, D + p), generator=g).to(TORCH_DT[dt]).to(_dev())[..., :D]  # noqa: E731
+        q, k, v, do = (wide(p) for p in pads)
+        assert k.stride(2) == D + pads[1]
+        qa, ka, va = (t.detach().requires_grad_(True) for t in (q, k, v))
+        o = FlashAttentionFunction.apply(qa, ka, va, None, False)
+        o.backward(do)
+        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (D ** -0.5)
+        truth = torch.matmul(torch.softmax(s, -1), v.float())
+        assert float((o.float() - truth).abs().max()) <= FLOOR[dt] * 2, pads
+        lse = flash_attn_wmma.forward(q, k, v, 64, 128, False, D ** -0.5, False)[5]
+        assert float((lse - torch.logsumexp(s, -1) * fo.LOG2E).abs().max()) <= LSE_TRUTH_TOL[dt], pads
+        for (b, h) in ((0, 0), (1, 15)):
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            _assert_close_to_oracle(o[sl].detach(), lse[sl], q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dt, False)
+            qd, kd, vd = (t[sl].double().requires_grad_(True) for t in (q, k, v))
+            torch.nn.functional.scaled_dot_product_attention(qd, kd, vd).backward(do[sl].double())
+            for name, got, want in (("dq", qa.grad, qd.grad), ("dk", ka.grad, kd.grad), ("dv", va.grad, vd.grad)):
+                err = float((got[sl].double() - want).abs().max())
+                assert err <= GRAD_TOL[dt] * max(1.0, float(want.abs().max())), (pads, name, err)

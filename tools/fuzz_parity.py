@@ -72,6 +72,17 @@ def one_case(i, rng, gen, want_bwd):
     if big:
         B, H = 1, rng.randint(1, 3)
     causal = rng.random() < 0.4
+    if rng.random() < 0.12:
+        # wide grids: more 256-row workgroups than CUs, so that the persistent hand-scheduled kernels (several items per workgroup, the folded fp16
+        # bodies) and the split of a partly filled last round (forward and backward, through the operator's own workspace) are drawn too
+        D = rng.choice([40, 64, 64, 80, 128, 128])
+        Nq = rng.choice([1024, 1536, 2048, 2304, 2560, 3072]) - rng.choice([0, 0, 0, 7, 100])
+        Nkv = Nq if rng.random() < 0.7 else rng.choice([1024, 2048, 3072]) - rng.choice([0, 0, 13])
+        items_per_head = (Nq + 255) // 256
+        heads = rng.randint(256 // items_per_head + 1, 640 // items_per_head)
+        B = rng.choice([b for b in (1, 2, 3, 4) if heads % b == 0])
+        H = heads // B
+        causal = rng.random() < 0.25
     dist = rng.choice(["rand", "randn"])
     scale = D ** -0.5
     r = rng.random()
@@ -87,6 +98,13 @@ def one_case(i, rng, gen, want_bwd):
     desc = dict(i=i, B=B, H=H, Nq=Nq, Nkv=Nkv, D=D, dtype=str(dtype)[6:], causal=causal, scale=round(scale, 5), dist=dist,
                 layouts=[lq, lk, lv], bwd=want_bwd)
     o_true, lse_true = dense64(q, k, v, causal, scale)
+    # fp16 launches of the hand-scheduled bodies (head dims 64 / 128, positive scale, grids of 256-row workgroups) fold scale * log2(e) into Q,
+    # rounded once to fp16 (fa2_fwd_prescales_q; the reference oracle's contract, pure_torch_ver.py:61): the second truth applies that rounding
+    # and nothing else.  A result must be within the bounds of ONE of the two documented contracts.
+    alt = None
+    if dtype == torch.float16 and D in (64, 128) and scale > 0:
+        qs = (q.float() * (scale * LOG2E)).to(torch.float16)
+        alt = dense64(qs, k, v, causal, 1.0 / LOG2E)
     fails = []
 
     if want_bwd:
@@ -119,6 +137,8 @@ def one_case(i, rng, gen, want_bwd):
         fails.append("O non-finite")
     else:
         err = (o.double() - o_true).abs().max().item()
+        if alt is not None:
+            err = min(err, (o.double() - alt[0]).abs().max().item())
         vmax = max(1.0, v.float().abs().max().item())
         if err > 2 * FLOOR[dtype] * vmax:
             fails.append("O err %.3e > %.3e" % (err, 2 * FLOOR[dtype] * vmax))
@@ -127,7 +147,11 @@ def one_case(i, rng, gen, want_bwd):
         # the f32 logit itself carries ~2^-24 relative rounding per accumulate step: bound scales with the logit magnitude
         smag = (q.float().abs().max() * k.float().abs().max() * D * abs(scale) * LOG2E).item()
         lim = max(1e-3, 4e-6 * smag)
+        if D == 64 and dtype == torch.bfloat16:
+            lim = max(lim, 4e-3)      # causal / wide launches run the hand-scheduled body, whose row sums add the ROUNDED P (tests/test_parity_gpu.py: 4e-3)
         lerr = (lse.double() - lse_true).abs().max().item()
+        if alt is not None:
+            lerr = min(lerr, (lse.double() - alt[1]).abs().max().item())
         if not lerr <= lim:
             fails.append("LSE err %.3e > %.3e" % (lerr, lim))
         desc["lse_err"] = lerr

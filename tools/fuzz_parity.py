@@ -83,6 +83,18 @@ def one_case(i, rng, gen, want_bwd):
         B = rng.choice([b for b in (1, 2, 3, 4) if heads % b == 0])
         H = heads // B
         causal = rng.random() < 0.25
+    elif rng.random() < 0.04:
+        # long causal sequences: >= 32 q blocks per head, or more pair units than CUs — the persistent causal launches (pairs of q blocks through the item seam)
+        D = rng.choice([64, 128])
+        if rng.random() < 0.5:
+            Nq = Nkv = rng.choice([8192, 8448, 9000])
+            B, H = 1, rng.randint(1, 3)
+        else:
+            Nq = Nkv = rng.choice([2048, 2304, 3000])
+            heads = rng.randint(70, 130)
+            B = rng.choice([b for b in (1, 2) if heads % b == 0])
+            H = heads // B
+        causal = True
     dist = rng.choice(["rand", "randn"])
     scale = D ** -0.5
     r = rng.random()

@@ -108,7 +108,7 @@ struct FwdParams {
     const void* bias;
     int64_t bs[3];
     int bias_kind;                       // 1: the I/O 16-bit dtype, 2: f32, 3: uint8 (non-zero = attend)
-    int bias_vec;                        // host: base pointer, strides and Nkv allow one aligned load per group of four kv
+    int bias_vec;                        // host: 1 = one aligned load per group of four kv, 2 = coalesced tiles through LDS (4-wave kernels), 3 = tiles by LDS-DMA (8-wave kernels, BIAS = 2)
     // KV-split tail (fa2_fwd_ws; non-causal, no bias, head dims <= 128, 256-row workgroups): B*H*nqblk equal items on the CUs take
     // ceil(items / CUs) rounds however empty the last one is.  The items of that last round — the last `split_items` of the item
     // order, after `full_items` whole ones — are each swept by `nsplit` workgroups ("parts") over disjoint KV ranges, which leave
@@ -246,10 +246,13 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // above 128, two q blocks per wave); the plain 128-row kernels of head dims <= 128 fit 256 registers, and with the smaller budget the
 // compiler keeps the accumulators out of the AGPRs (under the 512 budget it parked them there and wrapped every rescale in
 // v_accvgpr_read / write: 11-13 register moves per MFMA in the ISA) and two workgroups can share a CU.
-template <int HD, int NW, int QB, bool BIAS>
+// BIAS = 2 (round 3): the bias tile of a step goes global -> LDS by LDS-DMA, swizzled like a K tile, into a wave-private image and is decoded
+// group by group straight into the score registers — no 32 raw registers, so the 8-wave, 256-row shape (two waves per SIMD, 256 registers)
+// carries a dense per-row bias too.  Geometry: the "tile" form's (pointer, strides and Nkv multiples of 16 bytes), head dims <= 128.
+template <int HD, int NW, int QB, int BIAS>
 constexpr int fwd_min_waves_per_simd() { return (NW == 4 && !BIAS && QB == 1 && HD <= 128) ? 2 : (NW + 3) / 4; }
 
-template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, bool BIAS = false>
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, int BIAS = 0>
 __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>())) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
@@ -392,8 +395,33 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     constexpr int kBiasRowB = 272;                           // up to 256 bytes of one row's 64 bias values (f32) + 16 bytes of padding
     constexpr int kBiasLdsBase = 2 * TILEB + 2 * VTILEB;     // "tile" form: NW wave-private images of 32 rows above the K / V buffers
     static_assert(!BIAS || QB == 1, "the bias kernels run one 32-row Q block per wave");
+    // BIAS == 2: per kind, a tile row is GPR granules of 16 bytes (64 elements), an LDS-DMA instruction covers RPI = 64 / GPR rows, the image keeps
+    // granule g of row r at slot g ^ (r & MASK) (the swizzle is applied to the lane's SOURCE address); rows >= Nq and granules past the last row's
+    // end are out of range for the descriptor and read zeros (such scores are masked or never stored)
+    constexpr int kBiasDmaBase = 2 * TILEB + 2 * VTILEB, kBiasDmaImg = 8192;       // NW wave-private images above the K / V buffers
+    auto load_bias_dma = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (BIAS == 2) {
+            auto one = [&](auto es_t) __attribute__((always_inline)) {
+                constexpr int ES = decltype(es_t)::value, GPR = 64 * ES / 16, RPI = 64 / GPR, NI = 32 / RPI, MASK = (GPR < RPI ? GPR : RPI) - 1;
+                const char* base = (const char*)p.bias + (b * p.bs[0] + h * p.bs[1]) * ES;
+                const uint32_t rowb = (uint32_t)p.bs[2] * ES;
+                const auto brs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(((int64_t)(p.Nq - 1) * p.bs[2] + p.Nkv) * ES), 0x00020000);
+                const int lr = lane / GPR, g = (lane % GPR) ^ (lr & MASK);
+                const int kvg = tile * kKvTile + g * (16 / ES);                         // first kv of this lane's granule
+                const uint32_t voff = kvg < p.Nkv ? (uint32_t)(qw0 + lr) * rowb + (uint32_t)kvg * ES : kOobOffset;
+                char* img = smem + kBiasDmaBase + wave * kBiasDmaImg;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dma16_to_lds(brs, img + i * 1024, voff, (uint32_t)(i * RPI) * rowb);
+            };
+            if (p.bias_kind == 1) one(std::integral_constant<int, 2>{});
+            else if (p.bias_kind == 2) one(std::integral_constant<int, 4>{});
+            else one(std::integral_constant<int, 1>{});
+        }
+    };
     auto load_bias = [&](int tile, u32x32& raw) __attribute__((always_inline)) {
-        if constexpr (BIAS) {
+        if constexpr (BIAS == 2) {
+            load_bias_dma(tile);
+        } else if constexpr (BIAS) {
             const int kv0 = tile * kKvTile + 4 * hi;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
@@ -473,7 +501,48 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
     // s <- s * cs + bias * log2(e)   (boolean mask: s * cs where kept, -inf where not).  One fully separate code path per bias
     // kind (compile-time KIND inside, wave-uniform dispatch outside): shared temporaries across the kinds ended up in scratch.
     auto add_bias = [&](f32x16& s0, f32x16& s1, const u32x32& raw) __attribute__((always_inline)) {
-        if constexpr (BIAS) {
+        if constexpr (BIAS == 2) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's LDS-DMA pieces of the tile have landed (the image is wave-private)
+            auto one = [&](auto es_t) __attribute__((always_inline)) {
+                constexpr int ES = decltype(es_t)::value, GPR = 64 * ES / 16, RPI = 64 / GPR, MASK = (GPR < RPI ? GPR : RPI) - 1;
+                constexpr float kLog2e = 1.4426950408889634f;
+                const char* row = smem + kBiasDmaBase + wave * kBiasDmaImg + l31 * (GPR * 16);
+                const int sw = l31 & MASK;
+#pragma unroll
+                for (int G = 0; G < 8; ++G) {          // group G: kv = 32 (G >> 2) + 8 (G & 3) + 4 hi + e, e = 0..3 -> registers 4 (G & 3) + e of s0 / s1
+                    const int byte = (32 * (G >> 2) + 8 * (G & 3) + 4 * hi) * ES;
+                    const char* src = row + (((byte >> 4) ^ sw) << 4) + (byte & 15);
+                    float bv[4];
+                    if constexpr (ES == 2) {
+                        const u32x2 w = *(const u32x2*)src;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t h16 = (e & 1) ? w[e >> 1] >> 16 : w[e >> 1] & 0xffffu;
+                            bv[e] = (BF16 ? __uint_as_float(h16 << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)h16)) * kLog2e;
+                        }
+                    } else if constexpr (ES == 4) {
+                        const u32x4 w = *(const u32x4*)src;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[e] = __uint_as_float(w[e]) * kLog2e;
+                    } else {
+                        const uint32_t w = *(const uint32_t*)src;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[e] = (w & (0xffu << (8 * e))) ? 0.f : -INFINITY;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {              // (vector elements cannot be bound to references: both halves spelled out)
+                        const int rr = 4 * (G & 3) + e;
+                        const float sc = (G >> 2) ? s1[rr] : s0[rr];
+                        const float nv = ES == 1 ? (bv[e] == 0.f ? sc * cs : -INFINITY) : __builtin_fmaf(sc, cs, bv[e]);
+                        if (G >> 2) s1[rr] = nv;
+                        else s0[rr] = nv;
+                    }
+                }
+            };
+            if (p.bias_kind == 1) one(std::integral_constant<int, 2>{});
+            else if (p.bias_kind == 2) one(std::integral_constant<int, 4>{});
+            else one(std::integral_constant<int, 1>{});
+        } else if constexpr (BIAS) {
             auto one_kind = [&](auto kind_t) __attribute__((always_inline)) {
                 constexpr int KIND = decltype(kind_t)::value;
                 constexpr float kLog2e = 1.4426950408889634f;

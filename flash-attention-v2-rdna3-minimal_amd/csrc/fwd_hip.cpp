@@ -13,13 +13,14 @@ namespace {
 
 constexpr bool kBF16 = FA2_TU_BF16 != 0;
 
-template <int HD, bool CAUSAL, int NW, bool BIAS = false>
+template <int HD, bool CAUSAL, int NW, int BIAS = 0>
 int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
     constexpr int lds_epi = FA2_EPI_LDS ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
     // bias kernels: + NW wave-private 32-row images of the "tile" bias form where they fit (not at D = 512: 160 KiB of K / V buffers)
-    constexpr int lds_bias = BIAS && lds_kv + NW * 32 * 272 <= 160 * 1024 ? NW * 32 * 272 : 0;
+    // (BIAS = 2, the LDS-DMA form: NW images of 8 KiB)
+    constexpr int lds_bias = BIAS == 2 ? NW * 8192 : BIAS && lds_kv + NW * 32 * 272 <= 160 * 1024 ? NW * 32 * 272 : 0;
     constexpr int lds = lds_kv + lds_bias > lds_epi ? lds_kv + lds_bias : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     fa2::FwdParams p = p0;
@@ -47,7 +48,12 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
 // registers per tile come out of the 512-register budget instead of spilling (the 8-wave shape at D = 64 spills 62-67 VGPRs).
 template <int HD, bool CAUSAL>
 int launch_t(const fa2::FwdParams& p, int rows, bool bias, hipStream_t stream) {
-    if (bias) return launch_shape<HD, CAUSAL, 4, true>(p, stream);
+    if constexpr (HD <= 128) {
+        // a dense per-row bias whose geometry allows whole 16-byte granules (p.bias_vec == 3, host.cpp) on a grid that fills the chip: the 8-wave,
+        // 256-row shape with the bias tile staged by LDS-DMA (fa2_fwd_kernel.hip.h, BIAS = 2)
+        if (bias && p.bias_vec == 3) return launch_shape<HD, CAUSAL, 8, 2>(p, stream);
+    }
+    if (bias) return launch_shape<HD, CAUSAL, 4, 1>(p, stream);
     if constexpr (HD > 256) {
         return launch_shape<HD, CAUSAL, 4>(p, stream);
     } else {

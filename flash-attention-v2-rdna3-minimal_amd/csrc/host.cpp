@@ -351,6 +351,12 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         if (p.bias_vec && HD <= 256 && Nkv % gran == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 && p.bs[0] % gran == 0 &&
             p.bs[1] % gran == 0 && p.bs[2] % gran == 0 && p.bs[2] != 0)
             p.bias_vec = 2;
+        // 3: the same geometry on a grid of more than 3/8 of the CUs' worth of 256-row workgroups, head dims <= 128, one (b, h) slice of the bias within
+        // 32-bit byte offsets: the 8-wave shape with the tile staged by LDS-DMA (no bias registers).  Measured (tools/mask_bench.py): dense fp16 bias
+        // shared by the heads, B2 H10 N4096 D64, 445 us as 4-wave workgroups; torch SDPA 339.
+        if (p.bias_vec == 2 && HD <= 128 && forced_rows() != 128 && (int64_t)B * H * ((Nq + 255) / 256) > fa2::device_cus() * 3 / 8 &&
+            ((int64_t)(Nq - 1) * p.bs[2] + Nkv + 64 * p.bs[2]) * (int64_t)esize < 0x7fffffffLL)
+            p.bias_vec = 3;
     }
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 

@@ -331,3 +331,41 @@ def test_masked_backward_causal_fully_masked_rows_and_hook():
     assert float((out.float() - ref).abs().max()) <= 4e-3
     for got, want in ((xd.grad, xf.grad), (cd.grad, cf.grad)):
         assert float((got.float() - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bool", "io", "f32"])
+@pytest.mark.parametrize("D,dt", [(64, torch.float16), (128, torch.bfloat16), (40, torch.float16)])
+def test_dense_masks_on_grids_that_fill_the_chip_take_the_lds_dma_form(kind, D, dt):
+    """A dense per-row mask whose geometry allows whole 16-byte granules, on a grid of more than 3/8 of the CUs' worth of 256-row workgroups, runs
+    the 8-wave kernels with the bias tile staged by LDS-DMA into a swizzled wave-private image (fa2_fwd_kernel.hip.h, BIAS = 2; host.cpp
+    bias_vec = 3).  Every broadcast pattern over batch / head, a padded row pitch, a ragged Nq, a masked tail tile (Nkv = 1000), causal on top,
+    a fully masked row; against dense float64 attention with the same mask and against the 4-wave path (option rows = 128) on the same inputs."""
+    from rocwmma_fattn import _fa2_lib
+    from rocwmma_fattn.FlashAttn import flash_attention
+    dev = torch.device("cuda", 0)
+    B, H, Nq, Nkv = 2, 60, 1000, 1000                      # 2 * 60 * 4 = 480 workgroups of 256 rows
+    g = torch.Generator(device=dev).manual_seed(D + len(kind))
+    q, k, v = (torch.randn((B, H, n, D), generator=g, device=dev).to(dt) for n in (Nq, Nkv, Nkv))
+    for (mb, mh, causal, pitch) in ((B, H, False, 1000), (1, 1, False, 1008), (B, 1, True, 1000), (1, H, False, 1024)):
+        if kind == "bool":
+            full = torch.rand((mb, mh, Nq, pitch), generator=g, device=dev) < 0.8
+            full[:, :, 7] = False                           # a fully masked row
+        else:
+            full = (torch.randn((mb, mh, Nq, pitch), generator=g, device=dev) * 1.5).to(dt if kind == "io" else torch.float32)
+        mask = full[..., :Nkv]                              # (a padded pitch: a view, its rows stay 16-byte aligned)
+        o = flash_attention(q, k, v, mask, causal)
+        with _fa2_lib.options(rows=128):
+            o4 = flash_attention(q, k, v, mask, causal)
+        s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * (D ** -0.5)
+        s = s.masked_fill(~mask, float("-inf")) if kind == "bool" else s + mask.double()
+        if causal:
+            s = s.masked_fill(torch.ones(Nq, Nkv, dtype=torch.bool, device=dev).triu(1), float("-inf"))
+        dead = torch.isinf(s).all(dim=-1, keepdim=True)
+        truth = torch.matmul(torch.softmax(s.masked_fill(dead, 0.0), -1).masked_fill(dead, 0.0), v.double())
+        tol = 2e-3 if dt == torch.float16 else 1.6e-2
+        assert torch.isfinite(o.float()).all()
+        assert float((o.double() - truth).abs().max()) <= tol * max(1.0, float(v.float().abs().max())), (kind, mb, mh, causal)
+        assert float((o.float() - o4.float()).abs().max()) <= tol, (kind, mb, mh, causal)
+        if kind == "bool":
+            assert float(o[:, :, 7].float().abs().max()) == 0.0

@@ -41,6 +41,14 @@ def one_case(i, rng, gen, want_bwd):
     if rng.random() < 0.5:
         Nkv = max(16, Nkv // 16 * 16)                                     # the aligned forms (groups of four, whole 16-byte granules)
     B, H = rng.randint(1, 3), rng.randint(1, 6)
+    if rng.random() < 0.2:
+        # grids that fill the chip: dense per-row masks then run the 8-wave kernels with the tile staged by LDS-DMA (fa2_fwd_kernel.hip.h, BIAS = 2)
+        D = rng.choice([40, 64, 64, 96, 128, 128])
+        Nq = rng.choice([512, 700, 1024, 1500, 2048])
+        Nkv = rng.choice([256, 512, 1000, 1024, 1536, 2040]) // 16 * 16
+        heads = rng.randint(100 // ((Nq + 255) // 256) + 1, 300 // ((Nq + 255) // 256) + 2)
+        B = rng.choice([b for b in (1, 2, 3) if heads % b == 0])
+        H = heads // B
     causal = rng.random() < 0.25
     scale = D ** -0.5 * rng.choice([1.0, 1.0, 1.0, 0.5, 2.0])
     mk = lambda *s: torch.randn(*s, generator=gen, device="cuda").to(dtype)  # noqa: E731

@@ -287,3 +287,48 @@ def test_operator_backward_takes_the_split_path_and_option_turns_it_off():
         assert lib.fa2_bwd_workspace_bytes(0, B, H, N, N, D, 0) == 0
     assert lib.fa2_bwd_workspace_bytes(0, B, H, N, N, D, 1) == 0                  # causal
     assert lib.fa2_bwd_workspace_bytes(0, 2, 16, 4096, 4096, 128, 0) == 0         # the hand-scheduled passes
+
+
+@pytest.mark.gpu
+def test_split_launches_are_graph_capturable_and_stream_safe():
+    """The operator takes the split's workspace from torch's caching allocator per call, so a captured graph owns its scratch memory (graph pool)
+    and two streams never share one: capture a forward of a split shape, replay it on new inputs, and run two streams concurrently."""
+    B, H, N, D = 2, 10, 4096, 64
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    mk = lambda: torch.randn((B, H, N, D), generator=g).half().to(dev)  # noqa: E731
+    q, k, v = mk(), mk(), mk()
+    lib = _fa2_lib.load(build_if_missing=False)
+    assert lib.fa2_fwd_workspace_bytes(0, B, H, N, N, D, 0) > 0
+    want = FlashAttentionFunction.apply(q, k, v, None, False).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            FlashAttentionFunction.apply(q, k, v, None, False)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = FlashAttentionFunction.apply(q, k, v, None, False)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    q2 = mk()
+    want2 = FlashAttentionFunction.apply(q2, k, v, None, False).clone()
+    q.copy_(q2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2)
+    # two streams at once, different inputs: each call has its own workspace
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    qa, qb = mk(), mk()
+    wa, wb = FlashAttentionFunction.apply(qa, k, v, None, False).clone(), FlashAttentionFunction.apply(qb, k, v, None, False).clone()
+    torch.cuda.synchronize()
+    outs = []
+    for st, qq in ((s1, qa), (s2, qb)):
+        with torch.cuda.stream(st):
+            for _ in range(4):
+                o = FlashAttentionFunction.apply(qq, k, v, None, False)
+            outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], wa) and torch.equal(outs[1], wb)

@@ -160,7 +160,10 @@ def one_case(i, rng, gen, want_bwd):
         smag = (q.float().abs().max() * k.float().abs().max() * D * abs(scale) * LOG2E).item()
         lim = max(1e-3, 4e-6 * smag)
         if D == 64 and dtype == torch.bfloat16:
-            lim = max(lim, 4e-3)      # causal / wide launches run the hand-scheduled body, whose row sums add the ROUNDED P (tests/test_parity_gpu.py: 4e-3)
+            # causal / wide launches run the hand-scheduled body, whose row sums add the ROUNDED P: when one key dominates a row (large logits) the sum
+            # carries that single term's bf16 rounding, log2(1 + 2^-9) = 2.8e-3, on top of the f32 bound (tests hold it to 4e-3 against the oracle
+            # under the same contract; against float64 truth, with logits scaled 3x: 4.4e-3 seen)
+            lim = max(lim, 2.8e-3 + lim, 5e-3)
         lerr = (lse.double() - lse_true).abs().max().item()
         if alt is not None:
             lerr = min(lerr, (lse.double() - alt[1]).abs().max().item())

@@ -332,3 +332,18 @@ def test_split_launches_are_graph_capturable_and_stream_safe():
             outs.append(o)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], wa) and torch.equal(outs[1], wb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,dt", [(64, 0), (128, 1)])
+def test_split_parts_with_one_workgroup_per_item(D, dt):
+    """Option persist = 0 launches one workgroup per list entry of the hand-scheduled kernels — whole items and KV-split parts alike — instead of
+    persistent workgroups: the arithmetic of an entry does not depend on how it was scheduled, so the merged result is bit-identical."""
+    B, H, N = 1, 24, 4096 if D == 128 else 3072
+    g = torch.Generator(device="cpu").manual_seed(12 + D)
+    q, k, v = (torch.randn((B, H, N, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(3))
+    o1, l1, need = _fwd(q, k, v, "ws")
+    assert need > 0
+    with _fa2_lib.options(persist=0):
+        o0, l0, _ = _fwd(q, k, v, "ws")
+    assert torch.equal(o1.view(torch.int16), o0.view(torch.int16)) and torch.equal(l1, l0)

@@ -13,33 +13,58 @@ namespace {
 
 constexpr bool kBF16 = FA2_TU_BF16 != 0;
 
+template <int HD, bool CAUSAL, int FORM>
+int launch_form(fa2::BwdParams p, hipStream_t stream);
+
+// FORM 2: bias tiles by LDS-DMA where the geometry allows and the images fit the LDS; FORM 1: one guarded load per score
 template <int HD, bool CAUSAL>
 int launch_t(fa2::BwdParams p, hipStream_t stream) {
+    constexpr int NW = HD > 128 ? 4 : 8;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB, kStages = NW == 8 ? 2 : 1;
+    if (p.bias_tile && kStages * (3 * TILEB + 512) + NW * p.bias_img <= 160 * 1024) return launch_form<HD, CAUSAL, 2>(p, stream);
+    p.bias_tile = 0;
+    return launch_form<HD, CAUSAL, 1>(p, stream);
+}
+
+template <int HD, bool CAUSAL, int FORM>
+int launch_form(fa2::BwdParams p, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
     constexpr int TILEB = fa2::Geo<HD, NW>::TILEB;
     int rc;
+    // bias tiles staged by LDS-DMA (p.bias_tile, host.cpp): NW wave-private images above the stages, where they fit the 160 KiB
+    const int img = p.bias_tile ? NW * p.bias_img : 0;
+    auto fits = [&](int base) { return base + img <= 160 * 1024; };
     {
-        constexpr int lds = kStages * 3 * TILEB;
-        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HD, true>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        p.nblk = (p.Nq + kRows - 1) / kRows;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        constexpr int lds0 = kStages * 3 * TILEB;
+        fa2::BwdParams pq = p;
+        if (!fits(lds0)) pq.bias_tile = 0;
+        const int lds = lds0 + (pq.bias_tile ? img : 0);
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HD, FORM>;
+        if ((rc = fa2::set_lds<kern>(160 * 1024))) return rc;
+        pq.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * pq.nblk)), dim3(NW * 64), lds, stream, pq);
         if ((rc = (int)hipGetLastError())) return rc;
     }
     p.nblk = (p.Nkv + kRows - 1) / kRows;
     {
-        constexpr int lds = kStages * (2 * TILEB + 512);
-        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HD, true>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        constexpr int lds0 = kStages * (2 * TILEB + 512);
+        fa2::BwdParams pv = p;
+        if (!fits(lds0)) pv.bias_tile = 0;
+        const int lds = lds0 + (pv.bias_tile ? img : 0);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HD, FORM>;
+        if ((rc = fa2::set_lds<kern>(160 * 1024))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, pv);
         if ((rc = (int)hipGetLastError())) return rc;
     }
     {
-        constexpr int lds = kStages * (3 * TILEB + 512);
-        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HD, true>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+        constexpr int lds0 = kStages * (3 * TILEB + 512);
+        fa2::BwdParams pk = p;
+        if (!fits(lds0)) pk.bias_tile = 0;
+        const int lds = lds0 + (pk.bias_tile ? img : 0);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HD, FORM>;
+        if ((rc = fa2::set_lds<kern>(160 * 1024))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, pk);
         if ((rc = (int)hipGetLastError())) return rc;
     }
     return 0;

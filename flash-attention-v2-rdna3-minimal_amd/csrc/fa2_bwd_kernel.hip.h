@@ -48,6 +48,9 @@ struct BwdParams {
     const void* bias;
     int64_t bs[3];
     int bias_kind;
+    int bias_tile;        // host: the bias geometry allows whole 16-byte granules -> a wave stages its tile of the bias by LDS-DMA (bwd_bias_tile_*);
+                          // 0: one guarded load per score (any alignment, any strides)
+    int bias_img;         // bytes of one wave's bias image (4096, or 8192 for f32)
     // split of a partly filled last round of 256-row workgroups (fa2_bwd_ws; non-causal, unbiased, 8-wave kernels; FwdParams has the
     // forward's twin): the last `split_items` workgroups of the pass being launched are each replaced by `nsplit` parts that sweep disjoint
     // tile ranges and leave f32 partial accumulators in `ws`; bwd_merge_kernel sums them.  The launcher fills these per pass.
@@ -67,20 +70,6 @@ __device__ __forceinline__ void store_partial_t(const f32x16 (&acc)[DT], float* 
             const f32x16& a = acc[dt];
             *(f32x4*)(tile + ((dt * 4 + g) * kSplitRows + row) * 8 + 4 * hi) = (f32x4){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
         }
-}
-
-// log2-domain bias term of score (q, kv) of head (b, h): bias * log2(e), or -inf where a boolean keep-mask is zero.  One guarded load per
-// element (the bias may be broadcast with zero strides and have any alignment): a correct path for the SD hosts' masks, not a tuned one.
-template <bool BF16>
-__device__ __forceinline__ float bwd_bias_term(const BwdParams& p, int b, int h, int q, int kv) {
-    const int64_t idx = b * p.bs[0] + h * p.bs[1] + (int64_t)q * p.bs[2] + kv;
-    if (p.bias_kind == 1) {
-        const uint16_t raw = ((const uint16_t*)p.bias)[idx];
-        const float f = BF16 ? __uint_as_float((uint32_t)raw << 16) : (float)__builtin_bit_cast(_Float16, raw);
-        return f * 1.4426950408889634f;
-    }
-    if (p.bias_kind == 2) return ((const float*)p.bias)[idx] * 1.4426950408889634f;
-    return ((const uint8_t*)p.bias)[idx] ? 0.f : -__builtin_inff();
 }
 
 // The backward kernels address LDS through address-space-3 pointers only (no generic pointers into LDS): besides
@@ -122,6 +111,98 @@ __device__ __forceinline__ float dot8(u32x4 a, u32x4 g) {
         for (int e = 0; e < 8; ++e) acc += (float)ah[e] * (float)gh[e];
     }
     return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Bias tiles of the masked backward (round 3; fa2_fwd_kernel.hip.h has the forward's, BIAS = 2).  One guarded load per score made the masked
+// backward 15x the unmasked one (with lane = Q row every load instruction touches 32 cache lines for a few useful bytes).  Where the bias
+// geometry allows whole 16-byte granules (pointer, strides, Nkv multiples of 16 bytes; a per-row bias) a wave stages its tile by LDS-DMA into a
+// wave-private image and reads its scores' values back from there.  Rows / granules out of range of the descriptor read zeros: such scores
+// are masked or belong to rows that are never stored.
+//   dQ pass   (lane = Q row): 32 rows x 64 kv, granule g of row r at slot g ^ (r & MASK)  — the forward's image
+//   dK/dV pass (lane = KV row): 64 q rows x 32 kv of the wave, row-major, no swizzle (a register's 32 lanes read 32 consecutive elements)
+template <int ES>
+__device__ __forceinline__ auto bwd_bias_rsrc(const BwdParams& p, int b, int h) {
+    const char* base = (const char*)p.bias + (b * p.bs[0] + h * p.bs[1]) * ES;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(((int64_t)(p.Nq - 1) * p.bs[2] + p.Nkv) * ES), 0x00020000);
+}
+
+// element form: one bounds-checked buffer load per score, 32-bit offsets inside the (b, h) slice (host: the slice spans < 2 GiB); out of range -> 0
+template <int ES, bool BF16, typename RSRC>
+__device__ __forceinline__ float bwd_bias_elem(RSRC brs, uint32_t voff) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    if constexpr (ES == 2) {
+        const uint16_t w = __builtin_amdgcn_raw_buffer_load_b16(brs, voff, 0, 0);
+        return (BF16 ? __uint_as_float((uint32_t)w << 16) : (float)__builtin_bit_cast(_Float16, w)) * kLog2e;
+    } else if constexpr (ES == 4) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, voff, 0, 0)) * kLog2e;
+    } else {
+        return __builtin_amdgcn_raw_buffer_load_b8(brs, voff, 0, 0) ? 0.f : -__builtin_inff();
+    }
+}
+
+template <int ES>
+__device__ __forceinline__ void bwd_bias_tile_dq_load(const BwdParams& p, int b, int h, int qw0, int kv0, int lane, lds_char_ptr img) {
+    constexpr int GPR = 64 * ES / 16, RPI = 64 / GPR, NI = 32 / RPI, MASK = (GPR < RPI ? GPR : RPI) - 1;
+    const uint32_t rowb = (uint32_t)p.bs[2] * ES;
+    const auto brs = bwd_bias_rsrc<ES>(p, b, h);
+    const int lr = lane / GPR, g = (lane % GPR) ^ (lr & MASK);
+    const int kvg = kv0 + g * (16 / ES);
+    const uint32_t voff = kvg < p.Nkv ? (uint32_t)(qw0 + lr) * rowb + (uint32_t)kvg * ES : kOobOffset;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dma16_to_lds3(brs, img + i * 1024, voff, (uint32_t)(i * RPI) * rowb);
+}
+
+// log2-domain bias terms of the four scores kv = kv0 + 32 half + 8 g + 4 hi + e of this lane's row (dQ pass image)
+template <int ES, bool BF16>
+__device__ __forceinline__ void bwd_bias_tile_dq_read(lds_char_ptr img, int l31, int hi, int half, int g, float (&bv)[4]) {
+    constexpr int GPR = 64 * ES / 16, RPI = 64 / GPR, MASK = (GPR < RPI ? GPR : RPI) - 1;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int byte = (32 * half + 8 * g + 4 * hi) * ES;
+    const lds_char_ptr src = img + l31 * (GPR * 16) + (((byte >> 4) ^ (l31 & MASK)) << 4) + (byte & 15);
+    if constexpr (ES == 2) {
+        const u32x2 w = *(const __attribute__((address_space(3))) u32x2*)src;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t h16 = (e & 1) ? w[e >> 1] >> 16 : w[e >> 1] & 0xffffu;
+            bv[e] = (BF16 ? __uint_as_float(h16 << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)h16)) * kLog2e;
+        }
+    } else if constexpr (ES == 4) {
+        const u32x4 w = *(const __attribute__((address_space(3))) u32x4*)src;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = __uint_as_float(w[e]) * kLog2e;
+    } else {
+        const uint32_t w = *(const __attribute__((address_space(3))) uint32_t*)src;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (w & (0xffu << (8 * e))) ? 0.f : -__builtin_inff();
+    }
+}
+
+template <int ES>
+__device__ __forceinline__ void bwd_bias_tile_kv_load(const BwdParams& p, int b, int h, int q0t, int kvw0, int lane, lds_char_ptr img) {
+    constexpr int GPR = 32 * ES / 16, RPI = 64 / GPR, NI = 64 / RPI;          // a row of the image: the wave's 32 kv
+    const uint32_t rowb = (uint32_t)p.bs[2] * ES;
+    const auto brs = bwd_bias_rsrc<ES>(p, b, h);
+    const int lr = lane / GPR, g = lane % GPR;
+    const int kvg = kvw0 + g * (16 / ES);
+    const uint32_t voff = kvg < p.Nkv ? (uint32_t)(q0t + lr) * rowb + (uint32_t)kvg * ES : kOobOffset;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dma16_to_lds3(brs, img + i * 1024, voff, (uint32_t)(i * RPI) * rowb);
+}
+
+// log2-domain bias term of score (tile row ql, this lane's kv row l31) (dK/dV pass image)
+template <int ES, bool BF16>
+__device__ __forceinline__ float bwd_bias_tile_kv_read(lds_char_ptr img, int ql, int l31) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const lds_char_ptr src = img + ql * (32 * ES) + l31 * ES;
+    if constexpr (ES == 2) {
+        const uint16_t w = *(const __attribute__((address_space(3))) uint16_t*)src;
+        return (BF16 ? __uint_as_float((uint32_t)w << 16) : (float)__builtin_bit_cast(_Float16, w)) * kLog2e;
+    } else if constexpr (ES == 4) {
+        return *(const __attribute__((address_space(3))) float*)src * kLog2e;
+    } else {
+        return *(const __attribute__((address_space(3))) uint8_t*)src ? 0.f : -__builtin_inff();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -186,7 +267,7 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // the whole head dim (Q / dO fragments of all HD columns in registers: the 512-register budget of one wave per SIMD), only the K^T image
 // and the accumulator are slab-sized; every slab recomputes S and dP (a correct path for the SD-VAE-sized head dim, not a tuned one).
 // BIAS: the forward was fa2_fwd_bias — P = 2^(S c + bias log2e - L); a fully masked row (L = -inf) has P = 0.
-template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD, bool BIAS = false>
+template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD, int BIAS = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_dq_kernel(const BwdParams p) {
     using L_ = BwdLane<HD, NW>;
     using LV_ = BwdLane<HDV, NW>;             // geometry of the transposed-read image (the slab)
@@ -327,6 +408,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
     // at the join in every iteration (64 v_mov per tile in the ISA); the mask is a wave-uniform block instead.
     auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {
         {
+            if constexpr (BIAS == 2) {
+                {                           // this wave's bias tile: in flight under the S products
+                    const lds_char_ptr bimg = smem + (DBUF ? 2 : 1) * STAGEB + wave * p.bias_img;
+                    if (p.bias_kind == 1) bwd_bias_tile_dq_load<2>(p, b, h, qw0, tile * kKvTile, lane, bimg);
+                    else if (p.bias_kind == 2) bwd_bias_tile_dq_load<4>(p, b, h, qw0, tile * kKvTile, lane, bimg);
+                    else bwd_bias_tile_dq_load<1>(p, b, h, qw0, tile * kKvTile, lane, bimg);
+                }
+            }
             const lds_char_ptr kR = smem + st * STAGEB;
             const lds_char_ptr vR = kR + TILEB;
             const lds_char_ptr kT3 = kR + 2 * TILEB;
@@ -342,16 +431,50 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
             const int lim_c = CAUSAL ? qrow : 0x7fffffff;
             const int lim = lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1;   // kv index must be <= lim (MASKED tiles only)
             // P^T = 2^(S^T c - L); masked entries -> 0
+            constexpr bool tiled = BIAS == 2;       // (BIAS = 1: one load per score; the two forms are separate instantiations — together
+                                                    //  they spilled hundreds of bytes per lane)
+            if constexpr (BIAS == 1) {
+                // element form (any alignment, broadcast rows: a [B,1,1,Nkv] key-padding mask): bounds-checked buffer loads with 32-bit offsets, the
+                // kind dispatched once outside the loop (guarded 64-bit loads with the kind inside it spilled 400-1000 bytes per lane)
+                auto one = [&](auto es_t) __attribute__((always_inline)) {
+                    constexpr int ES = decltype(es_t)::value;
+                    const auto brs = bwd_bias_rsrc<ES>(p, b, h);
+                    const uint32_t v0 = (uint32_t)qr * (uint32_t)p.bs[2] * ES + (uint32_t)(kv0 + 4 * hi) * ES;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float b0 = -Lq, b1 = -Lq;
-                if constexpr (BIAS) {
-                    const int kvi = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kvi < p.Nkv) b0 += bwd_bias_term<BF16>(p, b, h, qr, kvi);
-                    if (kvi + 32 < p.Nkv) b1 += bwd_bias_term<BF16>(p, b, h, qr, kvi + 32);
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t vo = v0 + ((r & 3) + 8 * (r >> 2)) * ES;
+                        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, bwd_bias_elem<ES, BF16>(brs, vo) - Lq));
+                        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, bwd_bias_elem<ES, BF16>(brs, vo + 32 * ES) - Lq));
+                    }
+                };
+                if (p.bias_kind == 1) one(std::integral_constant<int, 2>{});
+                else if (p.bias_kind == 2) one(std::integral_constant<int, 4>{});
+                else one(std::integral_constant<int, 1>{});
+            } else if constexpr (tiled) {
+                // the wave's 32 x 64 tile of the bias, staged by LDS-DMA at the top of the body (bias_issue below), read back in groups of four kv
+                const lds_char_ptr bimg = smem + (DBUF ? 2 : 1) * STAGEB + wave * p.bias_img;
+                __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): the pieces have landed (wave-private image)
+#pragma unroll
+                for (int G = 0; G < 8; ++G) {
+                    float bv[4];
+                    if (p.bias_kind == 1) bwd_bias_tile_dq_read<2, BF16>(bimg, l31, hi, G >> 2, G & 3, bv);
+                    else if (p.bias_kind == 2) bwd_bias_tile_dq_read<4, BF16>(bimg, l31, hi, G >> 2, G & 3, bv);
+                    else bwd_bias_tile_dq_read<1, BF16>(bimg, l31, hi, G >> 2, G & 3, bv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * (G & 3) + e;
+                        if (G >> 2) s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, bv[e] - Lq));
+                        else s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, bv[e] - Lq));
+                    }
                 }
-                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
-                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
+                // (kv >= Nkv: the image holds zeros or a neighbouring row's values, P stays finite; the MASKED block below zeroes those entries)
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float b0 = -Lq, b1 = -Lq;
+                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
+                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
+                }
             }
             if (masked) {
 #pragma unroll
@@ -425,7 +548,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
 // additionally carries dO in tr-form (Q row | dO row | Q tr | dO tr).
 // HDV < HD (HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dK / dV; S (and dP) are contracted over the whole head
 // dim, only the transposed-read image and the accumulator are slab-sized (see bwd_dq_kernel).
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD, bool BIAS = false>
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD, int BIAS = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
     static_assert(!BOTH || WANT_DK, "the fused pass is the dK pass plus a dV accumulator");
     static_assert(!BOTH || HDV == HD, "slabs exist for the separate passes only");
@@ -562,6 +685,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
 
     auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {       // one body: see bwd_dq_kernel
         {
+            constexpr bool tiled = BIAS == 2;
+            lds_char_ptr bimg = smem;
+            if constexpr (tiled) {
+                {                           // this wave's 64 x 32 tile of the bias (Q tile rows x its own KV rows): in flight under the S products
+                    bimg = smem + (DBUF ? 2 : 1) * STAGEB + wave * p.bias_img;
+                    if (p.bias_kind == 1) bwd_bias_tile_kv_load<2>(p, b, h, tile * kKvTile, kvw0, lane, bimg);
+                    else if (p.bias_kind == 2) bwd_bias_tile_kv_load<4>(p, b, h, tile * kKvTile, kvw0, lane, bimg);
+                    else bwd_bias_tile_kv_load<1>(p, b, h, tile * kKvTile, kvw0, lane, bimg);
+                }
+            }
             const lds_char_ptr qR = smem + st * STAGEB;
             const lds_char_ptr lt = qR + LOFF;
             f32x16 s0, s1;
@@ -584,24 +717,48 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                 }
             }
             const int q0t = tile * kKvTile;
-            // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32)
+            if constexpr (tiled) __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the bias tile has landed (wave-private image)
+            // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32).  The loop is a generic lambda over the
+            // bias element size: the kind of a masked call is dispatched ONCE, outside it (inside, the three kinds' code per element spilled).
             typedef float f32x4 __attribute__((ext_vector_type(4)));
+            auto p_loop = [&](auto es_t) __attribute__((always_inline)) {
+                constexpr int ES = decltype(es_t)::value;
+                [[maybe_unused]] const auto brs = bwd_bias_rsrc<ES>(p, b, h);
+                [[maybe_unused]] const uint32_t rowb = (uint32_t)p.bs[2];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 L0 = *(const __attribute__((address_space(3))) f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
-                const f32x4 L1 = *(const __attribute__((address_space(3))) f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 L0 = *(const __attribute__((address_space(3))) f32x4*)(lt + (8 * g4 + 4 * hi) * 4);
+                    const f32x4 L1 = *(const __attribute__((address_space(3))) f32x4*)(lt + (32 + 8 * g4 + 4 * hi) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    float b0 = -L0[e], b1 = -L1[e];
-                    if constexpr (BIAS) {        // (a fully masked row, L = -inf: P = 0)
-                        const int qi = q0t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        b0 = L0[e] == -__builtin_inff() ? -__builtin_inff() : b0 + (qi < p.Nq ? bwd_bias_term<BF16>(p, b, h, qi, kr) : 0.f);
-                        b1 = L1[e] == -__builtin_inff() ? -__builtin_inff() : b1 + (qi + 32 < p.Nq ? bwd_bias_term<BF16>(p, b, h, qi + 32, kr) : 0.f);
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        float b0 = -L0[e], b1 = -L1[e];
+                        if constexpr (BIAS) {        // (a fully masked row, L = -inf: P = 0)
+                            const int ql = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            float t0, t1;
+                            if constexpr (tiled) {
+                                t0 = bwd_bias_tile_kv_read<ES, BF16>(bimg, ql, l31);
+                                t1 = bwd_bias_tile_kv_read<ES, BF16>(bimg, ql + 32, l31);
+                            } else {
+                                // element form: bounds-checked buffer loads, 32-bit offsets (rows >= Nq are out of range and read 0; their P is never used)
+                                const uint32_t vq = (uint32_t)(q0t + ql) * rowb + (uint32_t)kr;
+                                t0 = bwd_bias_elem<ES, BF16>(brs, vq * ES);
+                                t1 = bwd_bias_elem<ES, BF16>(brs, (vq + 32 * rowb) * ES);
+                            }
+                            b0 = L0[e] == -__builtin_inff() ? -__builtin_inff() : b0 + t0;
+                            b1 = L1[e] == -__builtin_inff() ? -__builtin_inff() : b1 + t1;
+                        }
+                        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
+                        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
                     }
-                    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, b0));
-                    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, b1));
                 }
+            };
+            if constexpr (BIAS) {
+                if (p.bias_kind == 1) p_loop(std::integral_constant<int, 2>{});
+                else if (p.bias_kind == 2) p_loop(std::integral_constant<int, 4>{});
+                else p_loop(std::integral_constant<int, 1>{});
+            } else {
+                p_loop(std::integral_constant<int, 2>{});
             }
             if (CAUSAL && masked) {               // causal: pairs with kv > q contribute nothing (wave-uniform branch)
 #pragma unroll

@@ -36,8 +36,22 @@ FA2_HIDDEN int device_cus();           // compute units of the current device (c
 struct SplitPlan { int full_items = 0, split_items = 0, nsplit = 0; int64_t bytes = 0; };
 constexpr int64_t kMaxSplitWsBytes = 64ll << 20;
 
-inline SplitPlan plan_tail_split(int64_t items, int nt, double us_per_tile, double fixed_us, int64_t tile_bytes, int64_t cus) {
+// underfilled = true additionally splits EVERY item of a grid that covers at most half of the CUs (a KV-owned pass over a short KV — the dK / dV
+// pass of SD cross-attention, Nkv = 77: B*H workgroups in all — sweeps thousands of Q rows on a tenth of the chip).
+inline SplitPlan plan_tail_split(int64_t items, int nt, double us_per_tile, double fixed_us, int64_t tile_bytes, int64_t cus, bool underfilled = false) {
     SplitPlan none;
+    if (underfilled && items >= 1 && items <= cus / 2) {
+        int S = (int)(cus / items < kMaxSplit ? cus / items : kMaxSplit);
+        while (S > 1 && (nt / S < 8 || items * S * tile_bytes > kMaxSplitWsBytes)) --S;
+        const double t_item = nt * us_per_tile;
+        if (S < 2 || t_item * (1.0 - 1.0 / S) < 2.0 * fixed_us) return none;
+        SplitPlan pl;
+        pl.full_items = 0;
+        pl.split_items = (int)items;
+        pl.nsplit = S;
+        pl.bytes = items * S * tile_bytes;
+        return pl;
+    }
     if (items <= cus || items > 0x7fffffffLL || cus <= 0) return none;
     const int64_t r = items % cus;
     if (r == 0) return none;
@@ -91,7 +105,7 @@ inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan
     if (HD == 128 && p.D == 128 && (options().asm_mask.load(std::memory_order_relaxed) & 2)) return 0;      // the hand-scheduled passes
     const int64_t cus = device_cus(), bh = (int64_t)p.B * p.H, tile_bytes = (int64_t)kSplitRows * HD * 4;
     *dq = plan_tail_split(bh * ((p.Nq + 255) / 256), (p.Nkv + kKvTile - 1) / kKvTile, 1.35 * HD / 64.0, 10.0, tile_bytes, cus);
-    if (HD <= 64) *dkv = plan_tail_split(bh * ((p.Nkv + 255) / 256), (p.Nq + kKvTile - 1) / kKvTile, 1.8 * HD / 64.0, 10.0, 2 * tile_bytes, cus);
+    if (HD <= 64) *dkv = plan_tail_split(bh * ((p.Nkv + 255) / 256), (p.Nq + kKvTile - 1) / kKvTile, 1.8 * HD / 64.0, 10.0, 2 * tile_bytes, cus, true);
     return dq->bytes > dkv->bytes ? dq->bytes : dkv->bytes;
 }
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)

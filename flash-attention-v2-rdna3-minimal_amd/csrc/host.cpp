@@ -463,6 +463,19 @@ static int bwd_impl(int dtype, const void* q, const void* k, const void* v, cons
     p.bias = bias;
     p.bias_kind = bias_kind;
     for (int i = 0; i < 3; ++i) p.bs[i] = bias_kind != FA2_BIAS_NONE ? bias_strides[i] : 0;
+    // bias tiles by LDS-DMA (fa2_bwd_kernel.hip.h: bwd_bias_tile_*): a per-row bias whose pointer, strides and Nkv are multiples of 16 bytes, one
+    // (b, h) slice within 32-bit byte offsets; otherwise one guarded load per score
+    p.bias_tile = 0;
+    p.bias_img = 4096;
+    if (bias_kind != FA2_BIAS_NONE) {
+        const int64_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1, gran = 16 / esize;
+        // the backward addresses one (b, h) slice of the bias with 32-bit byte offsets (bounds-checked buffer loads), like K and V
+        if (((int64_t)(Nq - 1) * p.bs[2] + Nkv + 64 * p.bs[2]) * esize >= 0x7fffffffLL) return FA2_ERR_BAD_SHAPE;
+        if (bias_kind == FA2_BIAS_F32) p.bias_img = 8192;
+        if (Nkv % gran == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 && p.bs[0] % gran == 0 && p.bs[1] % gran == 0 && p.bs[2] % gran == 0 &&
+            p.bs[2] != 0)
+            p.bias_tile = 1;
+    }
     p.full_items = p.split_items = p.nsplit = 0;
     p.ws = (float*)ws;
     p.ws_bytes = ws_bytes;

@@ -206,8 +206,10 @@ size_t fa2_bwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, 
  * Backward through fa2_fwd_bias: the gradients of O = softmax(scale * Q K^T + bias [+ causal mask]) V with respect to Q, K, V (the bias /
  * mask itself is a constant of the call: it receives no gradient).  o and lse are the outputs of the fa2_fwd_bias call with the SAME bias
  * arguments; fully masked rows (lse = -inf) contribute nothing.  Arguments as fa2_bwd plus the bias triple of fa2_fwd_bias.
- * Three launches of the compiler-scheduled passes (dQ, dV, dK) with one guarded bias load per score: correct, not tuned.  Head dims up
- * to 256 (FA2_ERR_HEAD_DIM above).  The reference has no counterpart (its `mask` is ignored, FlashAttn.py:49/:74).
+ * Three launches of the compiler-scheduled passes (dQ, dV, dK); a per-row bias whose pointer, strides and Nkv are multiples of 16 bytes is staged
+ * tile by tile with LDS-DMA, anything else (a broadcast key-padding row, Nkv = 77) read with one bounds-checked load per score.  One (b, h) slice of the
+ * bias must span < 2 GiB (FA2_ERR_BAD_SHAPE).  Head dims up to 256 (FA2_ERR_HEAD_DIM above).  The reference has no counterpart (its `mask` is
+ * ignored, FlashAttn.py:49/:74).
  */
 int fa2_bwd_bias(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                  void* dq, void* dk, void* dv, float* delta_ws,

@@ -347,3 +347,33 @@ def test_split_parts_with_one_workgroup_per_item(D, dt):
     with _fa2_lib.options(persist=0):
         o0, l0, _ = _fwd(q, k, v, "ws")
     assert torch.equal(o1.view(torch.int16), o0.view(torch.int16)) and torch.equal(l1, l0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 10, 4096, 77, 64, 0), (2, 8, 4096, 77, 40, 1), (1, 6, 2048, 300, 64, 0)])
+def test_short_kv_backward_splits_every_kv_owner(shape):
+    """Cross-attention backward (Nkv = 77): the KV-owned dK / dV pass has B*H workgroups in all, each sweeping every Q row — a tenth of the chip.
+    With a workspace (fa2_bwd_ws) every one of them is split along its Q sweep (plan_tail_split, underfilled grids) and merged.  Against the plain
+    call, the oracle and float64 autograd."""
+    from conftest import GRAD_TOL
+    B, H, N, Nkv, D, dt = shape
+    g = torch.Generator(device="cpu").manual_seed(4000 + D + Nkv)
+    q, do = (torch.randn((B, H, N, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+    k, v = (torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+    o, lse, gw, need = _fwd_bwd(q, k, v, do, "ws")
+    assert need > 0
+    _, _, gp, _ = _fwd_bwd(q, k, v, do, "none")
+    for name, a, b_ in zip("qkv", gw, gp):
+        assert torch.isfinite(a.float()).all(), name
+        tol = (2.0 ** -10 if dt == 0 else 2.0 ** -7) * max(1.0, float(b_.float().abs().max()))
+        assert float((a.float() - b_.float()).abs().max()) <= tol, name
+    for (b, h) in {(0, 0), (B - 1, H - 1)}:
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        want = fo.bwd_c(_bits(q[sl]), _bits(k[sl]), _bits(v[sl]), _bits(o[sl]), _bits(do[sl]), lse[sl].cpu().numpy(), dt, False)
+        for name, gt, w_bits in zip("qkv", gw, want):
+            w = fo.bits_to_f32(w_bits, dt)
+            assert np.abs(gt[sl].float().cpu().numpy() - w).max() <= GRAD_TOL[dt] * max(1.0, np.abs(w).max()), (name, (b, h))
+        qd, kd, vd = (t[sl].double().requires_grad_(True) for t in (q, k, v))
+        torch.nn.functional.scaled_dot_product_attention(qd, kd, vd).backward(do[sl].double())
+        for name, gt, w in zip("qkv", gw, (qd.grad, kd.grad, vd.grad)):
+            assert float((gt[sl].double() - w).abs().max()) <= GRAD_TOL[dt] * max(1.0, float(w.abs().max())), (name, (b, h))

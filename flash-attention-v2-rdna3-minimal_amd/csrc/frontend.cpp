@@ -5,6 +5,7 @@
 // reference's N-padded shapes, launch on torch's current stream) — about 6 us of host time per call instead of 11, which
 // only matters for back-to-back tiny calls (an SDXL cross-attention layer).  Optional: when this module is not built the
 // Python implementation is used; results are identical (tests/test_parity_gpu.py::test_compiled_front_end_matches_python).
+// `backward` (unmasked calls) likewise: the Python backward costs ~50 us of host time per call, which SD-size training shapes are bound by.
 //
 // Host-only C++ (g++): no device code here, the kernels live in libfa2_gfx950.so.
 #include <torch/extension.h>
@@ -95,9 +96,46 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     return {O_fwd, qp, kp, vp, O, L};
 }
 
+// backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH) -> [dQ, dK, dV] of the reference's module
+// (rocwmma_fattn/host.cpp:47-58, kernel_fp16.cu:878-1028), what _FlashAttnWmma.backward does in Python for unmasked calls: outputs and the delta
+// workspace from torch's allocator, the split's scratch when fa2_bwd_workspace_bytes asks for it, results sliced to the actual sizes.
+std::vector<at::Tensor> backward(at::Tensor Q, at::Tensor K, at::Tensor V, at::Tensor O, at::Tensor dO, at::Tensor L, int64_t act_n, int64_t act_nkv,
+                                 int64_t act_d, int64_t Br, int64_t Bc, bool causal, double scale, bool permute_NH) {
+    (void)Br;
+    (void)Bc;
+    TORCH_CHECK(Q.is_cuda() && dO.is_cuda(), "fa2: tensors must be on a ROCm device (no CPU path in this operator)");
+    const int n_ax = permute_NH ? 1 : 2, h_ax = permute_NH ? 2 : 1;
+    const int64_t b = Q.size(0), h = Q.size(h_ax), dk = Q.size(3);
+    const int dtype_code = Q.scalar_type() == at::kHalf ? FA2_DTYPE_F16 : FA2_DTYPE_BF16;
+    if (dO.scalar_type() != Q.scalar_type()) dO = dO.to(Q.scalar_type());          // host.cpp:47-58 dispatches on dO's dtype; Q's wins here
+    if (dO.size(3) != dk) dO = at::constant_pad_nd(dO, {0, dk - dO.size(3)});        // kernel_fp16.cu:900-905
+    dO = kernel_ready(dO);
+    at::Tensor dQ = at::empty(Q.sizes(), Q.options()), dK = at::empty(K.sizes(), K.options()), dV = at::empty(V.sizes(), V.options());
+    at::Tensor delta = at::empty({b, h, L.size(2)}, L.options());
+    if (L.strides() != delta.strides()) L = L.contiguous();
+    auto s3 = [&](const at::Tensor& t, int64_t* out) {
+        out[0] = t.stride(0);
+        out[1] = t.stride(h_ax);
+        out[2] = t.stride(n_ax);
+    };
+    int64_t qs[3], ks[3], vs[3], os[3], gs[3], dqs[3], dks[3], dvs[3], ls[2] = {L.stride(0), L.stride(1)};
+    s3(Q, qs); s3(K, ks); s3(V, vs); s3(O, os); s3(dO, gs); s3(dQ, dqs); s3(dK, dks); s3(dV, dvs);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
+    const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Q.device().index()).stream();
+    at::Tensor ws;
+    const size_t ws_bytes = causal ? 0 : fa2_bwd_workspace_bytes(dtype_code, (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, 0);
+    if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, Q.options().dtype(at::kByte));
+    const int rc = fa2_bwd_ws(dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr<float>(), dQ.data_ptr(),
+                              dK.data_ptr(), dV.data_ptr(), delta.data_ptr<float>(), (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, qs, ks, vs, os, gs,
+                              dqs, dks, dvs, ls, (float)scale, causal ? 1 : 0, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);
+    TORCH_CHECK(rc == 0, "fa2 call failed (", rc, "): ", fa2_error_string(rc));
+    return {dQ.narrow(n_ax, 0, act_n).narrow(3, 0, act_d), dK.narrow(n_ax, 0, act_nkv).narrow(3, 0, act_d), dV.narrow(n_ax, 0, act_nkv).narrow(3, 0, act_d)};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled front end of the gfx950 FlashAttention-2 operator (forward of the reference's flash_attn_wmma module)";
     m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal, scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
+    m.def("backward", &backward, "backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH) -> [dQ, dK, dV]");
 }

@@ -142,6 +142,15 @@ class _FlashAttnWmma:
         (host.cpp:47-58, kernel_fp16.cu:878-1028).  Q, K, V, O, L are the tensors the forward returned
         (D a multiple of 8); the gfx950 kernels take the actual Nq / Nkv / D and mask in-kernel, so nothing is
         padded here except a dO whose D differs from Q's."""
+        if bias is None:
+            fe = _frontend()
+            if fe is not None and hasattr(fe, "backward"):      # the compiled front end (csrc/frontend.cpp): the same steps in C++
+                return fe.backward(Q, K, V, O, dO, L, int(act_n), int(act_nkv), int(act_d), int(Br), int(Bc), bool(causal), float(scale), bool(permute_NH))
+        return _FlashAttnWmma.backward_py(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH, bias)
+
+    @staticmethod
+    def backward_py(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH, bias=None):
+        """backward() in Python (masked calls; every call when the compiled front end is absent)."""
         lib = _fa2_lib.load()
         if not (Q.is_cuda and dO.is_cuda):
             raise RuntimeError("fa2: tensors must be on a ROCm device (no CPU path in this operator)")

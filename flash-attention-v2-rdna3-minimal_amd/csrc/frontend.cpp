@@ -132,10 +132,45 @@ std::vector<at::Tensor> backward(at::Tensor Q, at::Tensor K, at::Tensor V, at::T
     return {dQ.narrow(n_ax, 0, act_n).narrow(3, 0, act_d), dK.narrow(n_ax, 0, act_nkv).narrow(3, 0, act_d), dV.narrow(n_ax, 0, act_nkv).narrow(3, 0, act_d)};
 }
 
+// The autograd node of FlashAttentionFunction (rocwmma_fattn/FlashAttn.py:45-92 of the reference: forward saves q_pad, k_pad, v_pad, O, L; backward
+// returns dQ, dK, dV) as a C++ node: the engine runs a ROCm node's backward on its device thread, and a Python node makes that thread take the
+// GIL and walk the Python wrapper first — tens of microseconds a call, which SD-size training shapes (20 .. 60 us of kernels) are bound by.
+// Same Br rule (FlashAttn.py:56-67), same saved tensors, same results as the Python class (tests/test_parity_gpu.py).
+const auto op_forward = &forward;       // (the node's own members hide the names)
+const auto op_backward = &backward;
+
+struct AttentionNode : public torch::autograd::Function<AttentionNode> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor q, at::Tensor k, at::Tensor v, bool causal, double scale, bool permute_NH) {
+        const int n_ax = permute_NH ? 1 : 2;
+        const int64_t d = q.size(3), n = q.size(n_ax), n_kv = k.size(n_ax);
+        std::vector<at::Tensor> r = op_forward(q, k, v, d > 384 ? 32 : 64, 128, causal, scale, permute_NH);
+        ctx->save_for_backward({r[1], r[2], r[3], r[4], r[5]});
+        ctx->saved_data["n"] = n;
+        ctx->saved_data["n_kv"] = n_kv;
+        ctx->saved_data["d"] = d;
+        ctx->saved_data["causal"] = causal;
+        ctx->saved_data["scale"] = scale;
+        ctx->saved_data["permute_NH"] = permute_NH;
+        return r[0];
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        std::vector<at::Tensor> g = op_backward(s[0], s[1], s[2], s[3], grads[0], s[4], ctx->saved_data["n"].toInt(), ctx->saved_data["n_kv"].toInt(),
+                                               ctx->saved_data["d"].toInt(), 128, 128, ctx->saved_data["causal"].toBool(),
+                                               ctx->saved_data["scale"].toDouble(), ctx->saved_data["permute_NH"].toBool());
+        return {g[0], g[1], g[2], at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor attention(at::Tensor q, at::Tensor k, at::Tensor v, bool causal, double scale, bool permute_NH) {
+    return AttentionNode::apply(q, k, v, causal, scale, permute_NH);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled front end of the gfx950 FlashAttention-2 operator (forward of the reference's flash_attn_wmma module)";
     m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal, scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
+    m.def("attention", &attention, "attention(q, k, v, causal, scale, permute_NH) -> O, differentiable (the C++ autograd node of FlashAttentionFunction)");
     m.def("backward", &backward, "backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH) -> [dQ, dK, dV]");
 }

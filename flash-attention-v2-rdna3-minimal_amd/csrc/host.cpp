@@ -113,6 +113,19 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
 // randomised sweep, tools/fuzz_parity.py, once it drew grids wide enough for these kernels: profiles/r06_fuzz_parity_seed5.json).
 bool asm_pitch_ok(int64_t row_stride_elems, int HD) { return row_stride_elems % HD == 0; }
 bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32); }
+// ... and pays a fixed head and tail per item (the Q tile through LDS, the first K / V tiles before any MFMA, the drain of the software pipeline):
+// over a short KV sweep (cross-attention, low-resolution self-attention) the compiler-scheduled kernels — two waves per SIMD hiding each
+// other's prologue — are faster.  tools/asm_kv_ab.py, one box, fp16, B4 H16 N4096, HIP time / hand-scheduled time at Nkv = 77, 256, 512,
+// 768, 1024, 2048:  D = 64  0.88 0.90 0.96 0.995 1.015 1.06;  D = 128  1.006 0.86 0.955 1.00 1.03 1.08 (bf16 1.12 0.925 0.99 1.02 1.04 1.07;
+// bf16 keeps its two-tile sweeps on the hand-scheduled body, fp16 measured 0.94 .. 1.006 there).  The crossover is the same at B2 and at Nq = 1024.
+// Causal self-attention sweeps half the sequence on average: B8 H16, N = 512 768 1024 1536 2048: D = 64 0.90 0.90 0.97 0.88 1.10, D = 128 0.92 0.90
+// 0.96 0.89 1.07 (bf16 alike) — the hand-scheduled body from N = 1792 (profiles/r06_asm_kv_ab.txt).  Option "asm" bit 5 and option "rows" = 256 ignore this rule (A/B measurements, tests).
+bool asm_kv_len_ok(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
+    if ((fa2::options().asm_mask.load(std::memory_order_relaxed) & 32) || forced_rows() == 256) return true;     // (option rows = 256 pins the
+    if (causal) return p.Nkv >= 1792;                                                                              //  hand-scheduled kernels: tests)
+    if (p.Nkv >= 896) return true;
+    return HD == 128 && bf16 && p.Nkv <= 2 * fa2::kKvTile;
+}
 
 int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     const int rows = pick_rows(p, causal);
@@ -123,9 +136,15 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
     // (round 3) fp16: the generated body folds the scale into Q and then beats the 8-wave kernel non-causal too, so every fp16 launch takes it.
     const bool d64_asm = HD == 64 && (causal || !bf16 || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
-    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD))
+    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
+        asm_kv_len_ok(HD, bf16, p, causal))
         return fa2::launch_fwd_asm(HD, bf16, p, causal, stream);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
+}
+
+// non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 in fp16 (launch_range)
+bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
+    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) && asm_kv_len_ok(HD, bf16, p, false);
 }
 
 // KV-split tail (fa2_fwd_ws).  B*H*ceil(Nq/256) equal workgroups on the CUs take ceil(x / CUs) rounds however empty the last one is: SDXL's
@@ -144,13 +163,8 @@ fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causa
     const int64_t items = (int64_t)p.nbh * ((p.Nq + kFwdRows - 1) / kFwdRows);
     const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
     // whole rounds on the hand-scheduled persistent kernel (head dim 128; head dim 64 in fp16): the parts need a launch of their own
-    const bool asm_rounds = HD == 128 || (HD == 64 && !bf16 && p.D == 64);
+    const bool asm_rounds = asm_noncausal_ok(HD, bf16, p);
     return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, asm_rounds ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
-}
-
-// non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 in fp16 (launch_range)
-bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
-    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD);
 }
 
 int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {

@@ -346,6 +346,10 @@ _autograd_apply = FlashAttentionFunction.apply
 
 def _apply(q, k, v, mask=None, causal=None, scale=None, BNHD_fmt=False, *args, **kwargs):
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        fe = _frontend()
+        if fe is not None and q.requires_grad and not args and not kwargs and hasattr(fe, "attention"):
+            # the same node in C++ (csrc/frontend.cpp::AttentionNode): its backward runs on the autograd engine's device thread without the GIL
+            return fe.attention(q, k, v, bool(causal), float(q.shape[3] ** -0.5 if scale is None else scale), bool(BNHD_fmt))
         return _autograd_apply(q, k, v, mask, causal, scale, BNHD_fmt, *args, **kwargs)
     return FlashAttentionFunction.forward(None, q, k, v, mask, causal, scale, BNHD_fmt)
 

@@ -238,8 +238,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
  *   1  launches of this head dim MAY fold scale * log2(e) into Q, rounded once to the I/O dtype — the scaling contract of the reference's own
  *      oracle (`scale * q_frags`, pure_torch_ver.py:61) — and feed the reference maximum to the matrix pipe as the C operand of the first
  *      Q.K^T k-step.  Version 0.8: head dims exactly 64 and 128 with a positive scale, where the fp16 launches of 256-row workgroups run the
- *      hand-scheduled bodies (bf16 launches, 128-row workgroups and other head dims
- *      scale the f32 product).  The fold removes the 64 v_fma per tile of bodies that run at their instruction-issue bound (+9 % at head dim 64,
+ *      hand-scheduled bodies (bf16 launches, 128-row workgroups, other head dims and KV sweeps too short for those bodies to pay — under 896 keys,
+ *      under 1792 when causal — scale the f32 product).  The fold removes the 64 v_fma per tile of bodies that run at their instruction-issue bound (+9 % at head dim 64,
  *      +1.4 ... +2.9 % at 128); it costs ~2e-4 of log2-LSE accuracy on U[0,1) / N(0,1) inputs, inside every tolerance of the test-suite, and grows
  *      with the logits (~1e-2 in O at logits of several hundred).  The head-dim-64 body also forms its row sums on the matrix pipe, i.e. from
  *      the rounded P the P.V product consumes.

@@ -200,4 +200,12 @@ int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipSt
     }
 }
 
+#if FA2_TU_BF16
+int launch_bwd_merge_bf16(int HD, const BwdParams& p, int which, hipStream_t stream) {
+#else
+int launch_bwd_merge_f16(int HD, const BwdParams& p, int which, hipStream_t stream) {
+#endif
+    return HD == 64 ? launch_merge<64>(p, which, stream) : HD == 128 ? launch_merge<128>(p, which, stream) : FA2_ERR_HEAD_DIM;
+}
+
 }  // namespace fa2

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
     int bid = blockIdx.x;
     // split last round: blocks [full_items, ...) are parts, part-major (fa2_fwd_kernel.hip.h has the forward's twin)
     int part = -1, sidx = 0;
-    if constexpr (!CAUSAL && !BIAS && NW == 8 && HDV == HD) {
+    if constexpr (!CAUSAL && NW == 8 && HDV == HD) {
         if (p.nsplit > 1 && bid >= p.full_items) {
             const int j = bid - p.full_items;
             part = j / p.split_items;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
-    if constexpr (!CAUSAL && !BIAS && NW == 8 && HDV == HD) {
+    if constexpr (!CAUSAL && NW == 8 && HDV == HD) {
         if (part >= 0) {                   // unscaled f32 partial dQ tile; bwd_merge_kernel sums the parts, scales and rounds once
             store_partial_t<DT>(acc, p.ws + (int64_t)(sidx * p.nsplit + part) * kSplitRows * HD, 32 * wave + l31, hi);
             return;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     const int nbh = p.B * p.H;
     int bid = blockIdx.x;
     int part = -1, sidx = 0;               // split last round (fused pass only): see bwd_dq_kernel
-    if constexpr (!CAUSAL && !BIAS && NW == 8 && BOTH) {
+    if constexpr (!CAUSAL && NW == 8 && BOTH) {
         if (p.nsplit > 1 && bid >= p.full_items) {
             const int j = bid - p.full_items;
             part = j / p.split_items;
@@ -683,6 +683,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     // Q tiles from first_plain on lie entirely at or below this wave's KV rows' diagonal (q >= kv for every pair)
     const int first_plain = CAUSAL ? (kvw0 + 31 + kKvTile - 1) / kKvTile : 0;
 
+    // element form of a bias broadcast over the Q rows (row stride 0: a [B, 1, 1, Nkv] key-padding mask, the mask of SD cross-attention): the
+    // score's bias depends on the lane's KV row only — ONE load before the sweep instead of 32 per tile and lane
+    // (BIAS = 3, an instantiation of its own: with the per-score loads of BIAS = 1 in the same kernel the fused pass spilled 300 bytes per lane)
+    [[maybe_unused]] float bias_row = 0.f;
+    if constexpr (BIAS == 3) {
+        if (p.bias_kind == 1) bias_row = bwd_bias_elem<2, BF16>(bwd_bias_rsrc<2>(p, b, h), (uint32_t)kr * 2u);
+        else if (p.bias_kind == 2) bias_row = bwd_bias_elem<4, BF16>(bwd_bias_rsrc<4>(p, b, h), (uint32_t)kr * 4u);
+        else bias_row = bwd_bias_elem<1, BF16>(bwd_bias_rsrc<1>(p, b, h), (uint32_t)kr);
+    }
+
     auto tile_body = [&](int tile, int st, bool masked) __attribute__((always_inline)) {       // one body: see bwd_dq_kernel
         {
             constexpr bool tiled = BIAS == 2;
@@ -721,8 +731,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
             // P = 2^(S c - L[q]); rows q are spread over the registers: q = q0t + (r&3) + 8(r>>2) + 4hi (+32).  The loop is a generic lambda over the
             // bias element size: the kind of a masked call is dispatched ONCE, outside it (inside, the three kinds' code per element spilled).
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            auto p_loop = [&](auto es_t) __attribute__((always_inline)) {
+            auto p_loop = [&](auto es_t, auto bc_t) __attribute__((always_inline)) {
                 constexpr int ES = decltype(es_t)::value;
+                constexpr bool BC = decltype(bc_t)::value;      // a bias broadcast over the Q rows: this lane's one value, loaded before the sweep
                 [[maybe_unused]] const auto brs = bwd_bias_rsrc<ES>(p, b, h);
                 [[maybe_unused]] const uint32_t rowb = (uint32_t)p.bs[2];
 #pragma unroll
@@ -739,6 +750,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                             if constexpr (tiled) {
                                 t0 = bwd_bias_tile_kv_read<ES, BF16>(bimg, ql, l31);
                                 t1 = bwd_bias_tile_kv_read<ES, BF16>(bimg, ql + 32, l31);
+                            } else if constexpr (BC) {
+                                t0 = t1 = bias_row;
                             } else {
                                 // element form: bounds-checked buffer loads, 32-bit offsets (rows >= Nq are out of range and read 0; their P is never used)
                                 const uint32_t vq = (uint32_t)(q0t + ql) * rowb + (uint32_t)kr;
@@ -754,11 +767,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                 }
             };
             if constexpr (BIAS) {
-                if (p.bias_kind == 1) p_loop(std::integral_constant<int, 2>{});
-                else if (p.bias_kind == 2) p_loop(std::integral_constant<int, 4>{});
-                else p_loop(std::integral_constant<int, 1>{});
+                if constexpr (BIAS == 3) p_loop(std::integral_constant<int, 1>{}, std::true_type{});
+                else if (p.bias_kind == 1) p_loop(std::integral_constant<int, 2>{}, std::false_type{});
+                else if (p.bias_kind == 2) p_loop(std::integral_constant<int, 4>{}, std::false_type{});
+                else p_loop(std::integral_constant<int, 1>{}, std::false_type{});
             } else {
-                p_loop(std::integral_constant<int, 2>{});
+                p_loop(std::integral_constant<int, 2>{}, std::false_type{});
             }
             if (CAUSAL && masked) {               // causal: pairs with kv > q contribute nothing (wave-uniform branch)
 #pragma unroll
@@ -833,7 +847,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }
-    if constexpr (!CAUSAL && !BIAS && NW == 8 && BOTH) {
+    if constexpr (!CAUSAL && NW == 8 && BOTH) {
         if (part >= 0) {                   // unscaled f32 partial dK and dV tiles
             const int64_t slot = sidx * p.nsplit + part, ntile = (int64_t)p.split_items * p.nsplit;
             store_partial_t<DT>(acc, p.ws + slot * kSplitRows * HD, 32 * wave + l31, hi);

@@ -100,9 +100,10 @@ FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal
 inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan* dq, SplitPlan* dkv) {
     *dq = SplitPlan();
     *dkv = SplitPlan();
-    if (causal || p.bias_kind != 0 || HD > 128 || !options().split.load(std::memory_order_relaxed)) return 0;
+    if (causal || HD > 128 || !options().split.load(std::memory_order_relaxed)) return 0;
     if (options().rows.load(std::memory_order_relaxed) == 128) return 0;
-    if (HD == 128 && p.D == 128 && (options().asm_mask.load(std::memory_order_relaxed) & 2)) return 0;      // the hand-scheduled passes
+    // the hand-scheduled passes (unmasked calls only: the masked backward runs the BIAS forms of the compiler-scheduled passes at every head dim)
+    if (p.bias_kind == 0 && HD == 128 && p.D == 128 && (options().asm_mask.load(std::memory_order_relaxed) & 2)) return 0;
     const int64_t cus = device_cus(), bh = (int64_t)p.B * p.H, tile_bytes = (int64_t)kSplitRows * HD * 4;
     *dq = plan_tail_split(bh * ((p.Nq + 255) / 256), (p.Nkv + kKvTile - 1) / kKvTile, 1.35 * HD / 64.0, 10.0, tile_bytes, cus);
     if (HD <= 64) *dkv = plan_tail_split(bh * ((p.Nkv + 255) / 256), (p.Nq + kKvTile - 1) / kKvTile, 1.8 * HD / 64.0, 10.0, 2 * tile_bytes, cus, true);
@@ -111,6 +112,9 @@ inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// sum of the parts a split pass left in p.ws (bwd_merge_kernel, bwd_hip.cpp): which = 1: dQ, 2: dK and dV; head dims <= 128
+FA2_HIDDEN int launch_bwd_merge_f16(int HD, const BwdParams& p, int which, hipStream_t stream);
+FA2_HIDDEN int launch_bwd_merge_bf16(int HD, const BwdParams& p, int which, hipStream_t stream);
 // HIP backward through a biased / masked forward (bwd_bias_hip.cpp): dQ, dV, dK; head dims up to 256
 FA2_HIDDEN int launch_bwd_bias_hip_f16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_bias_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream);

@@ -425,6 +425,8 @@ int fa2_fwd_bias(int dtype, const void* q, const void* k, const void* v, void* o
                     scale, causal, bias, bias_kind, bias_strides, hip_stream);
 }
 
+static const int64_t* ls3_zero() { static const int64_t z[3] = {0, 0, 0}; return z; }
+
 static int bwd_impl(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
             void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
             const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
@@ -533,6 +535,30 @@ size_t fa2_bwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, 
     size_t need = 0;
     if (bwd_impl(dtype, dummy, dummy, dummy, dummy, dummy, (const float*)dummy, dummy, dummy, dummy, (float*)dummy, B, H, Nq, Nkv, D, one, one, one, one,
                  one, one, one, one, ls, 1.0f, causal, nullptr, FA2_BIAS_NONE, nullptr, nullptr, nullptr, 0, &need) != FA2_OK)
+        return 0;
+    return need;
+}
+
+int fa2_bwd_bias_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                    void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Nq, int Nkv, int D,
+                    const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                    const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                    const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
+                    int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* workspace, size_t workspace_bytes,
+                    void* hip_stream) {
+    return bwd_impl(dtype, q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, H, Nq, Nkv, D, q_strides, k_strides, v_strides, o_strides,
+                    do_strides, dq_strides, dk_strides, dv_strides, lse_strides, scale, causal, bias, bias_kind, bias_strides, hip_stream,
+                    workspace, workspace_bytes);
+}
+
+size_t fa2_bwd_bias_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal) {
+    static const int64_t one[3] = {8, 8, 8};
+    alignas(16) static char dummy[16];
+    const int64_t ls[2] = {0, 0};
+    size_t need = 0;
+    // (the plan does not depend on the bias' kind or strides: any valid description will do)
+    if (bwd_impl(dtype, dummy, dummy, dummy, dummy, dummy, (const float*)dummy, dummy, dummy, dummy, (float*)dummy, B, H, Nq, Nkv, D, one, one, one, one,
+                 one, one, one, one, ls, 1.0f, causal, dummy, FA2_BIAS_BOOL, ls3_zero(), nullptr, nullptr, 0, &need) != FA2_OK)
         return 0;
     return need;
 }

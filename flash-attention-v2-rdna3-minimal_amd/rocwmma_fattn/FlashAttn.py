@@ -184,13 +184,13 @@ class _FlashAttnWmma:
             bias_t, kind, bstr = _prepare_bias(bias, b, h, act_n, act_nkv, Q.dtype, Q.device)
             args += (bias_t.data_ptr(), kind, _fa2_lib.strides3(*bstr))
             fn = lib.fa2_bwd_bias
-        if bias is None and not causal:
-            # scratch for the split of a partly filled last round of workgroups (fa2_bwd_ws, the backward's twin of fa2_fwd_ws)
-            need = lib.fa2_bwd_workspace_bytes(dtype_code, b, h, act_n, act_nkv, dk, 0)
+        if not causal:
+            # scratch for the split of a partly filled last round of workgroups (fa2_bwd_ws / fa2_bwd_bias_ws, the backward's twins of fa2_fwd_ws)
+            need = (lib.fa2_bwd_workspace_bytes if bias is None else lib.fa2_bwd_bias_workspace_bytes)(dtype_code, b, h, act_n, act_nkv, dk, 0)
             if need:
                 ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
                 args += (ws.data_ptr(), need)
-                fn = lib.fa2_bwd_ws
+                fn = lib.fa2_bwd_ws if bias is None else lib.fa2_bwd_bias_ws
         args += (stream,)
         if Q.device.index != _current_device():
             with torch.cuda.device(Q.device):

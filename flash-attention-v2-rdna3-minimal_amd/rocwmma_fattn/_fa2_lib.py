@@ -47,6 +47,8 @@ SYMBOLS = {
     "fa2_bwd_ws": (ctypes.c_int, [ctypes.c_int] + _BWD_ARGTYPES[:-1] + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fa2_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "fa2_bwd_bias": (ctypes.c_int, [ctypes.c_int] + _BWD_ARGTYPES[:-1] + [ctypes.c_void_p, ctypes.c_int, _i64p, ctypes.c_void_p]),
+    "fa2_bwd_bias_ws": (ctypes.c_int, [ctypes.c_int] + _BWD_ARGTYPES[:-1] + [ctypes.c_void_p, ctypes.c_int, _i64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fa2_bwd_bias_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "fa2_supported_head_dims": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
     "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

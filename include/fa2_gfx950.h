@@ -206,8 +206,9 @@ size_t fa2_bwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, 
  * Backward through fa2_fwd_bias: the gradients of O = softmax(scale * Q K^T + bias [+ causal mask]) V with respect to Q, K, V (the bias /
  * mask itself is a constant of the call: it receives no gradient).  o and lse are the outputs of the fa2_fwd_bias call with the SAME bias
  * arguments; fully masked rows (lse = -inf) contribute nothing.  Arguments as fa2_bwd plus the bias triple of fa2_fwd_bias.
- * Three launches of the compiler-scheduled passes (dQ, dV, dK); a per-row bias whose pointer, strides and Nkv are multiples of 16 bytes is staged
- * tile by tile with LDS-DMA, anything else (a broadcast key-padding row, Nkv = 77) read with one bounds-checked load per score.  One (b, h) slice of the
+ * The compiler-scheduled passes — dQ, then dK and dV in one sweep at head dims <= 64 (dV, then dK above); a per-row bias whose pointer, strides and Nkv are multiples of 16 bytes is staged
+ * tile by tile with LDS-DMA, anything else (Nkv = 77) read with one bounds-checked load per score — a bias broadcast over the Q rows (a
+ * [B, 1, 1, Nkv] key-padding mask) with one load per KV row in the dK / dV pass.  One (b, h) slice of the
  * bias must span < 2 GiB (FA2_ERR_BAD_SHAPE).  Head dims up to 256 (FA2_ERR_HEAD_DIM above).  The reference has no counterpart (its `mask` is
  * ignored, FlashAttn.py:49/:74).
  */
@@ -220,6 +221,24 @@ int fa2_bwd_bias(int dtype, const void* q, const void* k, const void* v, const v
                  float scale, int causal,
                  const void* bias, int bias_kind, const int64_t bias_strides[3],
                  void* hip_stream);
+
+/*
+ * fa2_bwd_bias with scratch memory — fa2_bwd_ws for the masked backward: non-causal calls of head dims <= 128 split the workgroups of a partly
+ * filled last round of the dQ pass, and (head dims <= 64) of the fused dK / dV pass, where an underfilled KV-owner grid — cross-attention over
+ * 77 keys has B * H workgroups in all — splits every workgroup along its Q sweep.  Same contract as fa2_bwd_ws: 16-byte aligned workspace of at
+ * least fa2_bwd_bias_workspace_bytes(...) bytes, private to the call until the stream has passed it; NULL / too small / 0 needed: exactly
+ * fa2_bwd_bias.  The plan does not depend on the bias' kind or strides.
+ */
+int fa2_bwd_bias_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                    void* dq, void* dk, void* dv, float* delta_ws,
+                    int B, int H, int Nq, int Nkv, int D,
+                    const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                    const int64_t o_strides[3], const int64_t do_strides[3], const int64_t dq_strides[3],
+                    const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2],
+                    float scale, int causal,
+                    const void* bias, int bias_kind, const int64_t bias_strides[3],
+                    void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t fa2_bwd_bias_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal);
 
 /* Head dims the forward kernels are instantiated for (ascending).  Writes up to `cap` entries into `dims`, returns
  * the total count.  Any D that is a multiple of 8 runs on the next of these with its tail columns masked; only a D

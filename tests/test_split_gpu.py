@@ -377,3 +377,61 @@ def test_short_kv_backward_splits_every_kv_owner(shape):
         torch.nn.functional.scaled_dot_product_attention(qd, kd, vd).backward(do[sl].double())
         for name, gt, w in zip("qkv", gw, (qd.grad, kd.grad, vd.grad)):
             assert float((gt[sl].double() - w).abs().max()) <= GRAD_TOL[dt] * max(1.0, float(w.abs().max())), (name, (b, h))
+
+
+MASKED_SPLIT_CASES = [
+    # B, H, Nq, Nkv, D, dt, mask kind: "pad" = [B,1,1,Nkv] bool key-padding (row broadcast: one load per KV row in the dK / dV pass),
+    # "add" = [B,1,Nq,Nkv] additive in the I/O dtype (per score; Nkv = 77: unaligned, 80: LDS-DMA tiles), "f32h" = [1,H,Nq,Nkv] float32
+    (2, 10, 4096, 77, 64, 0, "pad"), (2, 8, 4096, 77, 40, 1, "pad"), (2, 10, 2048, 77, 64, 0, "add"), (2, 10, 2048, 80, 64, 0, "add"),
+    (1, 6, 2048, 304, 64, 1, "f32h"), (2, 10, 4096, 4096, 64, 0, "pad"), (1, 24, 3072, 3072, 64, 0, "pad"), (1, 24, 4096, 4096, 128, 0, "pad"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MASKED_SPLIT_CASES)
+def test_masked_backward_with_workspace(case):
+    """fa2_bwd_bias_ws: the masked backward under the split of fa2_bwd_ws — short-KV cross-attention with a key-padding mask (every KV-owner
+    workgroup of the fused dK / dV pass split along its Q sweep), partly filled last rounds of the dQ pass, head dim 128 (dQ pass only).  Through the
+    operator (flash_attention(mask=...)), split on against split off (same kernels, other f32 summation order) and against float64 autograd; fully
+    masked keys get zero dK / dV."""
+    from conftest import GRAD_TOL
+    from rocwmma_fattn.FlashAttn import flash_attention
+    B, H, N, Nkv, D, dt, kind = case
+    g = torch.Generator(device="cpu").manual_seed(5000 + N + Nkv + D)
+    q, do = (torch.randn((B, H, N, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+    k, v = (torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+    if kind == "pad":
+        keep = torch.rand((B, 1, 1, Nkv), generator=g) < 0.7
+        keep[..., 0] = True
+        mask = keep.to(_dev())
+    elif kind == "add":
+        mask = (torch.randn((B, 1, N, Nkv), generator=g) * 2).to(TORCH_DT[dt]).to(_dev())
+    else:
+        mask = (torch.randn((1, H, N, Nkv), generator=g) * 2).to(_dev())
+    lib = _fa2_lib.load()
+    need = lib.fa2_bwd_bias_workspace_bytes(dt, B, H, N, Nkv, D + (-D % 8), 0)
+    assert need > 0, "the case is meant to split"
+    grads = {}
+    for mode in (1, 0):
+        with _fa2_lib.options(split=mode):
+            qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+            flash_attention(qq, kk, vv, mask=mask).backward(do)
+            torch.cuda.synchronize()
+            grads[mode] = (qq.grad, kk.grad, vv.grad)
+    for name, a, b_ in zip("qkv", grads[1], grads[0]):
+        assert torch.isfinite(a.float()).all(), name
+        tol = (2.0 ** -9 if dt == 0 else 2.0 ** -6) * max(1.0, float(b_.float().abs().max()))
+        assert float((a.float() - b_.float()).abs().max()) <= tol, name
+    if kind == "pad":
+        dead = ~mask[:, 0, 0]                                    # [B, Nkv]
+        for t in grads[1][1:]:
+            assert float(t.float().abs().amax(dim=(1, 3))[dead].max() if dead.any() else 0.0) == 0.0
+    for (b, h) in {(0, 0), (B - 1, H - 1)}:
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        qd, kd, vd = (t[sl].double().requires_grad_(True) for t in (q, k, v))
+        mb, mh = (b if mask.shape[0] > 1 else 0), (h if mask.shape[1] > 1 else 0)
+        m = mask[mb:mb + 1, mh:mh + 1]
+        m = m if m.dtype == torch.bool else m.double()
+        torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, attn_mask=m).backward(do[sl].double())
+        for name, gt, w in zip("qkv", grads[1], (qd.grad, kd.grad, vd.grad)):
+            assert float((gt[sl].double() - w).abs().max()) <= GRAD_TOL[dt] * max(1.0, float(w.abs().max())), (name, (b, h))

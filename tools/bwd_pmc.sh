@@ -1,6 +1,6 @@
 #!/bin/bash
 # Backward kernels under rocprofv3 at one BASELINE shape (developer tool, run from the repo root on the GPU box):
-#   bash tools/bwd_pmc.sh [c2|c3|c4] [out-dir]
+#   bash tools/bwd_pmc.sh [c2|c3|c4|sdxl|d64] [out-dir]
 # One kernel-trace pass (per (kernel, grid) median / min of the launch durations: an average over all launches of an instantiation
 # would mix shapes) and separate --pmc passes (never combined with other trace domains), summarised on stdout.
 CFG=${1:-c2}
@@ -12,7 +12,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.join("$PWD", "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction
 B, H, N, D, dt, causal = {"c2": (2, 16, 4096, 128, torch.float16, False), "c3": (2, 16, 4096, 128, torch.bfloat16, True),
-                          "c4": (1, 32, 8192, 128, torch.float16, True)}["$CFG"]
+                          "c4": (1, 32, 8192, 128, torch.float16, True), "sdxl": (2, 10, 4096, 64, torch.float16, False),
+                          "d64": (2, 16, 4096, 64, torch.float16, False)}["$CFG"]
 g = torch.Generator(device="cuda").manual_seed(1)
 q, k, v = (torch.rand((B, H, N, D), generator=g, device="cuda").to(dt).requires_grad_(True) for _ in range(3))
 o = FlashAttentionFunction.apply(q, k, v, None, causal)

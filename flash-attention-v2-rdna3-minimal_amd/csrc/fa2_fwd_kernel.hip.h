@@ -108,7 +108,7 @@ struct FwdParams {
     const void* bias;
     int64_t bs[3];
     int bias_kind;                       // 1: the I/O 16-bit dtype, 2: f32, 3: uint8 (non-zero = attend)
-    int bias_vec;                        // host: 1 = one aligned load per group of four kv, 2 = coalesced tiles through LDS (4-wave kernels), 3 = tiles by LDS-DMA (8-wave kernels, BIAS = 2)
+    int bias_vec;                        // host: 1 = one aligned load per group of four kv, 2 = coalesced tiles through LDS (4-wave kernels), 3 = tiles by LDS-DMA (8-wave kernels, BIAS = 2), 4 = row-broadcast bias, one load per wave and tile
     // KV-split tail (fa2_fwd_ws; non-causal, no bias, head dims <= 128, 256-row workgroups): B*H*nqblk equal items on the CUs take
     // ceil(items / CUs) rounds however empty the last one is.  The items of that last round — the last `split_items` of the item
     // order, after `full_items` whole ones — are each swept by `nsplit` workgroups ("parts") over disjoint KV ranges, which leave
@@ -427,7 +427,16 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
             for (int qb = 0; qb < QB; ++qb) {
                 const int qr = qrow[qb] < p.Nq ? qrow[qb] : p.Nq - 1;
                 const int64_t row = b * p.bs[0] + h * p.bs[1] + (int64_t)qr * p.bs[2];
-                if (p.bias_vec == 2) {
+                if (p.bias_vec == 4) {
+                    // a bias broadcast over the Q rows (row stride 0: a [B, 1, 1, Nkv] key-padding mask): the tile's 64 values are the same for
+                    // every row — lane l fetches the one of kv0 + l (one coalesced load per wave and tile instead of 8 .. 32 per lane); add_bias
+                    // spreads them through the wave's LDS image.  raw[0] = the element, 0 past Nkv (those columns are masked by the tail anyway).
+                    const int kvl = tile * kKvTile + lane;
+                    const int64_t at = b * p.bs[0] + h * p.bs[1] + kvl;
+                    if (p.bias_kind == 1) raw[0] = kvl < p.Nkv ? (uint32_t)((const uint16_t*)p.bias)[at] : 0u;
+                    else if (p.bias_kind == 2) raw[0] = kvl < p.Nkv ? ((const uint32_t*)p.bias)[at] : 0u;
+                    else raw[0] = kvl < p.Nkv ? (uint32_t)((const uint8_t*)p.bias)[at] : 0u;
+                } else if (p.bias_vec == 2) {
                     // a tile row is 64 elements = LPR lanes of 16 bytes; instruction i covers rows [i*RPI, +RPI) of the wave's 32
                     // (RPI = 64 / LPR); its words land in raw[4i .. 4i+3]
                     auto tile_rows = [&](auto es_t, auto lpr_log_t) __attribute__((always_inline)) {
@@ -567,7 +576,27 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
                     if constexpr (KIND == 3) return bv == 0.f ? s * cs : -INFINITY;
                     else return __builtin_fmaf(s, cs, bv);
                 };
-                if (p.bias_vec == 2) {
+                if (p.bias_vec == 4) {
+                    // row-broadcast form: this lane's element -> log2-domain term (bool: 0 / -inf), 64 floats through the wave's LDS image, the
+                    // lane's eight groups of four read back (LDS operations of one wave execute in order: no barrier)
+                    char* bimg = smem + kBiasLdsBase + wave * (32 * kBiasRowB);
+                    float t;
+                    if constexpr (KIND == 3) t = raw[0] ? 0.f : -INFINITY;
+                    else if constexpr (KIND == 2) t = __uint_as_float(raw[0]) * kLog2e;
+                    else t = io16(raw[0]) * kLog2e;
+                    *(float*)(bimg + lane * 4) = t;
+                    typedef float f32x4b __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int G = 0; G < 8; ++G) {
+                        const f32x4b w = *(const f32x4b*)(bimg + (32 * (G >> 2) + 8 * (G & 3) + 4 * hi) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rr = 4 * (G & 3) + e;
+                            if (G >> 2) s1[rr] = __builtin_fmaf(s1[rr], cs, w[e]);
+                            else s0[rr] = __builtin_fmaf(s0[rr], cs, w[e]);
+                        }
+                    }
+                } else if (p.bias_vec == 2) {
                     // wave-private image above the K / V buffers: park the coalesced tile, read this lane's row back (the LDS
                     // operations of one wave execute in order, so neither a barrier nor a second buffer is needed)
                     char* bimg = smem + kBiasLdsBase + wave * (32 * kBiasRowB);

@@ -371,6 +371,9 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         if (p.bias_vec == 2 && HD <= 128 && forced_rows() != 128 && (int64_t)B * H * ((Nq + 255) / 256) > fa2::device_cus() * 3 / 8 &&
             ((int64_t)(Nq - 1) * p.bs[2] + Nkv + 64 * p.bs[2]) * (int64_t)esize < 0x7fffffffLL)
             p.bias_vec = 3;
+        // 4: a bias broadcast over the Q rows (row stride 0 — the [B, 1, 1, Nkv] key-padding mask of padded token batches and of SD cross-attention),
+        // any alignment: a wave fetches the tile's 64 values once and spreads them through its LDS image (head dims <= 256: the image exists)
+        if (p.bs[2] == 0 && HD <= 256) p.bias_vec = 4;
     }
     if ((int64_t)B * H * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
 

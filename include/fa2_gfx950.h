@@ -133,7 +133,8 @@ size_t fa2_fwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, 
  *   fully masked rows (every score -inf) produce O = 0 and lse = -inf (torch's math path returns NaN there).
  * Runs the compiler-scheduled HIP kernels (the hand-scheduled bodies have no bias stream): a dense per-row bias whose pointer, strides and Nkv
  * are multiples of 16 bytes, on a grid that fills the chip at head dims <= 128, as 8-wave 256-row workgroups with the bias tile staged by LDS-DMA;
- * everything else as 4-wave 128-row workgroups.  Its backward is fa2_bwd_bias (fa2_bwd recomputes unbiased scores).
+ * everything else as 4-wave 128-row workgroups (a bias broadcast over the rows, bias_strides[2] == 0 — a key-padding mask — costs one load per
+ * wave and KV tile there).  Its backward is fa2_bwd_bias (fa2_bwd recomputes unbiased scores).
  */
 int fa2_fwd_bias(int dtype,
                  const void* q, const void* k, const void* v, void* o, float* lse,

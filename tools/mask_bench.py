@@ -36,7 +36,7 @@ def timeit(fn, iters=100):
 
 def main():
     dev = torch.device("cuda", 0)
-    print("%-36s %10s %10s %7s %12s %10s" % ("case", "fa2 mask", "sdpa mask", "x", "fa2 no mask", "max diff"))
+    print("%-36s %10s %10s %7s %12s %10s %10s" % ("case", "fa2 mask", "sdpa mask", "x", "fa2 no mask", "fa2 err", "sdpa err"))
     with torch.no_grad():
         for name, B, H, Nq, Nkv, D, dt, kind, mshape in CASES:
             g = torch.Generator(device=dev).manual_seed(1)
@@ -50,8 +50,15 @@ def main():
             t_f = timeit(lambda: flash_attention(q, k, v, mask))
             t_s = timeit(lambda: F.scaled_dot_product_attention(q, k, v, attn_mask=mask))
             t_0 = timeit(lambda: FlashAttentionFunction.apply(q, k, v, None, False))
-            err = (flash_attention(q, k, v, mask).float() - F.scaled_dot_product_attention(q, k, v, attn_mask=mask).float()).abs().max().item()
-            print("%-36s %8.1fus %8.1fus %6.2fx %10.1fus %10.1e" % (name, t_f, t_s, t_s / t_f, t_0, err))
+            # both against float64 attention of two heads (torch SDPA's fused kernel has been seen to return wrong rows, |err| ~ 0.4, on the
+            # unaligned [B,1,Nq,77] fp16 mask in some calls of a run; this operator's output is the same bits every call)
+            md = mask if mask.dtype == torch.bool else mask.double()
+            if md.dim() == 4:
+                md = md[:1, :2] if md.shape[1] > 1 else md[:1]
+            ref = F.scaled_dot_product_attention(q[:1, :2].double(), k[:1, :2].double(), v[:1, :2].double(), attn_mask=md)
+            e_f = (flash_attention(q, k, v, mask)[:1, :2].double() - ref).abs().max().item()
+            e_s = (F.scaled_dot_product_attention(q, k, v, attn_mask=mask)[:1, :2].double() - ref).abs().max().item()
+            print("%-36s %8.1fus %8.1fus %6.2fx %10.1fus %10.1e %10.1e" % (name, t_f, t_s, t_s / t_f, t_0, e_f, e_s))
 
 
 if __name__ == "__main__":

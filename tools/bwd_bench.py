@@ -19,7 +19,9 @@ CFGS = {"c2": (2, 16, 4096, 128, torch.float16, False), "c3": (2, 16, 4096, 128,
         "c4": (1, 32, 8192, 128, torch.float16, True), "b8": (8, 16, 4096, 128, torch.float16, False),
         "n1k": (2, 16, 1024, 128, torch.float16, False), "n2kc": (1, 8, 2048, 128, torch.float16, True),
         "n2k": (2, 16, 2048, 128, torch.float16, False), "n512": (2, 16, 512, 128, torch.float16, False),
-        "h8n4k": (1, 8, 4096, 128, torch.float16, False), "h8n8k": (1, 8, 8192, 128, torch.float16, False)}
+        "h8n4k": (1, 8, 4096, 128, torch.float16, False), "h8n8k": (1, 8, 8192, 128, torch.float16, False),
+        "d64": (2, 16, 4096, 64, torch.float16, False), "d64c": (2, 16, 4096, 64, torch.bfloat16, True), "sdxl": (2, 10, 4096, 64, torch.float16, False),
+        "sd15": (2, 8, 4096, 40, torch.float16, False), "d64n8k": (1, 24, 8192, 64, torch.float16, False), "sdxl32": (2, 20, 1024, 64, torch.float16, False)}
 GEMMS = {1: 3, 2: 4, 3: 7}      # GEMM-equivalents executed by the passes (a forward is 2)
 
 

@@ -2,7 +2,6 @@
 // build.py compiles this file twice, -DFA2_TU_BF16=0 and =1.  Reference counterpart: backward_fp16 / backward_bf16
 // (kernel_fp16.cu:878-1028).
 #include "fa2_launch.h"
-#include "fa2_bwd_pp.hip.h"
 
 #include "fa2_gfx950.h"
 
@@ -110,6 +109,9 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     } else if constexpr (HD <= 64) {
         // D <= 64: both accumulators fit one wave, one sweep forms S and P once for dK and dV
         p.nblk = (p.Nkv + kRows - 1) / kRows;
+        constexpr int lds = kStages * (4 * TILEB + 512);
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
         int64_t grid = (int64_t)p.B * p.H * p.nblk;
         if constexpr (!CAUSAL) {
             if (sp_dkv.nsplit > 1) {
@@ -117,18 +119,7 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
                 grid = (int64_t)p.full_items + (int64_t)p.split_items * p.nsplit;
             }
         }
-        if (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) {
-            // the two waves of a SIMD half a tile out of phase (fa2_bwd_pp.hip.h): one in its matrix phase while the other does the softmax work
-            constexpr int lds = fa2::kPpStages * (4 * TILEB + 512);
-            constexpr auto kern = fa2::bwd_dkv_pp_kernel<HD, kBF16, CAUSAL>;
-            if ((rc = fa2::set_lds<kern>(lds))) return rc;
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
-        } else {
-            constexpr int lds = kStages * (4 * TILEB + 512);
-            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true>;
-            if ((rc = fa2::set_lds<kern>(lds))) return rc;
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
-        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
         if ((rc = (int)hipGetLastError())) return rc;
         return p.nsplit > 1 ? launch_merge<HD>(p, 2, stream) : 0;
     } else {

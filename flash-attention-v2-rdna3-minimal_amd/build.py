@@ -36,9 +36,13 @@ UNITS = [
     ("host", "host.cpp", []),
     ("fwd_hip_f16", "fwd_hip.cpp", ["-DFA2_TU_BF16=0"]),
     ("fwd_hip_bf16", "fwd_hip.cpp", ["-DFA2_TU_BF16=1"]),
+    ("fwd_hip_trim_f16", "fwd_hip.cpp", ["-DFA2_TU_BF16=0", "-DFA2_TU_TRIM=1"]),
+    ("fwd_hip_trim_bf16", "fwd_hip.cpp", ["-DFA2_TU_BF16=1", "-DFA2_TU_TRIM=1"]),
     ("fwd_asm", "fwd_asm.cpp", []),
     ("bwd_hip_f16", "bwd_hip.cpp", ["-DFA2_TU_BF16=0"]),
     ("bwd_hip_bf16", "bwd_hip.cpp", ["-DFA2_TU_BF16=1"]),
+    ("bwd_hip_trim_f16", "bwd_hip.cpp", ["-DFA2_TU_BF16=0", "-DFA2_TU_TRIM=1"]),
+    ("bwd_hip_trim_bf16", "bwd_hip.cpp", ["-DFA2_TU_BF16=1", "-DFA2_TU_TRIM=1"]),
     ("bwd_asm", "bwd_asm.cpp", []),
     ("bwd_bias_hip_f16", "bwd_bias_hip.cpp", ["-DFA2_TU_BF16=0"]),
     ("bwd_bias_hip_bf16", "bwd_bias_hip.cpp", ["-DFA2_TU_BF16=1"]),

@@ -8,15 +8,23 @@
 #ifndef FA2_TU_BF16
 #error "compile with -DFA2_TU_BF16=0 or 1"
 #endif
+// -DFA2_TU_TRIM=1: this unit holds the TRIMMED instantiations instead (head dims well below the kernel's HD run only the MFMA k-steps and
+// accumulator column blocks that hold real columns: fa2_bwd_kernel.hip.h, KSN / DTN) and exports launch_bwd_hip_trim_{f16,bf16}.
+#ifndef FA2_TU_TRIM
+#define FA2_TU_TRIM 0
+#endif
+#ifndef FA2_TRIM          // 0: never dispatch to the trimmed kernels (A/B builds, tools/kbench.py)
+#define FA2_TRIM 1
+#endif
 
 namespace {
 
 constexpr bool kBF16 = FA2_TU_BF16 != 0;
 
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, int KSN, int DTN>
 int launch_bwd_pair(const fa2::BwdParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (4 * fa2::Geo<HD, 8>::TILEB + 512) + 4 * 4096;
-    constexpr auto kern = fa2::bwd_dkv_pair_kernel<HD, kBF16, CAUSAL>;
+    constexpr auto kern = fa2::bwd_dkv_pair_kernel<HD, kBF16, CAUSAL, KSN, DTN>;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(512), lds, stream, p);
     return (int)hipGetLastError();
@@ -46,7 +54,7 @@ int launch_merge(const fa2::BwdParams& p, int which, hipStream_t stream) {
 }
 
 // parts: bit 0 = the dQ pass (which also fills the delta workspace), bit 1 = the dK / dV pass(es)
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, int KSN = HD / 16, int DTN = HD / 32>
 int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     constexpr int NW = HD > 128 ? 4 : 8;          // D = 256: one wave per SIMD (512 registers), single LDS stage
     constexpr int kRows = NW * 32, kStages = NW == 8 ? 2 : 1;
@@ -77,7 +85,7 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     } else if (dq_small) {
         if constexpr (NW == 8) {
             constexpr int lds = 2 * 3 * fa2::Geo<HD, 4>::TILEB;
-            constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, 4>;
+            constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, 4, HD, 0, KSN, DTN>;
             if ((rc = fa2::set_lds<kern>(lds))) return rc;
             p.nblk = (p.Nq + 127) / 128;
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), lds, stream, p);
@@ -85,7 +93,7 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         }
     } else {
         constexpr int lds = kStages * 3 * TILEB;
-        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW>;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HD, 0, KSN, DTN>;
         if ((rc = fa2::set_lds<kern>(lds))) return rc;
         p.nblk = (p.Nq + kRows - 1) / kRows;
         int64_t grid = (int64_t)p.B * p.H * p.nblk;
@@ -105,12 +113,12 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         // D in 65..128: dK and dV in one sweep by wave pairs (bwd_dkv_pair_kernel): 128 KV rows per workgroup, S and P formed once
         p.nblk = (p.Nkv + 127) / 128;
         if ((int64_t)p.B * p.H * p.nblk > 0x7fffffffLL) return FA2_ERR_GRID;
-        return launch_bwd_pair<HD, CAUSAL>(p, stream);
+        return launch_bwd_pair<HD, CAUSAL, KSN, DTN>(p, stream);
     } else if constexpr (HD <= 64) {
         // D <= 64: both accumulators fit one wave, one sweep forms S and P once for dK and dV
         p.nblk = (p.Nkv + kRows - 1) / kRows;
         constexpr int lds = kStages * (4 * TILEB + 512);
-        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true>;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true, HD, 0, KSN, DTN>;
         if ((rc = fa2::set_lds<kern>(lds))) return rc;
         int64_t grid = (int64_t)p.B * p.H * p.nblk;
         if constexpr (!CAUSAL) {
@@ -126,14 +134,14 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows, two sweeps
         {
             constexpr int lds = kStages * (2 * TILEB + 512);
-            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW>;
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HD, 0, KSN, DTN>;
             if ((rc = fa2::set_lds<kern>(lds))) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
             if ((rc = (int)hipGetLastError())) return rc;
         }
         {
             constexpr int lds = kStages * (3 * TILEB + 512);
-            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW>;
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HD, 0, KSN, DTN>;
             if ((rc = fa2::set_lds<kern>(lds))) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
             if ((rc = (int)hipGetLastError())) return rc;
@@ -141,6 +149,45 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         return 0;
     }
 }
+
+#if FA2_TU_TRIM
+
+template <int HD, int KSN, int DTN>
+int launch_trim(const fa2::BwdParams& p, bool causal, int parts, hipStream_t stream) {
+    return causal ? launch_bwd_t<HD, true, KSN, DTN>(p, parts, stream) : launch_bwd_t<HD, false, KSN, DTN>(p, parts, stream);
+}
+
+}  // namespace
+
+namespace fa2 {
+
+// Trimmed backward kernels; -1 = none for this p.D (the caller runs the full kernels).  The head dims the forward trims (fwd_hip.cpp):
+//   HD  64: D <= 32 -> 2 k-steps, 1 column block;   HD 128: D <= 96 -> 6, 3;   HD 256: D <= 160 / 192 / 224 -> 10, 5 / 12, 6 / 14, 7
+// Measured (tools/trim_ab.py --bwd, profiles/r08_trim_ab_bwd.txt): B1 H24 N4096 D 16 / 32 +30 %, 80 / 96 +17 %, 144 / 160 +36 %, 176 / 192 +19 %, 208 / 224 +7 %.
+#if FA2_TU_BF16
+int launch_bwd_hip_trim_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
+#else
+int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
+#endif
+    switch (HD) {
+        case 64:
+            if (p.D <= 32) return launch_trim<64, 2, 1>(p, causal, parts, stream);
+            return -1;      // (3 k-steps, 2 blocks for D <= 48 measured -1 .. +3 %: the fused D <= 64 pass is not bound by its MFMAs; not instantiated)
+        case 128:
+            if (p.D <= 96) return launch_trim<128, 6, 3>(p, causal, parts, stream);
+            return -1;
+        case 256:
+            if (p.D <= 160) return launch_trim<256, 10, 5>(p, causal, parts, stream);
+            if (p.D <= 192) return launch_trim<256, 12, 6>(p, causal, parts, stream);
+            if (p.D <= 224) return launch_trim<256, 14, 7>(p, causal, parts, stream);
+            return -1;
+        default: return -1;
+    }
+}
+
+}  // namespace fa2
+
+#else   // !FA2_TU_TRIM
 
 // Head dims above 256 (kernel head dim 512, the SD VAE attention block): 4-wave workgroups of 128 rows, one wave per SIMD with the 512-register
 // budget, single LDS stage; every workgroup produces a 128-column slab of its output (grid.y = 4) and recomputes S (and dP) over the whole
@@ -191,6 +238,14 @@ int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipS
 #else
 int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
 #endif
+    if (FA2_TRIM && p.D < HD && HD <= 256) {      // a trimmed instantiation, where one exists
+#if FA2_TU_BF16
+        const int rc = launch_bwd_hip_trim_bf16(HD, p, causal, parts, stream);
+#else
+        const int rc = launch_bwd_hip_trim_f16(HD, p, causal, parts, stream);
+#endif
+        if (rc >= 0) return rc;
+    }
     switch (HD) {
         case 64: return launch_bwd<64>(p, causal, parts, stream);
         case 128: return launch_bwd<128>(p, causal, parts, stream);
@@ -209,3 +264,5 @@ int launch_bwd_merge_f16(int HD, const BwdParams& p, int which, hipStream_t stre
 }
 
 }  // namespace fa2
+
+#endif  // FA2_TU_TRIM

@@ -267,14 +267,18 @@ __device__ __forceinline__ void store_acc_t(const f32x16 (&acc)[DT], uint16_t* r
 // the whole head dim (Q / dO fragments of all HD columns in registers: the 512-register budget of one wave per SIMD), only the K^T image
 // and the accumulator are slab-sized; every slab recomputes S and dP (a correct path for the SD-VAE-sized head dim, not a tuned one).
 // BIAS: the forward was fa2_fwd_bias — P = 2^(S c + bias log2e - L); a fully masked row (L = -inf) has P = 0.
-template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD, int BIAS = 0>
+// KSN / DTN ("trimmed" instantiations, bwd_hip.cpp; the forward's twin, fa2_fwd_kernel.hip.h): a head dim well below HD keeps HD's LDS
+// images and staging (columns >= D are never fetched) but runs only KSN = ceil(D / 16) k-steps of the products contracted over the head dim
+// and DTN = ceil(D / 32) column blocks of the accumulators.  Defaults = the full kernel.
+template <int HD, bool BF16, bool CAUSAL, int NW = 8, int HDV = HD, int BIAS = 0, int KSN = HD / 16, int DTN = HDV / 32>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_dq_kernel(const BwdParams p) {
     using L_ = BwdLane<HD, NW>;
     using LV_ = BwdLane<HDV, NW>;             // geometry of the transposed-read image (the slab)
     constexpr int kRows = NW * 32;            // rows per workgroup (p.nblk = ceil(N / kRows))
     constexpr bool DBUF = NW == 8 || HD <= 128;   // (NW = 4 at head dims <= 128: the small-grid shape, 128 Q rows per workgroup, 256 registers, two stages)
-    constexpr int NPASS = L_::NPASS, KS = L_::KS, ROWB = L_::ROWB, TILEB = L_::TILEB;
-    constexpr int NPASSV = LV_::NPASS, DT = LV_::DT, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    constexpr int NPASS = L_::NPASS, KS = KSN, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NPASSV = LV_::NPASS, DT = DTN, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    static_assert(KSN <= L_::KS && DTN <= LV_::DT, "trimmed loop bounds");
     constexpr int STAGEB = 2 * TILEB + TILEBV;
     const int vcol0 = HDV == HD ? 0 : blockIdx.y * HDV;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || HD <= 128) ? 2 : 1) void bwd_d
 // additionally carries dO in tr-form (Q row | dO row | Q tr | dO tr).
 // HDV < HD (HD = 512): the workgroup produces the HDV-column slab blockIdx.y of dK / dV; S (and dP) are contracted over the whole head
 // dim, only the transposed-read image and the accumulator are slab-sized (see bwd_dq_kernel).
-template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD, int BIAS = 0>
+template <int HD, bool BF16, bool CAUSAL, bool WANT_DK, int NW = 8, bool BOTH = false, int HDV = HD, int BIAS = 0, int KSN = HD / 16, int DTN = HDV / 32>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParams p) {
     static_assert(!BOTH || WANT_DK, "the fused pass is the dK pass plus a dV accumulator");
     static_assert(!BOTH || HDV == HD, "slabs exist for the separate passes only");
@@ -556,8 +560,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
     using LV_ = BwdLane<HDV, NW>;
     constexpr int kRows = NW * 32;
     constexpr bool DBUF = NW == 8;
-    constexpr int NPASS = L_::NPASS, KS = L_::KS, ROWB = L_::ROWB, TILEB = L_::TILEB;
-    constexpr int NPASSV = LV_::NPASS, DT = LV_::DT, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    constexpr int NPASS = L_::NPASS, KS = KSN, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NPASSV = LV_::NPASS, DT = DTN, ROWBV = LV_::ROWB, TILEBV = LV_::TILEB;
+    static_assert(KSN <= L_::KS && DTN <= LV_::DT, "trimmed loop bounds");
     constexpr int NT = BOTH ? 4 : WANT_DK ? 3 : 2;                 // images per stage; the last one is the transposed-read image
     constexpr int TROFF = (NT - 1) * TILEB;                        // ... which starts here (BOTH: Q tr at 2, dO tr at 3 tiles)
     constexpr int LOFF = HDV == HD ? NT * TILEB : TROFF + TILEBV;   // L | D values of the tile
@@ -884,12 +889,12 @@ __device__ __forceinline__ void pair_mid_barrier() {
 // for both products: 4 GEMMs per (kv, q) pair instead of the 5 of the two separate passes, 7 instead of 8 for the whole backward.
 // Each tile has two phases separated by a barrier: {S, exp | dP} and {dV | dS, dK}; the transcendental / VALU stretch of one wave
 // of a pair runs beside the MFMAs of the other.  Stage: Q row | dO row | Q tr | dO tr | L | D, two stages (129 KiB) + 16 KiB of slots.
-template <int HD, bool BF16, bool CAUSAL>
+template <int HD, bool BF16, bool CAUSAL, int KSN = HD / 16, int DTN = HD / 32>
 __global__ __launch_bounds__(512, 2) void bwd_dkv_pair_kernel(const BwdParams p) {
     constexpr int NW = 8;
     using L_ = BwdLane<HD, NW>;
     constexpr int kRows = 128;
-    constexpr int NPASS = L_::NPASS, KS = L_::KS, DT = L_::DT, ROWB = L_::ROWB, TILEB = L_::TILEB;
+    constexpr int NPASS = L_::NPASS, KS = KSN, DT = DTN, ROWB = L_::ROWB, TILEB = L_::TILEB;
     constexpr int NT = 4, STAGEB = NT * TILEB + 512, XCHB = 4096;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const lds_char_ptr smem = (lds_char_ptr)smem_generic;

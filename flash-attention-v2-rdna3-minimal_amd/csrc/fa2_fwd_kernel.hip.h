@@ -252,16 +252,26 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 template <int HD, int NW, int QB, int BIAS>
 constexpr int fwd_min_waves_per_simd() { return (NW == 4 && !BIAS && QB == 1 && HD <= 128) ? 2 : (NW + 3) / 4; }
 
-template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, int BIAS = 0>
+//
+// KSQ / DTN / RTD (round 3, "trimmed" instantiations, fwd_hip.cpp): a head dim D below the kernel's HD keeps the LDS images and
+// the staging pattern of HD (columns >= D are never fetched: out-of-range granules) but runs only the MFMA k-steps and O column
+// blocks that hold real columns — KSQ = ceil(D / 16) k-steps of Q.K^T (rounded up to the instantiated value), DTN = 32-wide O
+// blocks per column half.  RTD (HD = 256, two column halves): the SECOND half holds D - 128 columns only, its block count is a
+// workgroup-uniform run-time bound.  Defaults = the full kernel.  KV-split parts keep the workspace layout of HD (the merge kernel never
+// reads columns >= D).  Reference counterpart: the host-side zero padding of D to a
+// multiple of 32 (kernel_fp16.cu:763-779) — it multiplies the zeros.
+template <int HD, int HDV, bool BF16, bool CAUSAL, int NW, int QB, int BIAS = 0, int KSQ = HD / 16, int DTN = HDV / 32, bool RTD = false>
 __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>())) void fwd_kernel(const FwdParams p) {
     constexpr int kRowsPerBlock = NW * QB * 32;   // Q rows per workgroup (p.nqblk = ceil(Nq / kRowsPerBlock))
     using G_ = Geo<HD, NW>;    // K tile image
     using GV_ = Geo<HDV, NW>;  // V tile image
     constexpr int ROWB = G_::ROWB, TILEB = G_::TILEB, NPASS = G_::NPASS;
     constexpr int VROWB = GV_::ROWB, VTILEB = GV_::TILEB, VNPASS = GV_::NPASS;
-    constexpr int KS_QK = G_::KS_QK, DT = GV_::DT;
+    constexpr int KS_QK = KSQ, DT = DTN;
+    static_assert(KSQ <= G_::KS_QK && DTN <= GV_::DT, "trimmed loop bounds");
     constexpr int VBASE = 2 * TILEB;   // LDS: K buf0 | K buf1 | V buf0 | V buf1
     const int vcol0 = blockIdx.y * HDV;   // first V / O column of this workgroup
+    const int ndt = RTD ? (p.D - vcol0 + 31) / 32 : DT;   // O column blocks of this half that hold real columns (uniform)
     constexpr int kThreads = NW * 64, kRowsPerWave = 32 * QB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -820,6 +830,7 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                if (RTD && dt >= ndt) continue;
                 const char* va = vt + vr_off[dt] + 16 * ks * VROWB;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
                 const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * VROWB));

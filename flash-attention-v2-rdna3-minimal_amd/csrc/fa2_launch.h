@@ -89,6 +89,9 @@ int set_lds(int bytes) {
 // generic HIP forward (fwd_hip.cpp): rows = 256 (8 waves) or 128 (4 waves) per workgroup; bias: the BIAS kernels (always 128 rows)
 FA2_HIDDEN int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
+// trimmed instantiations of the same kernels for head dims well below HD (fwd_hip.cpp compiled with -DFA2_TU_TRIM=1); -1 = none for this p.D
+FA2_HIDDEN int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream);
+FA2_HIDDEN int launch_fwd_hip_trim_bf16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream);
 // merge of the KV-split parts a forward launch left in p.ws (fwd_hip.cpp)
 FA2_HIDDEN int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream);
@@ -112,6 +115,9 @@ inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// trimmed instantiations of the same passes for head dims well below HD (bwd_hip.cpp compiled with -DFA2_TU_TRIM=1); -1 = none for this p.D
+FA2_HIDDEN int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+FA2_HIDDEN int launch_bwd_hip_trim_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 // sum of the parts a split pass left in p.ws (bwd_merge_kernel, bwd_hip.cpp): which = 1: dQ, 2: dK and dV; head dims <= 128
 FA2_HIDDEN int launch_bwd_merge_f16(int HD, const BwdParams& p, int which, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_merge_bf16(int HD, const BwdParams& p, int which, hipStream_t stream);

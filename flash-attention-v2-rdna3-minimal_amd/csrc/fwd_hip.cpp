@@ -8,12 +8,20 @@
 #ifndef FA2_TU_BF16
 #error "compile with -DFA2_TU_BF16=0 or 1"
 #endif
+// -DFA2_TU_TRIM=1: this unit holds the TRIMMED instantiations instead (head dims below the kernel's HD run only the MFMA k-steps and O
+// column blocks that hold real columns: fa2_fwd_kernel.hip.h, KSQ / DTN / RTD) and exports launch_fwd_hip_trim_{f16,bf16}.
+#ifndef FA2_TU_TRIM
+#define FA2_TU_TRIM 0
+#endif
+#ifndef FA2_TRIM          // 0: never dispatch to the trimmed kernels (A/B builds, tools/kbench.py)
+#define FA2_TRIM 1
+#endif
 
 namespace {
 
 constexpr bool kBF16 = FA2_TU_BF16 != 0;
 
-template <int HD, bool CAUSAL, int NW, int BIAS = 0>
+template <int HD, bool CAUSAL, int NW, int BIAS = 0, int KSQ = HD / 16, int DTN = (HD > 128 ? 128 : HD) / 32, bool RTD = false>
 int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     constexpr int HDV = HD > 128 ? 128 : HD;
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
@@ -34,11 +42,55 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
         p.nsplit = 0;
     }
     const dim3 grid((unsigned)nblk, HD / HDV);
-    constexpr auto kern = fa2::fwd_kernel<HD, HDV, kBF16, CAUSAL, NW, 1, BIAS>;
+    constexpr auto kern = fa2::fwd_kernel<HD, HDV, kBF16, CAUSAL, NW, 1, BIAS, KSQ, DTN, RTD>;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
     return (int)hipGetLastError();
 }
+
+#if FA2_TU_TRIM
+
+// Trimmed kernels (no bias).  Returns -1 when the head dim has no trimmed instantiation (the caller runs the full kernel).
+//   HD  64: D <= 32 -> 2 k-steps, 1 column block;  D <= 48 -> 3, 2 (SD 1.5's head dim 40)
+//   HD 128: D <= 96 -> 6, 3 (head dims 80, 96)
+//   HD 256: D <= 160 / 192 / 224 -> 10 / 12 / 14 k-steps; the second column half runs ceil((D - 128) / 32) of its 4 blocks
+// Measured (tools/trim_ab.py, profiles/r08_trim_ab.txt; B1 H24 N4096 fp16, the reference harness's D-scan): D 16 / 32 +27 %, 40 / 48 +4 %,
+// 80 / 96 +12 %, 144 / 160 +19 %, 176 / 192 +10 %, 208 / 224 +3 %; bf16 causal B2 H16 D96 N4096 +9.5 %, D192 N2048 +27 %.
+template <int HD, int KSQ, int DTN, bool RTD>
+int launch_trim(const fa2::FwdParams& p, bool causal, int rows, hipStream_t stream) {
+    if (causal) return rows == 128 ? launch_shape<HD, true, 4, 0, KSQ, DTN, RTD>(p, stream) : launch_shape<HD, true, 8, 0, KSQ, DTN, RTD>(p, stream);
+    return rows == 128 ? launch_shape<HD, false, 4, 0, KSQ, DTN, RTD>(p, stream) : launch_shape<HD, false, 8, 0, KSQ, DTN, RTD>(p, stream);
+}
+
+}  // namespace
+
+namespace fa2 {
+
+#if FA2_TU_BF16
+int launch_fwd_hip_trim_bf16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream) {
+#else
+int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream) {
+#endif
+    switch (HD) {
+        case 64:
+            if (p.D <= 32) return launch_trim<64, 2, 1, false>(p, causal, rows, stream);
+            if (p.D <= 48) return launch_trim<64, 3, 2, false>(p, causal, rows, stream);
+            return -1;
+        case 128:
+            if (p.D <= 96) return launch_trim<128, 6, 3, false>(p, causal, rows, stream);
+            return -1;
+        case 256:
+            if (p.D <= 160) return launch_trim<256, 10, 4, true>(p, causal, rows, stream);
+            if (p.D <= 192) return launch_trim<256, 12, 4, true>(p, causal, rows, stream);
+            if (p.D <= 224) return launch_trim<256, 14, 4, true>(p, causal, rows, stream);
+            return -1;
+        default: return -1;
+    }
+}
+
+}  // namespace fa2
+
+#else   // !FA2_TU_TRIM
 
 // D = 256 runs as two, D = 512 as four 128-column slabs of O per Q block (grid.y), recomputing QK^T per slab.
 // D = 512 (the reference's D > 384 path, FlashAttn.py:65-67; the SD VAE attention block): 4-wave workgroups of 128 Q
@@ -91,6 +143,14 @@ int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool 
 #else
 int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
 #endif
+    if (FA2_TRIM && !bias && p.D < HD && HD <= 256) {     // a trimmed kernel, where one exists
+#if FA2_TU_BF16
+        const int rc = launch_fwd_hip_trim_bf16(HD, p, causal, rows, stream);
+#else
+        const int rc = launch_fwd_hip_trim_f16(HD, p, causal, rows, stream);
+#endif
+        if (rc >= 0) return rc;
+    }
     switch (HD) {
         case 64: return launch_hd<64>(p, causal, rows, bias, stream);
         case 128: return launch_hd<128>(p, causal, rows, bias, stream);
@@ -101,3 +161,5 @@ int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool b
 }
 
 }  // namespace fa2
+
+#endif  // FA2_TU_TRIM

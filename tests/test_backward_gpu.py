@@ -109,6 +109,21 @@ def test_backward_head_dims_masked_in_kernel(D, dt):
         _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
 
 
+@pytest.mark.parametrize("D", [16, 32, 48, 56, 96, 104, 160, 192, 224, 232])
+def test_trimmed_backward_kernels_on_wide_grids(D):
+    """Head dims well below the kernel's HD run TRIMMED instantiations of the passes (only the k-steps / accumulator column blocks that
+    hold real columns, bwd_hip.cpp: D <= 32 / 48 on the 64 kernels, <= 96 on the 128 kernels — wave-pair dK / dV pass included —,
+    <= 160 / 192 / 224 on the 256 kernels): every boundary of the dispatch and one dim beyond it, on a grid wide enough for the
+    256-row dQ workgroups (test_backward_head_dims_masked_in_kernel covers the small-grid shapes), ragged N."""
+    dt = (D // 8) & 1
+    g = torch.Generator(device="cpu").manual_seed(600 + D)
+    mk = lambda n: torch.randn((2, 17, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(1000), mk(900), mk(900), mk(1000)      # 34 heads x 4 q blocks = 136 workgroups of 256 rows
+    for causal in (False, True):
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, causal)
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal)
+
+
 def test_autograd_through_the_operator_matches_torch():
     """FlashAttentionFunction.apply(...).backward(dO) — the reference's training call shape (bench_with_sdpa.py:89-96)."""
     g = torch.Generator(device="cpu").manual_seed(21)

@@ -16,14 +16,17 @@
 #ifndef FA2_TRIM          // 0: never dispatch to the trimmed kernels (A/B builds, tools/kbench.py)
 #define FA2_TRIM 1
 #endif
+#ifndef FA2_TRIM256_MODE
+#define FA2_TRIM256_MODE 2
+#endif
 
 namespace {
 
 constexpr bool kBF16 = FA2_TU_BF16 != 0;
 
-template <int HD, bool CAUSAL, int NW, int BIAS = 0, int KSQ = HD / 16, int DTN = (HD > 128 ? 128 : HD) / 32, bool RTD = false>
+template <int HD, bool CAUSAL, int NW, int BIAS = 0, int KSQ = HD / 16, int DTN = (HD > 128 ? 128 : HD) / 32, bool RTD = false, int HDV_ = 0>
 int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr int HDV = HD > 128 ? 128 : HD;
+    constexpr int HDV = HDV_ ? HDV_ : HD > 128 ? 128 : HD;       // (HDV_ = 256: one pass over all columns, trimmed head dims 129..192 only)
     constexpr int lds_kv = 2 * fa2::Geo<HD, NW>::TILEB + 2 * fa2::Geo<HDV, NW>::TILEB;
     constexpr int lds_epi = FA2_EPI_LDS ? NW * 32 * (HDV * 2 + 16) : 0;     // epilogue image (reuses the K/V space)
     // bias kernels: + NW wave-private 32-row images of the "tile" bias form where they fit (not at D = 512: 160 KiB of K / V buffers)
@@ -80,6 +83,26 @@ int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, h
             if (p.D <= 96) return launch_trim<128, 6, 3, false>(p, causal, rows, stream);
             return -1;
         case 256:
+#if FA2_TRIM256_MODE >= 1
+            // Grids wide enough for 256-row workgroups: ONE pass over all columns instead of two column halves that each recompute Q.K^T
+            // (D <= 160: per 32 x 64 score tile 20 + 20 MFMAs instead of 2 x 20 + 16 + 4).  D <= 160: the accumulators of 5 column blocks and
+            // 10 Q fragments fit the 8-wave shape's 256 registers; above: 4-wave workgroups of 128 rows, one wave per SIMD (512 registers).
+            // Measured (tools/trim_ab.py --dmin 129, profiles/r08_trim256_ab.txt, B1 H24 N4096): D 144 / 160 386 / 390 -> 283 / 287 us (898 TF at
+            // D = 160), 176 / 192 430 / 436 -> 389 / 390; on small grids (rows == 128) the column halves — twice the workgroups — stay ahead.
+            if (rows != 128) {
+                if (p.D <= 160)
+                    return causal ? launch_shape<256, true, 8, 0, 10, 5, false, 256>(p, stream) : launch_shape<256, false, 8, 0, 10, 5, false, 256>(p, stream);
+                if (p.D <= 192)
+                    return causal ? launch_shape<256, true, 4, 0, 12, 6, false, 256>(p, stream) : launch_shape<256, false, 4, 0, 12, 6, false, 256>(p, stream);
+#if FA2_TRIM256_MODE >= 2
+                if (p.D <= 224)
+                    return causal ? launch_shape<256, true, 4, 0, 14, 7, false, 256>(p, stream) : launch_shape<256, false, 4, 0, 14, 7, false, 256>(p, stream);
+                // every column (D <= 256), causal only: the non-causal instantiation spills 27 registers and measured 547 -> 700 us at B1 H24 N4096,
+                // the causal one fits: bf16 B2 H16 N4096 D256 414 -> 351 us (profiles/r08_trim256_ab.txt)
+                if (causal) return launch_shape<256, true, 4, 0, 16, 8, false, 256>(p, stream);
+#endif
+            }
+#endif
             if (p.D <= 160) return launch_trim<256, 10, 4, true>(p, causal, rows, stream);
             if (p.D <= 192) return launch_trim<256, 12, 4, true>(p, causal, rows, stream);
             if (p.D <= 224) return launch_trim<256, 14, 4, true>(p, causal, rows, stream);
@@ -143,7 +166,7 @@ int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool 
 #else
 int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
 #endif
-    if (FA2_TRIM && !bias && p.D < HD && HD <= 256) {     // a trimmed kernel, where one exists
+    if (FA2_TRIM && !bias && (p.D < HD || (HD == 256 && causal && FA2_TRIM256_MODE >= 2)) && HD <= 256) {     // a trimmed kernel, where one exists
 #if FA2_TU_BF16
         const int rc = launch_fwd_hip_trim_bf16(HD, p, causal, rows, stream);
 #else

@@ -291,12 +291,13 @@ def test_head_dims_masked_in_kernel(D, dt):
         _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
 
 
-@pytest.mark.parametrize("D", [16, 32, 48, 56, 88, 96, 104, 136, 160, 168, 192, 216, 224, 232])
+@pytest.mark.parametrize("D", [16, 32, 48, 56, 88, 96, 104, 136, 160, 168, 192, 216, 224, 232, 256])
 def test_trimmed_kernels_on_grids_of_256_row_workgroups(D):
     """Head dims below the kernel's HD run TRIMMED instantiations (only the MFMA k-steps and O column blocks that hold real
     columns, fwd_hip.cpp: D <= 32 / 48 on the 64 kernel, <= 96 on the 128 kernel, <= 160 / 192 / 224 on the 256 kernel whose second
     column half then runs ceil((D - 128) / 32) blocks) — here on a grid wide enough for the 8-wave 256-row shape (the small-grid
-    128-row shape is test_head_dims_masked_in_kernel), at every boundary of the dispatch and one dim beyond it, ragged N."""
+    128-row shape is test_head_dims_masked_in_kernel), at every boundary of the dispatch and one dim beyond it, ragged N.  On such
+    grids head dims 129..224 (causal: ..256) run ONE pass over all columns (HDV = 256) instead of two column halves."""
     dt = (D // 8) & 1
     g = torch.Generator(device="cpu").manual_seed(500 + D)
     B, H, N, Nkv = 2, 13, 1000, 1111           # 26 heads x 4 q blocks = 104 workgroups > 3/8 of the CUs

@@ -31,6 +31,14 @@ SHAPES = [("ref D-scan", 1, 24, 4096, 4096, d, torch.float16, False) for d in (1
     ("ragged", 3, 5, 1000, 777, 88, torch.float16, False),
     ("ragged", 3, 5, 1000, 777, 152, torch.bfloat16, True),
     ("ragged", 3, 5, 333, 1111, 24, torch.float16, False),
+    ("f16 causal", 2, 16, 2048, 2048, 160, torch.float16, True),
+    ("small grid", 1, 8, 1024, 1024, 160, torch.float16, False),
+    ("small grid", 1, 8, 1024, 1024, 192, torch.bfloat16, True),
+    ("d-scan bf16", 1, 24, 4096, 4096, 136, torch.bfloat16, False),
+    ("ref D-scan", 1, 24, 4096, 4096, 240, torch.float16, False),
+    ("ref D-scan", 1, 24, 4096, 4096, 256, torch.float16, False),
+    ("bf16 causal", 2, 16, 4096, 4096, 256, torch.bfloat16, True),
+    ("b8 d256", 8, 16, 2048, 2048, 256, torch.float16, False),
 ]
 
 
@@ -49,6 +57,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--libs", default="base,notrim")
+    ap.add_argument("--dmin", type=int, default=0, help="only shapes with D >= this")
     ap.add_argument("--bwd", action="store_true", help="time fa2_bwd (forward once, then the backward) instead of the forward")
     a = ap.parse_args()
     libs = {n: load(n) for n in a.libs.split(",")}
@@ -56,6 +65,8 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     print(torch.cuda.get_device_name(0), "builds:", list(libs))
     for label, B, H, Nq, Nkv, D, dt, causal in SHAPES:
+        if D < a.dmin:
+            continue
         g = torch.Generator(device=dev).manual_seed(7)
         q = torch.rand((B, H, Nq, D), generator=g, device=dev, dtype=torch.float32).to(dt)
         k, v = (torch.rand((B, H, Nkv, D), generator=g, device=dev, dtype=torch.float32).to(dt) for _ in range(2))

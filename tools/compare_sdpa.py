@@ -25,16 +25,21 @@ SHAPES = [  # name, B, H, Nq, Nkv, D, dtype, causal
 ]
 
 
-def timeit(fn, iters):
+def timeit(fn, iters, windows=5):
+    """median over `windows` timing windows of `iters` calls (HIP events): a single window of a few milliseconds of host-bound calls — the
+    small SD shapes' backward — doubles when the host thread is descheduled once (seen on three boxes: 59 / 117 / 181 us for the same shape)"""
     for _ in range(max(3, iters // 5)):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    ts = []
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def main():

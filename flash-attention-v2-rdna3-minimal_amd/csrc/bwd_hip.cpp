@@ -16,6 +16,9 @@
 #ifndef FA2_TRIM          // 0: never dispatch to the trimmed kernels (A/B builds, tools/kbench.py)
 #define FA2_TRIM 1
 #endif
+#ifndef FA2_BWD_FUSE256   // 0: trimmed head dims 129..224 keep the separate dV and dK sweeps (A/B builds)
+#define FA2_BWD_FUSE256 1
+#endif
 
 namespace {
 
@@ -132,6 +135,20 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
         return p.nsplit > 1 ? launch_merge<HD>(p, 2, stream) : 0;
     } else {
         p.nblk = (p.Nkv + kRows - 1) / kRows;   // dV, dK: one workgroup per kRows KV rows, two sweeps
+#if FA2_BWD_FUSE256
+        // trimmed head dims 129..224: both KV-owned accumulators (2 x DTN blocks) and the K / V fragments of KSN k-steps fit the 512-register budget
+        // of one wave per SIMD, so dK and dV come from ONE sweep that forms S and dP once (4 GEMMs instead of 2 + 3, one launch less).  Measured
+        // (tools/trim_ab.py --bwd --dmin 129, profiles/r08_fuse256_ab.txt, whole backward B1 H24 N4096): D 144 / 160 1 277 / 1 287 -> 1 143 / 1 142 us,
+        // 176 / 192 1 490 / 1 498 -> 1 304 / 1 319, 208 / 224 1 707 / 1 771 -> 1 627 / 1 716, B1 H8 N1024 D160 115 -> 97
+        if constexpr (HD == 256 && !CAUSAL && DTN <= 7) {   // (causal: 11 spilled registers at 5 blocks, 100+ above; measured -5 .. -9 %)
+            constexpr int lds = kStages * (4 * TILEB + 512);
+            static_assert(lds <= 160 * 1024, "LDS budget");
+            constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, true, HD, 0, KSN, DTN>;
+            if ((rc = fa2::set_lds<kern>(lds))) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(NW * 64), lds, stream, p);
+            return (int)hipGetLastError();
+        }
+#endif
         {
             constexpr int lds = kStages * (2 * TILEB + 512);
             constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HD, 0, KSN, DTN>;

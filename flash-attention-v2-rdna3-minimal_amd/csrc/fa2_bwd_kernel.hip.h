@@ -660,6 +660,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
                 if constexpr (WANT_DK) {
                     dma16_to_lds3(grs, dst + TILEB, grow_b + ln.r_src[i], 0);
                     if constexpr (HDV == HD) dma16_to_lds3(qrs, dst + 2 * TILEB, qrow_b + ln.t_src[i], 0);
+                    if constexpr (BOTH) dma16_to_lds3(grs, dst + 3 * TILEB, grow_b + ln.t_src[i], 0);   // dO tr-form (fused pass of the trimmed head dims 129..224)
                 } else {
                     if constexpr (HDV == HD) dma16_to_lds3(grs, dst + TILEB, grow_b + ln.t_src[i], 0);
                 }

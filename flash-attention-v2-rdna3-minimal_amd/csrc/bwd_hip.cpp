@@ -167,6 +167,42 @@ int launch_bwd_t(fa2::BwdParams p, int parts, hipStream_t stream) {
     }
 }
 
+// Head dims above 256 (kernel head dim 512, the SD VAE attention block): 4-wave workgroups of 128 rows, one wave per SIMD with the 512-register
+// budget, single LDS stage; every workgroup produces a 128-column slab of its output (grid.y = 4) and recomputes S (and dP) over the whole
+// head dim.  Three launches: dQ (+ delta), dV, dK.  A correct path for a rare shape, not a tuned one.
+// KSN (trimmed instantiations): ceil(D / 16) k-steps of the products contracted over the head dim; only the slabs that hold real columns are launched.
+template <bool CAUSAL, int KSN = 32>
+int launch_bwd_512(fa2::BwdParams p, int parts, hipStream_t stream) {
+    constexpr int HD = 512, HDV = 128, NW = 4, kRows = NW * 32;
+    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB, TILEBV = fa2::Geo<HDV, NW>::TILEB;
+    int rc;
+    if (parts & 1) {
+        constexpr int lds = 2 * TILEB + TILEBV;
+        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HDV, 0, KSN, HDV / 32>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        p.nblk = (p.Nq + kRows - 1) / kRows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), (p.D + HDV - 1) / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    if (!(parts & 2)) return 0;
+    p.nblk = (p.Nkv + kRows - 1) / kRows;
+    {
+        constexpr int lds = TILEB + TILEBV + 512;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HDV, 0, KSN, HDV / 32>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), (p.D + HDV - 1) / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    {
+        constexpr int lds = 2 * TILEB + TILEBV + 512;
+        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HDV, 0, KSN, HDV / 32>;
+        if ((rc = fa2::set_lds<kern>(lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), (p.D + HDV - 1) / HDV), dim3(NW * 64), lds, stream, p);
+        if ((rc = (int)hipGetLastError())) return rc;
+    }
+    return 0;
+}
+
 #if FA2_TU_TRIM
 
 template <int HD, int KSN, int DTN>
@@ -198,6 +234,11 @@ int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, 
             if (p.D <= 192) return launch_trim<256, 12, 6>(p, causal, parts, stream);
             if (p.D <= 224) return launch_trim<256, 14, 7>(p, causal, parts, stream);
             return -1;
+        case 512:
+            if (p.D <= 320) return causal ? launch_bwd_512<true, 20>(p, parts, stream) : launch_bwd_512<false, 20>(p, parts, stream);
+            if (p.D <= 384) return causal ? launch_bwd_512<true, 24>(p, parts, stream) : launch_bwd_512<false, 24>(p, parts, stream);
+            if (p.D <= 448) return causal ? launch_bwd_512<true, 28>(p, parts, stream) : launch_bwd_512<false, 28>(p, parts, stream);
+            return -1;
         default: return -1;
     }
 }
@@ -205,41 +246,6 @@ int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, 
 }  // namespace fa2
 
 #else   // !FA2_TU_TRIM
-
-// Head dims above 256 (kernel head dim 512, the SD VAE attention block): 4-wave workgroups of 128 rows, one wave per SIMD with the 512-register
-// budget, single LDS stage; every workgroup produces a 128-column slab of its output (grid.y = 4) and recomputes S (and dP) over the whole
-// head dim.  Three launches: dQ (+ delta), dV, dK.  A correct path for a rare shape, not a tuned one.
-template <bool CAUSAL>
-int launch_bwd_512(fa2::BwdParams p, int parts, hipStream_t stream) {
-    constexpr int HD = 512, HDV = 128, NW = 4, kRows = NW * 32;
-    constexpr int TILEB = fa2::Geo<HD, NW>::TILEB, TILEBV = fa2::Geo<HDV, NW>::TILEB;
-    int rc;
-    if (parts & 1) {
-        constexpr int lds = 2 * TILEB + TILEBV;
-        constexpr auto kern = fa2::bwd_dq_kernel<HD, kBF16, CAUSAL, NW, HDV>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        p.nblk = (p.Nq + kRows - 1) / kRows;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
-        if ((rc = (int)hipGetLastError())) return rc;
-    }
-    if (!(parts & 2)) return 0;
-    p.nblk = (p.Nkv + kRows - 1) / kRows;
-    {
-        constexpr int lds = TILEB + TILEBV + 512;
-        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, false, NW, false, HDV>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
-        if ((rc = (int)hipGetLastError())) return rc;
-    }
-    {
-        constexpr int lds = 2 * TILEB + TILEBV + 512;
-        constexpr auto kern = fa2::bwd_dkv_kernel<HD, kBF16, CAUSAL, true, NW, false, HDV>;
-        if ((rc = fa2::set_lds<kern>(lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk), HD / HDV), dim3(NW * 64), lds, stream, p);
-        if ((rc = (int)hipGetLastError())) return rc;
-    }
-    return 0;
-}
 
 template <int HD>
 int launch_bwd(const fa2::BwdParams& p, bool causal, int parts, hipStream_t stream) {
@@ -255,7 +261,7 @@ int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipS
 #else
 int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream) {
 #endif
-    if (FA2_TRIM && p.D < HD && HD <= 256) {      // a trimmed instantiation, where one exists
+    if (FA2_TRIM && p.D < HD) {      // a trimmed instantiation, where one exists
 #if FA2_TU_BF16
         const int rc = launch_bwd_hip_trim_bf16(HD, p, causal, parts, stream);
 #else

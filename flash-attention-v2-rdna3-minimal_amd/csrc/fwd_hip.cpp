@@ -44,7 +44,7 @@ int launch_shape(const fa2::FwdParams& p0, hipStream_t stream) {
     } else {
         p.nsplit = 0;
     }
-    const dim3 grid((unsigned)nblk, HD / HDV);
+    const dim3 grid((unsigned)nblk, (p.D + HDV - 1) / HDV);      // column slabs that hold real columns (HD / HDV of them at most)
     constexpr auto kern = fa2::fwd_kernel<HD, HDV, kBF16, CAUSAL, NW, 1, BIAS, KSQ, DTN, RTD>;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
@@ -107,6 +107,13 @@ int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, h
             if (p.D <= 192) return launch_trim<256, 12, 4, true>(p, causal, rows, stream);
             if (p.D <= 224) return launch_trim<256, 14, 4, true>(p, causal, rows, stream);
             return -1;
+        case 512:
+            // 128-column slabs of O per 128-row workgroup, each recomputing Q.K^T over the head dim: ceil(D / 16) k-steps instead of 32 (and only the
+            // slabs that hold real columns are launched at all: launch_shape); the last slab runs ceil((D mod 128) / 32) of its 4 blocks
+            if (p.D <= 320) return causal ? launch_shape<512, true, 4, 0, 20, 4, true>(p, stream) : launch_shape<512, false, 4, 0, 20, 4, true>(p, stream);
+            if (p.D <= 384) return causal ? launch_shape<512, true, 4, 0, 24, 4, true>(p, stream) : launch_shape<512, false, 4, 0, 24, 4, true>(p, stream);
+            if (p.D <= 448) return causal ? launch_shape<512, true, 4, 0, 28, 4, true>(p, stream) : launch_shape<512, false, 4, 0, 28, 4, true>(p, stream);
+            return -1;
         default: return -1;
     }
 }
@@ -166,7 +173,7 @@ int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool 
 #else
 int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream) {
 #endif
-    if (FA2_TRIM && !bias && (p.D < HD || (HD == 256 && causal && FA2_TRIM256_MODE >= 2)) && HD <= 256) {     // a trimmed kernel, where one exists
+    if (FA2_TRIM && !bias && (p.D < HD || (HD == 256 && causal && FA2_TRIM256_MODE >= 2))) {     // a trimmed kernel, where one exists
 #if FA2_TU_BF16
         const int rc = launch_fwd_hip_trim_bf16(HD, p, causal, rows, stream);
 #else

@@ -196,7 +196,7 @@ def test_full_size_config3_backward_sampled_heads():
     assert float((grads[2][:, :, -1].float() - want).abs().max()) <= 1.6e-2 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("D", [264, 320, 384, 512])
+@pytest.mark.parametrize("D", [264, 320, 328, 384, 448, 456, 512])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_backward_head_dims_above_256(D, dt):
     """Head dims above 256 (the forward reaches 512: the SD VAE attention block, the reference's D > 384 case, FlashAttn.py:65-67) run the

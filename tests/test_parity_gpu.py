@@ -309,7 +309,7 @@ def test_trimmed_kernels_on_grids_of_256_row_workgroups(D):
         _assert_close_to_oracle(o, lse, q, k, v, dt, causal)
 
 
-@pytest.mark.parametrize("D", [264, 320, 384, 512])
+@pytest.mark.parametrize("D", [264, 320, 328, 384, 448, 456, 512])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_head_dims_above_256(D, dt):
     """The reference accepts any head dim (it pads D to a multiple of 32 and switches to Br = 32 above 384,

@@ -39,6 +39,14 @@ SHAPES = [("ref D-scan", 1, 24, 4096, 4096, d, torch.float16, False) for d in (1
     ("ref D-scan", 1, 24, 4096, 4096, 256, torch.float16, False),
     ("bf16 causal", 2, 16, 4096, 4096, 256, torch.bfloat16, True),
     ("b8 d256", 8, 16, 2048, 2048, 256, torch.float16, False),
+    ("d-scan >256", 1, 24, 4096, 4096, 264, torch.float16, False),
+    ("d-scan >256", 1, 24, 4096, 4096, 320, torch.float16, False),
+    ("d-scan >256", 1, 24, 4096, 4096, 384, torch.float16, False),
+    ("d-scan >256", 1, 24, 4096, 4096, 448, torch.float16, False),
+    ("d-scan >256", 1, 24, 4096, 4096, 512, torch.float16, False),
+    ("bf16 causal", 2, 8, 2048, 2048, 320, torch.bfloat16, True),
+    ("ragged", 2, 3, 700, 900, 392, torch.bfloat16, True),
+    ("sd vae", 1, 1, 4096, 4096, 512, torch.float16, False),
 ]
 
 

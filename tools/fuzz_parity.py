@@ -58,9 +58,9 @@ def make(shape_bhnd, dtype, layout, rng, gen, dist):
 def one_case(i, rng, gen, want_bwd):
     dtype = rng.choice([torch.float16, torch.bfloat16])
     dmax = 512
-    D = rng.choice([8, 16, 24, 32, 40, 48, 64, 72, 80, 96, 104, 112, 120, 128, 128, 128, 136, 160, 192, 256, 320, 384, 512])
+    D = rng.choice([8, 16, 24, 32, 40, 48, 64, 72, 80, 96, 104, 112, 120, 128, 128, 128, 136, 144, 160, 176, 192, 208, 224, 232, 256, 320, 328, 384, 448, 512])
     while D > dmax:
-        D = rng.choice([40, 64, 80, 128, 160, 256])
+        D = rng.choice([32, 40, 64, 80, 96, 128, 160, 192, 224, 256])
     big = rng.random() < 0.15
     nmax = 2300 if big and D <= 128 else 700 if D <= 256 else 300
     pick_n = lambda: rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 77, 127, 128, 129, 255, 256, 257, 511, 512, 513]) \

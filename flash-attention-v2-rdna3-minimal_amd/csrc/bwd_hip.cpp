@@ -227,6 +227,7 @@ int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, 
             if (p.D <= 32) return launch_trim<64, 2, 1>(p, causal, parts, stream);
             return -1;      // (3 k-steps, 2 blocks for D <= 48 measured -1 .. +3 %: the fused D <= 64 pass is not bound by its MFMAs; not instantiated)
         case 128:
+            if (p.D <= 80) return launch_trim<128, 5, 3>(p, causal, parts, stream);
             if (p.D <= 96) return launch_trim<128, 6, 3>(p, causal, parts, stream);
             return -1;
         case 256:

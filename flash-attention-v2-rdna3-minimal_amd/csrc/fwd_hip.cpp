@@ -80,6 +80,7 @@ int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, h
             if (p.D <= 48) return launch_trim<64, 3, 2, false>(p, causal, rows, stream);
             return -1;
         case 128:
+            if (p.D <= 80) return launch_trim<128, 5, 3, false>(p, causal, rows, stream);      // (SD 1.5's head dim 80: 5 k-steps exactly)
             if (p.D <= 96) return launch_trim<128, 6, 3, false>(p, causal, rows, stream);
             return -1;
         case 256:

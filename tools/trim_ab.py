@@ -22,6 +22,7 @@ from rocwmma_fattn import _fa2_lib  # noqa: E402
 SHAPES = [("ref D-scan", 1, 24, 4096, 4096, d, torch.float16, False) for d in (16, 32, 40, 48, 80, 96, 144, 160, 176, 192, 208, 224)] + [
     ("sd15-64x64", 2, 8, 4096, 4096, 40, torch.float16, False),
     ("sd15-32x32", 2, 8, 1024, 1024, 80, torch.float16, False),
+    ("bf16 causal", 2, 16, 4096, 4096, 72, torch.bfloat16, True),
     ("sd15-16x16", 2, 8, 256, 256, 160, torch.float16, False),
     ("sd15-cross", 2, 8, 4096, 77, 40, torch.float16, False),
     ("sd21-64x64", 2, 5, 4096, 4096, 64, torch.float16, False),
@@ -66,6 +67,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--libs", default="base,notrim")
     ap.add_argument("--dmin", type=int, default=0, help="only shapes with D >= this")
+    ap.add_argument("--dmax", type=int, default=1 << 20, help="only shapes with D <= this")
     ap.add_argument("--bwd", action="store_true", help="time fa2_bwd (forward once, then the backward) instead of the forward")
     a = ap.parse_args()
     libs = {n: load(n) for n in a.libs.split(",")}
@@ -73,7 +75,7 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     print(torch.cuda.get_device_name(0), "builds:", list(libs))
     for label, B, H, Nq, Nkv, D, dt, causal in SHAPES:
-        if D < a.dmin:
+        if D < a.dmin or D > a.dmax:
             continue
         g = torch.Generator(device=dev).manual_seed(7)
         q = torch.rand((B, H, Nq, D), generator=g, device=dev, dtype=torch.float32).to(dt)

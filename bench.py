@@ -165,9 +165,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher.  One rank per GPU under
+        # torch.distributed.run on a free loopback port; rank 0 of the children prints the JSON line, this process is replaced.
+        if not args.same_device:
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                sys.exit("bench.py --gpus %d: only %d GPU(s) visible (use --backend gloo --same-device for a one-GPU dry run)" % (args.gpus, have))
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.realpath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the attention operator has no CPU path")
@@ -328,6 +342,14 @@ def main():
                        "recompute S and dP, so 7 GEMM-equivalents execute; time = wall of 30 autograd backward calls / 30 (HIP events)"}
 
     elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms])
+    rank_info = None
+    if use_dist:
+        # which device every rank ran on, as the process group saw it (evidence that N ranks on N GPUs took part)
+        me = {"rank": rank, "device": "cuda:%d" % dev_index, "name": torch.cuda.get_device_name(dev_index),
+              "uuid": str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", ""))}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, me)
+        rank_info = {"backend": args.backend, "world_size": dist.get_world_size(), "ranks": gathered}
 
     if rank == 0:
         flops_global = attention_flops(B_global, H, N, N, D, causal)
@@ -361,8 +383,10 @@ def main():
         }
         if steady is not None:
             line["steady"] = steady
-        if args.force_dist and world == 1:
-            line["dist"] = {"backend": args.backend, "world": 1, "note": "process group, barriers and reductions executed with one rank (--force-dist)"}
+        if rank_info is not None:
+            line["dist"] = rank_info
+            if args.force_dist and world == 1:
+                line["dist"]["note"] = "process group, barriers and reductions executed with one rank (--force-dist)"
         if args.backend != "nccl" or args.same_device:
             line["dry_run"] = "backend=%s same_device=%s: control-flow check of the multi-rank path, not a scaling measurement" % (
                 args.backend, args.same_device)

@@ -22,6 +22,8 @@ struct Options {
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
     std::atomic<int> split{1};         // FA2_SPLIT: KV-split of the last, partly filled round of forward workgroups (fa2_fwd_ws)
+    std::atomic<int> epoch{0};         // bumped by every fa2_set_option: callers that cache a plan (the compiled front end) key it on this
+    std::atomic<int> fold{1};          // FA2_FOLD: 0 = the hand-scheduled forward bodies scale the f32 product, 1 = fp16 launches fold the scale into Q, 2 = bf16 too
 };
 FA2_HIDDEN Options& options();
 FA2_HIDDEN int device_cus();           // compute units of the current device (cached per device index)
@@ -96,7 +98,8 @@ FA2_HIDDEN int launch_fwd_hip_trim_bf16(int HD, const FwdParams& p, bool causal,
 FA2_HIDDEN int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream);
 // hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
-FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
+// fold: the body that folds scale * log2(e) into Q (FA2_CONTRACT_PRESCALE_Q) instead of scaling the f32 product
+FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream);
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
 // dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).
 // Tile costs (us per 64-row tile of a 256-row workgroup, 8-wave HIP kernels): dQ pass 3 GEMMs, fused dK / dV pass 4 — 1.5x / 2x the forward's 0.9 * HD / 64.

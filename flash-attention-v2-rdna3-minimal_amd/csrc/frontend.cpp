@@ -23,6 +23,28 @@ bool strides_ok(const at::Tensor& t) {
 
 at::Tensor kernel_ready(const at::Tensor& t) { return strides_ok(t) ? t : t.contiguous(); }
 
+// Workspace sizes are a function of (dtype, shape, device, options): asked once per shape and option epoch instead of on every call
+// (an SDXL UNet step makes 140 attention calls over 6 shapes).  Per thread: no lock on the call path.
+struct WsKey {
+    int which, dtype, dev; int64_t b, h, n, nkv, d;
+    bool operator==(const WsKey& o) const { return which == o.which && dtype == o.dtype && dev == o.dev && b == o.b && h == o.h && n == o.n && nkv == o.nkv && d == o.d; }
+};
+size_t cached_ws_bytes(int which, int dtype, int dev, int64_t b, int64_t h, int64_t n, int64_t nkv, int64_t d) {
+    struct Entry { WsKey key; size_t bytes; };
+    thread_local std::vector<Entry> cache;
+    thread_local int epoch = -1;
+    const int now = fa2_get_option("epoch");
+    if (now != epoch) { cache.clear(); epoch = now; }
+    const WsKey key{which, dtype, dev, b, h, n, nkv, d};
+    for (const Entry& e : cache)
+        if (e.key == key) return e.bytes;
+    const size_t bytes = which == 0 ? fa2_fwd_workspace_bytes(dtype, (int)b, (int)h, (int)n, (int)nkv, (int)d, 0)
+                                    : fa2_bwd_workspace_bytes(dtype, (int)b, (int)h, (int)n, (int)nkv, (int)d, 0);
+    if (cache.size() >= 64) cache.clear();
+    cache.push_back({key, bytes});
+    return bytes;
+}
+
 std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_t Br, int64_t Bc, bool causal, double scale,
                                 bool permute_NH) {
     (void)Bc;
@@ -84,7 +106,7 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream();
     // scratch for the KV-split of a partly filled last round of workgroups (fa2_fwd_ws): from the caching allocator, per call
     at::Tensor ws;
-    const size_t ws_bytes = causal ? 0 : fa2_fwd_workspace_bytes(dtype_code, (int)b, (int)h, (int)n, (int)n_kv, (int)d_kernel, 0);
+    const size_t ws_bytes = causal ? 0 : cached_ws_bytes(0, dtype_code, q.device().index(), b, h, n, n_kv, d_kernel);
     if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, q.options().dtype(at::kByte));
     const int rc = fa2_fwd_ws(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
                               (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, causal ? 1 : 0,
@@ -123,7 +145,7 @@ std::vector<at::Tensor> backward(at::Tensor Q, at::Tensor K, at::Tensor V, at::T
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Q.device().index()).stream();
     at::Tensor ws;
-    const size_t ws_bytes = causal ? 0 : fa2_bwd_workspace_bytes(dtype_code, (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, 0);
+    const size_t ws_bytes = causal ? 0 : cached_ws_bytes(1, dtype_code, Q.device().index(), b, h, act_n, act_nkv, dk);
     if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, Q.options().dtype(at::kByte));
     const int rc = fa2_bwd_ws(dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr<float>(), dQ.data_ptr(),
                               dK.data_ptr(), dV.data_ptr(), delta.data_ptr<float>(), (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, qs, ks, vs, os, gs,

@@ -10,9 +10,9 @@ namespace {
 // Persistent workgroups of the d128 kernel (non-causal launches): at most one workgroup per CU, each working through a
 // strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
 // (fa2_fwd_d128.hip.h).  Option "persist" = 0 launches one workgroup per item instead (A/B measurements, bit-identity tests).
-template <int HD, bool BF16, bool CAUSAL>
+template <int HD, bool BF16, bool CAUSAL, bool FOLD>
 int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL>;
+    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL, FOLD>;
     constexpr int lds = fa2::AsmGeo<HD>::LDS_BYTES;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     fa2::FwdParams p = p0;
@@ -38,13 +38,15 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
 
 namespace fa2 {
 
-int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
-    if (HD == 128) {
-        if (bf16) return causal ? launch_asm_t<128, true, true>(p, stream) : launch_asm_t<128, true, false>(p, stream);
-        return causal ? launch_asm_t<128, false, true>(p, stream) : launch_asm_t<128, false, false>(p, stream);
-    }
-    if (bf16) return causal ? launch_asm_t<64, true, true>(p, stream) : launch_asm_t<64, true, false>(p, stream);
-    return causal ? launch_asm_t<64, false, true>(p, stream) : launch_asm_t<64, false, false>(p, stream);
+template <int HD, bool BF16>
+static int launch_asm_hd(const FwdParams& p, bool causal, bool fold, hipStream_t stream) {
+    if (fold) return causal ? launch_asm_t<HD, BF16, true, true>(p, stream) : launch_asm_t<HD, BF16, false, true>(p, stream);
+    return causal ? launch_asm_t<HD, BF16, true, false>(p, stream) : launch_asm_t<HD, BF16, false, false>(p, stream);
+}
+
+int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream) {
+    if (HD == 128) return bf16 ? launch_asm_hd<128, true>(p, causal, fold, stream) : launch_asm_hd<128, false>(p, causal, fold, stream);
+    return bf16 ? launch_asm_hd<64, true>(p, causal, fold, stream) : launch_asm_hd<64, false>(p, causal, fold, stream);
 }
 
 }  // namespace fa2

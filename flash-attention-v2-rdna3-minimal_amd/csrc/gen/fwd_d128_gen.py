@@ -1090,21 +1090,24 @@ def main():
         if hd == 64 and any(o in PROBE_OPTS for o in cfg.get("opt", ())):
             continue
         for bf16 in (False, True):
-            c = dict(cfg)
-            opts = tuple(o for o in cfg.get("opt", ()) if o != "f32scale")
-            # fp16: the shipped bodies fold the scale into Q ("ct": Q * scale*log2e rounded once to fp16 — the scaling contract of the reference's own
-            # oracle, pure_torch_ver.py:61 — and the running reference enters the first QK^T k-step as its C operand): the 64 v_fma_f32 per tile go.
-            # Head dim 64, whose body runs at its issue bound: +9 % (B2 H16 N4096); head dim 128: +1.4 % config 2, +2.1 % config 4, +2.9 % B8
-            # (tools/kbench.py, one box).  It costs ~2e-4 of log2 LSE on U[0,1) / N(0,1) inputs.  bf16 keeps the f32 scale (its 8-bit mantissa would
-            # cost 6e-3 of LSE); opt=f32scale builds the unfolded fp16 bodies (A/B runs).
-            if not bf16 and "f32scale" not in cfg.get("opt", ()) and "ct" not in opts:
-                opts += ("ct",)
-            c["opt"] = opts
-            g = Gen(bf16, hd=hd, **c)
-            prog = g.build()
-            path = os.path.join(out_dir, "fa2_fwd_d%d_%s.inc" % (hd, "bf16" if bf16 else "f16"))
-            write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))
-            print(path, len(prog.ins), "instructions")
+            # Two bodies per (head dim, dtype), chosen per launch by the host (host.cpp: plan_range; option "fold"):
+            #   fa2_fwd_d<hd>_<dt>.inc       the scale multiplies the f32 Q.K^T product — the reference kernel's contract (kernel_fp16.cu:164)
+            #   fa2_fwd_d<hd>_<dt>_fold.inc  "ct": Q * scale*log2e rounded once to the I/O dtype — the scaling contract of the reference's own oracle,
+            #                                pure_torch_ver.py:61 — and the running reference enters the first QK^T k-step as its C operand: the 64
+            #                                v_fma_f32 per tile go.  Head dim 64, whose body runs at its issue bound: +9 % (B2 H16 N4096); head dim 128:
+            #                                +1.4 % config 2, +2.1 % config 4, +2.9 % B8 (tools/kbench.py, one box).  fp16: ~2e-4 of log2 LSE on U[0,1) /
+            #                                N(0,1) inputs, growing with the logits; bf16 (8-bit mantissa): ~6e-3 — opt-in only (option "fold" = 2).
+            for fold in (False, True):
+                c = dict(cfg)
+                opts = tuple(o for o in cfg.get("opt", ()) if o not in ("f32scale", "ct"))
+                if fold:
+                    opts += ("ct",)
+                c["opt"] = opts
+                g = Gen(bf16, hd=hd, **c)
+                prog = g.build()
+                path = os.path.join(out_dir, "fa2_fwd_d%d_%s%s.inc" % (hd, "bf16" if bf16 else "f16", "_fold" if fold else ""))
+                write_atomic(path, "// GENERATED by csrc/gen/fwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog))
+                print(path, len(prog.ins), "instructions")
     write_atomic(os.path.join(out_dir, "fa2_fwd_d128_clobbers.inc"),
                  "// GENERATED by csrc/gen/fwd_d128_gen.py — do not edit.\n" + clobber_list() + "\n")
 

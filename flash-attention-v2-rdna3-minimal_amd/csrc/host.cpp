@@ -31,6 +31,7 @@ Options& options() {
         if (const char* e = std::getenv("FA2_ASM")) o.asm_mask = std::atoi(e);
         if (const char* e = std::getenv("FA2_PERSIST")) o.persist = std::atoi(e);
         if (const char* e = std::getenv("FA2_SPLIT")) o.split = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FA2_FOLD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) o.fold = v; }
         return true;
     }();
     (void)init;
@@ -127,24 +128,44 @@ bool asm_kv_len_ok(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     return HD == 128 && bf16 && p.Nkv <= 2 * fa2::kKvTile;
 }
 
-int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+// Does a launch of the hand-scheduled body fold scale * log2(e) into Q (rounded once to the I/O dtype: FA2_CONTRACT_PRESCALE_Q), or does it scale
+// the f32 product like the reference kernel (kernel_fp16.cu:164) and every compiler-scheduled kernel here?  Option "fold": 0 never, 1 (default)
+// fp16 launches, 2 bf16 launches too.  Only while c = scale * log2(e) <= 1: the prescaled Q must stay inside the I/O dtype's range whatever the
+// caller's Q holds (|q| * c <= |q|); a larger scale runs the f32-scale body of the same schedule (scale > 0.69 could overflow fp16).
+bool asm_folds(bool bf16, const fa2::FwdParams& p) {
+    const int f = fa2::options().fold.load(std::memory_order_relaxed);
+    return (bf16 ? f >= 2 : f >= 1) && p.c <= 1.0f;
+}
+
+// What one launch over the heads [p.bh0, p.bh0 + p.nbh) runs: the ONE place that decides it (launch_range executes the plan, fa2_fwd_plan reports it).
+struct RangePlan { int kernel, contract; int rows; bool fold; };
+
+RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     const int rows = pick_rows(p, causal);
     // Head dim exactly 128 with a positive scale: the hand-scheduled 4-wave kernel (256-row workgroups).  Head dim 64 has its generated
     // body too (same generator, half the MFMAs per tile for the same softmax work, row sums on the matrix pipe), but a lone wave per SIMD
     // issues that VALU-bound mix no faster than the two waves of the compiler-scheduled 8-wave kernel: same box (tools/fwd_ab.py) B2 H16
     // N4096 933 vs 947 TF, B1 H24 N8192 1032 vs 1022, causal bf16 917 vs 869 — so it takes the causal launches (+5.5 %) only; option
     // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
-    // (round 3) fp16: the generated body folds the scale into Q and then beats the 8-wave kernel non-causal too, so every fp16 launch takes it.
-    const bool d64_asm = HD == 64 && (causal || !bf16 || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    // (round 3) the body that folds the scale into Q beats the 8-wave kernel non-causal too (+9 %), so every launch that folds takes it.
+    const bool fold = asm_folds(bf16, p);
+    const bool d64_asm = HD == 64 && (causal || fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
     if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
         asm_kv_len_ok(HD, bf16, p, causal))
-        return fa2::launch_fwd_asm(HD, bf16, p, causal, stream);
-    return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, rows, false, stream);
+        return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (HD == 64 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold};
+    return {rows == 256 ? FA2_KERNEL_HIP_256 : FA2_KERNEL_HIP_128, 0, rows, false};
 }
 
-// non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 in fp16 (launch_range)
+int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
+    const RangePlan r = plan_range(HD, bf16, p, causal);
+    if (r.kernel == FA2_KERNEL_ASM) return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream);
+    return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, r.rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, r.rows, false, stream);
+}
+
+// non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 when the launch folds the scale (plan_range)
 bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
-    return (HD == 128 || (HD == 64 && !bf16)) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) && asm_kv_len_ok(HD, bf16, p, false);
+    const bool d64 = HD == 64 && (asm_folds(bf16, p) || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    return (HD == 128 || d64) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) && asm_kv_len_ok(HD, bf16, p, false);
 }
 
 // KV-split tail (fa2_fwd_ws).  B*H*ceil(Nq/256) equal workgroups on the CUs take ceil(x / CUs) rounds however empty the last one is: SDXL's
@@ -167,25 +188,28 @@ fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causa
     return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, asm_rounds ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
 }
 
-int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
-    if (ws) {
+// The whole forward call: at most two launches (+ the merge of a split).  plan_fwd decides, launch_fwd executes, fa2_fwd_plan reports.
+struct FwdPlan {
+    fa2::SplitPlan split;        // nsplit > 1: the last round's items run as KV-split parts (needs the caller's workspace)
+    bool split_asm = false;      // ... inside the hand-scheduled persistent kernel (else the 8-wave HIP kernel)
+    int main_heads = 0;          // heads [0, main_heads) run `main`, the others `tail` (HD <= 64 tail split; main_heads == nbh: one launch)
+    RangePlan main{0, 0, 0, false}, tail{0, 0, 0, false};
+};
+
+FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool have_ws, size_t ws_bytes) {
+    FwdPlan f;
+    f.main_heads = p0.nbh;
+    if (have_ws) {
         const fa2::SplitPlan pl = plan_split(p0, HD, bf16, causal);
-        if (pl.nsplit > 1 && (int64_t)ws_bytes >= fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD) && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
+        if (pl.nsplit > 1 && (int64_t)ws_bytes >= fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD)) {
             fa2::FwdParams p = p0;
             p.rows_hint = 256;
-            p.full_items = pl.full_items; p.split_items = pl.split_items; p.nsplit = pl.nsplit;
-            p.ws = (float*)ws;
-            int rc;
-            if (asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256) {
-                // the hand-scheduled persistent kernel: every workgroup works through its whole items, then its parts (the item seam hides a
-                // part's load phase like any other item's; the block stores a part's f32 tile itself)
-                p.item_cap = pl.full_items + pl.split_items * pl.nsplit;
-                rc = fa2::launch_fwd_asm(HD, bf16, p, false, stream);
-            } else {
-                rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
-            }
-            if (rc) return rc;
-            return bf16 ? fa2::launch_fwd_combine_bf16(HD, p, stream) : fa2::launch_fwd_combine_f16(HD, p, stream);
+            f.split = pl;
+            f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
+            const bool fold = f.split_asm && asm_folds(bf16, p);
+            f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (HD == 64 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}
+                                 : RangePlan{FA2_KERNEL_HIP_256, 0, 256, false};
+            return f;
         }
     }
     if (HD <= 64) {     // (measured at D = 128, B1 H24 N4096: 188 -> 194 us — the 128-row shape is too slow there)
@@ -193,12 +217,47 @@ int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStre
         if (main_heads < p0.nbh) {
             fa2::FwdParams p = p0;
             p.nbh = main_heads;
-            if (int rc = launch_range(HD, bf16, p, causal, stream)) return rc;
+            f.main_heads = main_heads;
+            f.main = plan_range(HD, bf16, p, causal);
             p.bh0 = p0.bh0 + main_heads;
             p.nbh = p0.nbh - main_heads;
             p.rows_hint = 128;
-            return launch_range(HD, bf16, p, causal, stream);
+            f.tail = plan_range(HD, bf16, p, causal);
+            return f;
         }
+    }
+    f.main = plan_range(HD, bf16, p0, causal);
+    return f;
+}
+
+int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStream_t stream, void* ws, size_t ws_bytes) {
+    const bool have_ws = ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0;
+    const FwdPlan f = plan_fwd(HD, bf16, p0, causal, have_ws, ws_bytes);
+    if (f.split.nsplit > 1) {
+        fa2::FwdParams p = p0;
+        p.rows_hint = 256;
+        p.full_items = f.split.full_items; p.split_items = f.split.split_items; p.nsplit = f.split.nsplit;
+        p.ws = (float*)ws;
+        int rc;
+        if (f.split_asm) {
+            // the hand-scheduled persistent kernel: every workgroup works through its whole items, then its parts (the item seam hides a
+            // part's load phase like any other item's; the block stores a part's f32 tile itself)
+            p.item_cap = f.split.full_items + f.split.split_items * f.split.nsplit;
+            rc = fa2::launch_fwd_asm(HD, bf16, p, false, f.main.fold, stream);
+        } else {
+            rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
+        }
+        if (rc) return rc;
+        return bf16 ? fa2::launch_fwd_combine_bf16(HD, p, stream) : fa2::launch_fwd_combine_f16(HD, p, stream);
+    }
+    if (f.main_heads < p0.nbh) {
+        fa2::FwdParams p = p0;
+        p.nbh = f.main_heads;
+        if (int rc = launch_range(HD, bf16, p, causal, stream)) return rc;
+        p.bh0 = p0.bh0 + f.main_heads;
+        p.nbh = p0.nbh - f.main_heads;
+        p.rows_hint = 128;
+        return launch_range(HD, bf16, p, causal, stream);
     }
     return launch_range(HD, bf16, p0, causal, stream);
 }
@@ -257,7 +316,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile) {
 
 int fa2_fwd_prescales_q(int D, float scale) {
     if (fa2_padded_head_dim(D) < 0) return -1;
-    return (D == 64 || D == 128) && scale > 0.f ? 1 : 0;      // the fp16 launches that take the hand-scheduled bodies (launch_range)
+    // the fp16 launches that take the hand-scheduled bodies MAY fold (plan_range; fa2_fwd_plan says what one call does)
+    return (D == 64 || D == 128) && scale > 0.f && scale * 1.4426950408889634f <= 1.0f && fa2::options().fold.load(std::memory_order_relaxed) >= 1 ? 1 : 0;
 }
 
 int fa2_set_option(const char* name, int value) {
@@ -267,8 +327,10 @@ int fa2_set_option(const char* name, int value) {
     else if (!std::strcmp(name, "asm")) o.asm_mask = value;
     else if (!std::strcmp(name, "persist")) o.persist = value != 0;
     else if (!std::strcmp(name, "split")) o.split = value != 0;
+    else if (!std::strcmp(name, "fold")) { if (value < 0 || value > 2) return FA2_ERR_BAD_SHAPE; o.fold = value; }
     else if (!std::strcmp(name, "bwd_parts")) { if (value < 1 || value > 3) return FA2_ERR_BAD_SHAPE; o.bwd_parts = value; }
     else return FA2_ERR_BAD_SHAPE;
+    o.epoch.fetch_add(1, std::memory_order_relaxed);
     return FA2_OK;
 }
 
@@ -279,6 +341,8 @@ int fa2_get_option(const char* name) {
     if (!std::strcmp(name, "asm")) return o.asm_mask.load();
     if (!std::strcmp(name, "persist")) return o.persist.load();
     if (!std::strcmp(name, "split")) return o.split.load();
+    if (!std::strcmp(name, "fold")) return o.fold.load();
+    if (!std::strcmp(name, "epoch")) return o.epoch.load() & 0x3fffffff;
     if (!std::strcmp(name, "bwd_parts")) return o.bwd_parts.load();
     return FA2_ERR_BAD_SHAPE;
 }
@@ -306,12 +370,15 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
                     int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
                     const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
                     float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
-                    void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr) {
+                    void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr, fa2_fwd_plan_t* plan_out = nullptr) {
+    // ws_need / plan_out: validate and plan only (fa2_fwd_workspace_bytes, fa2_fwd_plan) — the data pointers are stand-ins then
+    const bool plan_only = ws_need || plan_out;
     if (ws_need) *ws_need = 0;
     if (!q || !k || !v || !o || !lse || !q_strides || !k_strides || !v_strides || !o_strides || !lse_strides)
         return FA2_ERR_NULL_POINTER;
     if (bias_kind != FA2_BIAS_NONE) {
         if (bias_kind != FA2_BIAS_IO_DTYPE && bias_kind != FA2_BIAS_F32 && bias_kind != FA2_BIAS_BOOL) return FA2_ERR_BIAS;
+        if (plan_only) { static const int64_t z3[3] = {0, 0, 0}; if (!bias) bias = q; if (!bias_strides) bias_strides = z3; }
         if (!bias || !bias_strides) return FA2_ERR_NULL_POINTER;
         if (bias_strides[0] < 0 || bias_strides[1] < 0 || bias_strides[2] < 0) return FA2_ERR_BIAS;
         const uintptr_t esize = bias_kind == FA2_BIAS_F32 ? 4 : bias_kind == FA2_BIAS_IO_DTYPE ? 2 : 1;
@@ -381,14 +448,29 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     const bool bf16 = dtype == FA2_DTYPE_BF16;
     if (bias_kind != FA2_BIAS_NONE) {
         if ((int64_t)B * H * ((Nq + 127) / 128) > 0x7fffffffLL) return FA2_ERR_GRID;
-        if (ws_need) return FA2_OK;
+        if (plan_out) {
+            std::memset(plan_out, 0, sizeof(*plan_out));
+            plan_out->kernel = FA2_KERNEL_HIP_BIAS;
+            plan_out->rows = p.bias_vec == 3 ? 256 : 128;
+            plan_out->heads_main = B * H;
+        }
+        if (plan_only) return FA2_OK;
         return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal != 0, 128, true, stream) : fa2::launch_fwd_hip_f16(HD, p, causal != 0, 128, true, stream);
     }
-    if (ws_need) {      // fa2_fwd_workspace_bytes: validate and plan only
+    if (ws_need) {      // fa2_fwd_workspace_bytes
         const fa2::SplitPlan pl = plan_split(p, HD, dtype == FA2_DTYPE_BF16, causal != 0);
         if (pl.nsplit > 1) *ws_need = (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD);
-        return FA2_OK;
     }
+    if (plan_out) {     // fa2_fwd_plan: what launch_fwd would do with a (16-byte aligned) workspace of ws_bytes bytes
+        const FwdPlan f = plan_fwd(HD, bf16, p, causal != 0, ws_bytes > 0, ws_bytes);
+        std::memset(plan_out, 0, sizeof(*plan_out));
+        plan_out->kernel = f.main.kernel; plan_out->contract = f.main.contract; plan_out->rows = f.main.rows;
+        plan_out->heads_main = f.main_heads;
+        plan_out->kernel_tail = f.tail.kernel; plan_out->contract_tail = f.tail.contract; plan_out->rows_tail = f.tail.rows;
+        plan_out->nsplit = f.split.nsplit > 1 ? f.split.nsplit : 0;
+        plan_out->split_items = f.split.nsplit > 1 ? f.split.split_items : 0;
+    }
+    if (plan_only) return FA2_OK;
     return launch_fwd(HD, bf16, p, causal != 0, stream, ws, ws_bytes);
 }
 
@@ -408,16 +490,40 @@ int fa2_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, 
                     scale, causal, nullptr, FA2_BIAS_NONE, nullptr, hip_stream, workspace, workspace_bytes);
 }
 
+// Stand-in arguments of the plan-only calls: contiguous BHND tensors (the plan looks at the row pitches of Q and K: a contiguous tensor's are
+// what the size query must assume — ADVICE r3: stand-in pitches of 8 elements made the query plan for the compiler-scheduled kernels and
+// the launch for the hand-scheduled ones).
+struct ContigStrides {
+    int64_t q[3], k[3], ls[2];
+    ContigStrides(int H, int Nq, int Nkv, int D) {
+        const int64_t d = D > 0 ? D : 8;
+        q[2] = d; q[1] = (int64_t)Nq * d; q[0] = (int64_t)H * q[1];
+        k[2] = d; k[1] = (int64_t)Nkv * d; k[0] = (int64_t)H * k[1];
+        ls[1] = Nq; ls[0] = (int64_t)H * Nq;
+    }
+};
+alignas(16) static char g_plan_dummy[16];
+
 size_t fa2_fwd_workspace_bytes(int dtype, int B, int H, int Nq, int Nkv, int D, int causal) {
-    // the plan depends on the shape and the device's CU count only: run the validation + planning half of the call on stand-in arguments
-    static const int64_t one[3] = {8, 8, 8};
-    alignas(16) static char dummy[16];
+    // the plan depends on the shape, the options and the device's CU count only: run the validation + planning half of the call on stand-in arguments
+    if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return 0;
+    const ContigStrides cs(H, Nq, Nkv, D);
     size_t need = 0;
-    const int64_t ls[2] = {0, 0};
-    if (fwd_impl(dtype, dummy, dummy, dummy, dummy, (float*)dummy, B, H, Nq, Nkv, D, one, one, one, one, ls, 1.0f, causal, nullptr, FA2_BIAS_NONE,
+    char* d = g_plan_dummy;
+    if (fwd_impl(dtype, d, d, d, d, (float*)d, B, H, Nq, Nkv, D, cs.q, cs.k, cs.k, cs.q, cs.ls, (float)(1.0 / std::sqrt((double)D)), causal, nullptr, FA2_BIAS_NONE,
                  nullptr, nullptr, nullptr, 0, &need) != FA2_OK)
         return 0;
     return need;
+}
+
+int fa2_fwd_plan(int dtype, int B, int H, int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],
+                 float scale, int causal, int bias_kind, size_t workspace_bytes, fa2_fwd_plan_t* plan) {
+    if (!plan) return FA2_ERR_NULL_POINTER;
+    if (B < 1 || H < 1 || Nq < 1 || Nkv < 1 || D < 1) return FA2_ERR_BAD_SHAPE;
+    const ContigStrides cs(H, Nq, Nkv, D);
+    char* d = g_plan_dummy;
+    return fwd_impl(dtype, d, d, d, d, (float*)d, B, H, Nq, Nkv, D, q_strides ? q_strides : cs.q, k_strides ? k_strides : cs.k, k_strides ? k_strides : cs.k,
+                    q_strides ? q_strides : cs.q, cs.ls, scale, causal, nullptr, bias_kind, nullptr, nullptr, nullptr, workspace_bytes, nullptr, plan);
 }
 
 int fa2_fwd_bias(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,

@@ -209,7 +209,14 @@ def _launch_fwd(lib, fn, args, dev, device, may_split):
     workspace for this shape (KV-split of the last, partly filled round of workgroups: include/fa2_gfx950.h): scratch memory from
     torch's caching allocator, taken per call — stream-ordered reuse and graph capture are then the allocator's business."""
     if may_split:
-        need = lib.fa2_fwd_workspace_bytes(args[0], *args[6:11], 0)
+        # (the size is a function of dtype, shape, device and the library's options: asked once per shape — _fa2_lib.options() and
+        #  _fa2_lib.set_option() drop the cache; a stale entry would only cost the split, the library re-plans every call itself)
+        key = (args[0], args[6], args[7], args[8], args[9], args[10], dev)
+        need = _WS_CACHE.get(key)
+        if need is None:
+            if len(_WS_CACHE) > 4096:
+                _WS_CACHE.clear()
+            need = _WS_CACHE[key] = lib.fa2_fwd_workspace_bytes(args[0], *args[6:11], 0)
         if need:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
             return lib.fa2_fwd_ws(*args, ws.data_ptr(), need, _raw_stream(dev))
@@ -234,7 +241,9 @@ def _frontend():
 
 
 _STRIDE_CACHE = {}       # (batch, head, row) element strides -> ctypes int64[3] (the arrays are read-only for the library)
-_MAX_HEAD_DIM = 512      # largest forward kernel head dim (fa2_supported_head_dims); the backward kernels stop at 256
+_WS_CACHE = _fa2_lib.WS_CACHE      # (dtype, B, H, Nq, Nkv, D, device) -> fa2_fwd_workspace_bytes
+_MAX_HEAD_DIM = 512      # largest kernel head dim, forward and backward (fa2_supported_head_dims)
+_MAX_MASKED_BWD_HEAD_DIM = 256     # ... of the masked backward (fa2_bwd_bias)
 
 
 def _raw_stream(device_index):
@@ -364,6 +373,14 @@ class _MaskedAttentionFunction(torch.autograd.Function):
     @torch.no_grad()
     def forward(ctx, q, k, v, mask, causal, scale, BNHD_fmt):
         D = q.shape[3]
+        # what fa2_bwd_bias would refuse is refused HERE, before the forward's work is done (a training step must not fail inside loss.backward())
+        if D > _MAX_MASKED_BWD_HEAD_DIM:
+            raise RuntimeError("fa2: a masked attention call that needs gradients supports head dims up to %d (got %d): fa2_bwd_bias has no kernel above"
+                               % (_MAX_MASKED_BWD_HEAD_DIM, D))
+        if torch.is_tensor(mask) and mask.dim() >= 2 and mask.shape[-2] > 1:
+            n_ax_ = 1 if BNHD_fmt else 2
+            if (q.shape[n_ax_] + 63) * k.shape[n_ax_] * (4 if mask.dtype == torch.float32 else 1 if mask.dtype == torch.bool else 2) >= 2 ** 31 - 1:
+                raise RuntimeError("fa2: one (batch, head) slice of the attention mask must span < 2 GiB for the masked backward (fa2_bwd_bias)")
         Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67
         o, q_bwd, k_bwd, v_bwd, o_bwd, L = flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)
         n_ax = 1 if BNHD_fmt else 2

@@ -21,7 +21,21 @@ FA2_DTYPE_F16 = 0
 FA2_DTYPE_BF16 = 1
 FA2_BIAS_NONE, FA2_BIAS_IO_DTYPE, FA2_BIAS_F32, FA2_BIAS_BOOL = 0, 1, 2, 3     # bias_kind of fa2_fwd_bias
 
+FA2_KERNEL_HIP_256, FA2_KERNEL_HIP_128, FA2_KERNEL_ASM, FA2_KERNEL_HIP_BIAS = 1, 2, 3, 4              # fa2_fwd_plan_t.kernel
+FA2_CONTRACT_PRESCALE_Q, FA2_CONTRACT_LSUM_P16 = 1, 2                                                   # fa2_fwd_plan_t.contract bits
+
 _i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class FwdPlan(ctypes.Structure):
+    """fa2_fwd_plan_t (include/fa2_gfx950.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in ("kernel", "contract", "rows", "heads_main", "kernel_tail", "contract_tail", "rows_tail",
+                                             "nsplit", "split_items")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _FWD_ARGTYPES = [
     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,  # q k v o lse
     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,                  # B H Nq Nkv D
@@ -53,6 +67,7 @@ SYMBOLS = {
     "fa2_padded_head_dim": (ctypes.c_int, [ctypes.c_int]),
     "fa2_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "fa2_fwd_prescales_q": (ctypes.c_int, [ctypes.c_int, ctypes.c_float]),
+    "fa2_fwd_plan": (ctypes.c_int, [ctypes.c_int] * 6 + [_i64p, _i64p, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(FwdPlan)]),
     "fa2_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "fa2_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "fa2_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -60,6 +75,7 @@ SYMBOLS = {
 }
 
 _lib = None
+WS_CACHE = {}        # FlashAttn.py: shape -> workspace bytes, valid for the current option values (dropped whenever an option is set here)
 
 
 def _build_module():
@@ -102,6 +118,12 @@ def check(code):
         raise RuntimeError("fa2 call failed (%d): %s" % (code, error_string(code)))
 
 
+def set_option(name, value):
+    """fa2_set_option, and forget what was planned under the old value."""
+    check(load().fa2_set_option(name.encode(), int(value)))
+    WS_CACHE.clear()
+
+
 class options:
     """with _fa2_lib.options(rows=256, persist=0): ... — set tuning switches of the library (fa2_set_option) and restore
     them on exit.  Process-wide: for A/B measurements and tests, not for concurrent use."""
@@ -118,13 +140,26 @@ class options:
                 raise ValueError("fa2: unknown option %r" % k)
             self.saved[k] = old
             check(lib.fa2_set_option(k.encode(), int(v)))
+        WS_CACHE.clear()
         return self
 
     def __exit__(self, *exc):
         lib = load()
         for k, v in self.saved.items():
             lib.fa2_set_option(k.encode(), v)
+        WS_CACHE.clear()
         return False
+
+
+def fwd_plan(q, k, causal, scale=None, bias_kind=FA2_BIAS_NONE, workspace_bytes=0):
+    """fa2_fwd_plan for the call fa2_fwd*(q, k, ...) would be: which kernel(s) serve it and under which numerical contract."""
+    B, H, Nq, D = q.shape
+    dt = FA2_DTYPE_F16 if q.dtype == torch.float16 else FA2_DTYPE_BF16
+    plan = FwdPlan()
+    check(load().fa2_fwd_plan(dt, B, H, Nq, k.shape[2], D, strides3(q.stride(0), q.stride(1), q.stride(2)),
+                              strides3(k.stride(0), k.stride(1), k.stride(2)), float(D ** -0.5 if scale is None else scale),
+                              int(bool(causal)), int(bias_kind), int(workspace_bytes), ctypes.byref(plan)))
+    return plan
 
 
 def strides3(a, b, c):

@@ -88,7 +88,12 @@ def webui_cross_attention_forward(self, x, context=None, mask=None, **kwargs):
     """Replacement for `CrossAttention.forward` of the ldm / sgm attention modules sd-webui runs (the call shape of its
     `sd_hijack_optimizations` functions): projections and output layer are the module's own, the attention in between is the
     gfx950 operator on the zero-copy [B, N, H, D] view.  A call this operator cannot serve (masked with gradients, oversize head
-    dim) goes to torch's scaled_dot_product_attention, as sd-webui's own sdp optimisation does."""
+    dim) goes to torch's scaled_dot_product_attention, as sd-webui's own sdp optimisation does.
+    `mask` is ldm's: a boolean PER-KEY mask [B, ...] (True = attend), flattened to [B, Nkv] and shared by heads and query rows
+    (ldm/modules/attention.py: `rearrange(mask, 'b ... -> b (...)')`, `repeat(mask, 'b j -> (b h) () j')`) — it is handed on as
+    the [B, 1, 1, Nkv] key-padding form the kernels serve with one load per KV tile.
+    Not reproduced: sd-webui's hypernetwork application to `context` and its `upcast_attn` handling (both live in the
+    functions of sd_hijack_optimizations this replaces); a UI with hypernetworks loaded should keep its own optimisation."""
     h = self.heads
     context = x if context is None else context
     q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
@@ -101,6 +106,10 @@ def webui_cross_attention_forward(self, x, context=None, mask=None, **kwargs):
         o = torch.nn.functional.scaled_dot_product_attention(t(q_), t(k_), t(v_), attn_mask=m_)
         return o.transpose(1, 2).reshape(b, q_.shape[1], inner)
 
+    if mask is not None:
+        mask = mask.reshape(mask.shape[0], 1, 1, -1)          # [B, ...] per key -> [B, 1, 1, Nkv]
+        if mask.dtype != torch.bool:
+            mask = mask.to(torch.bool)
     out = attention_bnhd(q, k, v, h, mask=mask, fallback=sdpa)
     return self.to_out(out.to(x.dtype))
 

@@ -253,17 +253,50 @@ int fa2_padded_head_dim(int D);
  * the counterparts of the reference's Br / Bc, FlashAttn.py:56-67). */
 int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
 
-/* Where the softmax scale is applied (numerical contract, informational).
- *   0  every launch of this head dim scales the f32 Q.K^T product, as the reference kernel does (kernel_fp16.cu:164);
- *   1  launches of this head dim MAY fold scale * log2(e) into Q, rounded once to the I/O dtype — the scaling contract of the reference's own
- *      oracle (`scale * q_frags`, pure_torch_ver.py:61) — and feed the reference maximum to the matrix pipe as the C operand of the first
- *      Q.K^T k-step.  Version 0.8: head dims exactly 64 and 128 with a positive scale, where the fp16 launches of 256-row workgroups run the
- *      hand-scheduled bodies (bf16 launches, 128-row workgroups, other head dims and KV sweeps too short for those bodies to pay — under 896 keys,
- *      under 1792 when causal — scale the f32 product).  The fold removes the 64 v_fma per tile of bodies that run at their instruction-issue bound (+9 % at head dim 64,
- *      +1.4 ... +2.9 % at 128); it costs ~2e-4 of log2-LSE accuracy on U[0,1) / N(0,1) inputs, inside every tolerance of the test-suite, and grows
- *      with the logits (~1e-2 in O at logits of several hundred).  The head-dim-64 body also forms its row sums on the matrix pipe, i.e. from
- *      the rounded P the P.V product consumes.
- *  -1  D not supported. */
+/*
+ * Which kernel serves a forward call, and which numerical contract its results follow — exact, per call (the launch code executes the
+ * same plan this function reports; csrc/host.cpp: plan_fwd).
+ *
+ * Contracts.  The reference KERNEL scales the f32 Q.K^T product (`* scale`, kernel_fp16.cu:164; its Q prescale is commented out, :364) and
+ * sums the unrounded f32 P; the reference's own ORACLE scales Q first, in the I/O dtype (`scale * q_frags`, pure_torch_ver.py:61).
+ *   contract == 0                 the reference kernel's: S = (Q K^T) * scale*log2(e) in f32, row sums of the f32 P.  Every compiler-scheduled
+ *                                 kernel, and the hand-scheduled bodies when they do not fold (bf16 by default; scale*log2(e) > 1; option "fold" = 0).
+ *   FA2_CONTRACT_PRESCALE_Q       Q * scale*log2(e) is rounded ONCE to the I/O dtype before Q K^T (the reference oracle's contract) and the running
+ *                                 reference maximum enters the first Q.K^T k-step as its C operand.  Removes the 64 v_fma per tile of bodies that run
+ *                                 at their instruction-issue bound (+9 % at head dim 64, +1.4 ... +2.9 % at 128).  fp16: ~2e-4 of log2 LSE on
+ *                                 U[0,1) / N(0,1) inputs, growing with the logits (~1e-2 in O at logits of several hundred); bf16: ~6e-3.
+ *   FA2_CONTRACT_LSUM_P16         the row sums add the P values ROUNDED to the I/O dtype — the ones the P.V product consumes (the head-dim-64
+ *                                 hand-scheduled body forms them on the matrix pipe).
+ * Kernels.
+ *   FA2_KERNEL_HIP_256 / _128     compiler-scheduled HIP kernel, 8-wave 256-row / 4-wave 128-row workgroups (csrc/fa2_fwd_kernel.hip.h)
+ *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py), head dims exactly 64 and 128
+ *   FA2_KERNEL_HIP_BIAS           the BIAS forms of the HIP kernel (fa2_fwd_bias)
+ * A call is at most two launches: heads [0, heads_main) of the flattened (b * H + h) order run `kernel` under `contract`, the others (head dims
+ * <= 64 whose last round of workgroups is nearly empty: a second launch of 128-row workgroups) run `kernel_tail` under `contract_tail`.
+ * nsplit > 1: with a workspace of `workspace_bytes` the `split_items` items of the last round run as nsplit KV-split parts each (fa2_fwd_ws), inside `kernel`.
+ *   q_strides / k_strides: as in fa2_fwd, or NULL for contiguous [B,H,N,D] tensors (the plan looks at the row pitches of Q and K only);
+ *   bias_kind: FA2_BIAS_NONE for fa2_fwd / fa2_fwd_ws;  workspace_bytes: 0 for fa2_fwd.
+ * Returns FA2_OK or the validation code the call itself would return.  Depends on the arguments, the options and the device's CU count.
+ */
+#define FA2_KERNEL_HIP_256  1
+#define FA2_KERNEL_HIP_128  2
+#define FA2_KERNEL_ASM      3
+#define FA2_KERNEL_HIP_BIAS 4
+#define FA2_CONTRACT_PRESCALE_Q 1
+#define FA2_CONTRACT_LSUM_P16   2
+typedef struct fa2_fwd_plan_t {
+    int kernel, contract, rows;                 /* main launch: FA2_KERNEL_*, FA2_CONTRACT_* bits, Q rows per workgroup */
+    int heads_main;                             /* flattened heads [0, heads_main) belong to it (B*H: the only launch) */
+    int kernel_tail, contract_tail, rows_tail;  /* second launch over the remaining heads (0: none) */
+    int nsplit, split_items;                    /* KV-split of the last round (0: none) */
+} fa2_fwd_plan_t;
+int fa2_fwd_plan(int dtype, int B, int H, int Nq, int Nkv, int D,
+                 const int64_t q_strides[3], const int64_t k_strides[3],
+                 float scale, int causal, int bias_kind, size_t workspace_bytes, fa2_fwd_plan_t* plan);
+
+/* Coarse form of the above (kept for callers of version 0.8): 1 if launches of this head dim MAY fold the scale into Q (head dims exactly 64
+ * and 128, 0 < scale*log2(e) <= 1, option "fold" >= 1: the fp16 launches the hand-scheduled bodies take), 0 if none does, -1: D not supported.
+ * fa2_fwd_plan is the exact, per-call answer. */
 int fa2_fwd_prescales_q(int D, float scale);
 
 /*
@@ -276,10 +309,15 @@ int fa2_fwd_prescales_q(int D, float scale);
  *                              forward body for non-causal launches too (default: causal only); default 3.  0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
  *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws / fa2_bwd_ws may split the last round of workgroups (0: they are fa2_fwd / fa2_bwd)
+   "fold"      FA2_FOLD       1 (default) | 0 | 2 — which launches of the hand-scheduled forward bodies fold scale*log2(e) into Q
+                              (FA2_CONTRACT_PRESCALE_Q above): 0 none — every launch scales the f32 product like the reference kernel
+                              (kernel_fp16.cu:164); 1 fp16 launches; 2 bf16 launches too.  Never when scale*log2(e) > 1 (the prescaled Q could
+                              leave the dtype's range).  This one changes the numerical contract, within the bounds stated there.
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.
  * fa2_set_option returns FA2_OK, or FA2_ERR_BAD_SHAPE for an unknown name / value; fa2_get_option the value (>= 0) or that code.
+ * fa2_get_option("epoch") counts the fa2_set_option calls so far: a caller that caches fa2_fwd_plan / fa2_*_workspace_bytes answers keys them on it.
  * Changing an option while launches are being issued from other threads is safe (atomics) but the switch-over point is not ordered.
  */
 int fa2_set_option(const char* name, int value);

@@ -198,3 +198,86 @@ def test_product_package_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), (dirpath, f)
                 assert "fa2_oracle" not in text and "libfa2_oracle" not in text, (dirpath, f)
+
+
+def _meta_plan(B, H, N, Nkv, D, dt=None, causal=False, scale=None, ws=0, kpad=0):
+    import torch
+    dt = dt or torch.float16
+    q = torch.empty((B, H, N, D), dtype=dt, device="meta")
+    k = torch.empty((B, H, Nkv, D + kpad), dtype=dt, device="meta")[..., :D]
+    return _fa2_lib.fwd_plan(q, k, causal, scale, workspace_bytes=ws)
+
+
+def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config():
+    """fa2_fwd_plan (host logic, no GPU needed: the CU count defaults to 256) pins WHICH kernel serves a call and under WHICH numerical contract —
+    the launch code executes the same plan (csrc/host.cpp: plan_fwd), so a launch that silently fell from the hand-scheduled body to the HIP
+    kernel (or the reverse) changes these answers.  The GPU parity tests compare against the oracle under exactly the contract named here."""
+    import torch
+    K, C = _fa2_lib, _fa2_lib
+    # BASELINE.json configs 2, 3, 4 and config 5's per-rank shard: the hand-scheduled body, one launch; fp16 folds the scale, bf16 does not
+    for shape, dt, causal, contract in (((2, 16, 4096, 4096, 128), torch.float16, False, C.FA2_CONTRACT_PRESCALE_Q),
+                                        ((2, 16, 4096, 4096, 128), torch.bfloat16, True, 0),
+                                        ((1, 32, 8192, 8192, 128), torch.float16, True, C.FA2_CONTRACT_PRESCALE_Q),
+                                        ((8, 16, 4096, 4096, 128), torch.float16, False, C.FA2_CONTRACT_PRESCALE_Q)):
+        p = _meta_plan(*shape, dt=dt, causal=causal)
+        assert (p.kernel, p.contract, p.rows, p.heads_main, p.kernel_tail, p.nsplit) == (K.FA2_KERNEL_ASM, contract, 256, shape[0] * shape[1], 0, 0), p.as_dict()
+    # config 1 (B1 H2 N128 D64): a grid this small runs 128-row workgroups of the HIP kernel, f32 scale
+    p = _meta_plan(1, 2, 128, 128, 64)
+    assert (p.kernel, p.contract, p.rows) == (K.FA2_KERNEL_HIP_128, 0, 128)
+    # head dim 64: fp16 -> the hand-scheduled body (folded scale, row sums of the rounded P); bf16 non-causal -> 8-wave HIP kernel; bf16 causal -> the body, f32 scale
+    p = _meta_plan(2, 16, 4096, 4096, 64)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_PRESCALE_Q | C.FA2_CONTRACT_LSUM_P16)
+    p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
+    p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16, causal=True)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
+    # two launches: 544 workgroups = two full rounds of the body + the last two heads as 128-row workgroups of the HIP kernel
+    p = _meta_plan(2, 17, 4096, 4096, 64)
+    assert (p.heads_main, p.kernel, p.kernel_tail, p.contract_tail, p.rows_tail) == (32, K.FA2_KERNEL_ASM, K.FA2_KERNEL_HIP_128, 0, 128)
+    # what the bodies cannot serve goes to the HIP kernels: other head dims, short KV sweeps, a K row pitch that is not a multiple of a tile row, a negative scale
+    assert _meta_plan(2, 16, 4096, 4096, 96).kernel == K.FA2_KERNEL_HIP_256
+    assert _meta_plan(2, 16, 4096, 77, 128).kernel == K.FA2_KERNEL_HIP_256
+    assert _meta_plan(2, 16, 2048, 2048, 128, kpad=8).kernel == K.FA2_KERNEL_HIP_256
+    assert _meta_plan(2, 16, 4096, 4096, 128, scale=-0.1).kernel == K.FA2_KERNEL_HIP_256
+    # the fold needs scale * log2(e) <= 1 (the prescaled Q must stay inside fp16's range): a larger scale runs the f32-scale body of the same schedule
+    p = _meta_plan(2, 16, 4096, 4096, 128, scale=0.8)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, 0)
+    p = _meta_plan(2, 16, 4096, 4096, 64, scale=0.8)           # head dim 64 without the fold: the 8-wave kernel non-causal (plan_range)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
+    # the KV-split of a partly filled last round needs the caller's workspace (fa2_fwd_ws); whole items and parts share one kernel and one contract
+    lib = _fa2_lib.load(build_if_missing=False)
+    need = lib.fa2_fwd_workspace_bytes(_fa2_lib.FA2_DTYPE_F16, 2, 10, 4096, 4096, 64, 0)
+    assert need > 0
+    p = _meta_plan(2, 10, 4096, 4096, 64, ws=need)
+    assert (p.nsplit, p.split_items, p.kernel, p.kernel_tail) == (4, 64, K.FA2_KERNEL_ASM, 0)
+    assert _meta_plan(2, 10, 4096, 4096, 64, ws=need - 1).nsplit == 0 and _meta_plan(2, 10, 4096, 4096, 64).nsplit == 0
+    # a masked call: the BIAS kernels
+    q = torch.empty((2, 10, 1024, 64), dtype=torch.float16, device="meta")
+    assert _fa2_lib.fwd_plan(q, q, False, bias_kind=_fa2_lib.FA2_BIAS_BOOL).kernel == K.FA2_KERNEL_HIP_BIAS
+    # validation is the call's own
+    bad = _fa2_lib.FwdPlan()
+    import ctypes
+    assert lib.fa2_fwd_plan(0, 1, 1, 16, 16, 12, None, None, 0.1, 0, 0, 0, ctypes.byref(bad)) == -3      # FA2_ERR_HEAD_DIM
+    assert lib.fa2_fwd_plan(0, 1, 1, 16, 16, 64, None, None, 0.1, 0, 0, 0, None) == -1                   # FA2_ERR_NULL_POINTER
+
+
+def test_option_fold_switches_the_contract_and_nothing_else():
+    """Option "fold": 0 = every launch scales the f32 product like the reference kernel (kernel_fp16.cu:164), 1 (default) = fp16 launches of the
+    hand-scheduled bodies fold the scale into Q, 2 = bf16 launches too.  Setting any option bumps the "epoch" cached plans are keyed on."""
+    import torch
+    lib = _fa2_lib.load(build_if_missing=False)
+    assert lib.fa2_get_option(b"fold") == 1
+    e0 = lib.fa2_get_option(b"epoch")
+    with _fa2_lib.options(fold=0):
+        assert lib.fa2_get_option(b"epoch") > e0
+        p = _meta_plan(2, 16, 4096, 4096, 128)
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, 0)
+        p = _meta_plan(2, 16, 4096, 4096, 64)                  # head dim 64 fp16 without the fold: back on the 8-wave kernel (non-causal)
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_HIP_256, 0)
+        assert lib.fa2_fwd_prescales_q(128, 0.1) == 0
+    with _fa2_lib.options(fold=2):
+        p = _meta_plan(2, 16, 4096, 4096, 128, dt=torch.bfloat16, causal=True)
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, _fa2_lib.FA2_CONTRACT_PRESCALE_Q)
+    assert lib.fa2_get_option(b"fold") == 1 and lib.fa2_set_option(b"fold", 3) < 0
+    p = _meta_plan(2, 16, 4096, 4096, 128)
+    assert p.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q

@@ -48,44 +48,61 @@ def _cabi_forward(q, k, v, causal, scale=None):
     return o, lse
 
 
-def _oracle_flags(D, scale=None):
-    """PRESCALE_Q if launches of this head dim may fold the scale into Q (fa2_fwd_prescales_q: head dim 64 with a positive scale — the fp16
-    launches that take the hand-scheduled body do), else 0."""
-    lib = _fa2_lib.load(build_if_missing=False)
-    pre = lib.fa2_fwd_prescales_q(D, float(D ** -0.5 if scale is None else scale))
-    assert pre in (0, 1)
-    return fo.PRESCALE_Q if pre else 0
+def _plan(q, k, causal, scale=None, workspace_bytes=0):
+    """fa2_fwd_plan of the call fa2_fwd*(q, k, v, causal, scale): the kernel(s) that serve it and their numerical contract."""
+    return _fa2_lib.fwd_plan(q, k, causal, scale, workspace_bytes=workspace_bytes)
 
 
-def _assert_close_to_oracle(o, lse, q, k, v, dt, causal, scale=None):
-    """Against the oracle run under the contract of the kernel that served the call.  Head dims other than 64 have one contract (scale applied to
-    the f32 product, row sums of the unrounded P), head dim 128 has that and, for the fp16 launches of the hand-scheduled body, the folded scale
-    (PRESCALE_Q).  At head dim 64 the library documents three, chosen by the launch geometry and dtype
-    (include/fa2_gfx950.h, fa2_fwd_prescales_q): the 8-wave / 128-row HIP kernels (the contract above); the hand-scheduled body (causal launches,
-    every fp16 launch of 256-row workgroups), whose row sums ride the matrix pipe, i.e. add the ROUNDED P (FA2_ORACLE_LSUM_P16); and, in fp16,
-    that body with the scale folded into Q (PRESCALE_Q: Q * scale*log2e rounded once, the reference oracle's own contract, pure_torch_ver.py:61).
-    The result must match ONE of them within the usual tolerance (bf16 row sums of rounded P: 4e-3 — the kernel rounds P against its deferred
-    reference maximum, the oracle against the running one: 2^-9 relative noise per term, a row with one to three visible keys shows all of it)."""
-    D = q.shape[-1]
-    contracts = [(0, LSE_TOL)]
-    if D == 64:
-        contracts.append((fo.LSUM_P16, LSE_TOL if dt == 0 else 4e-3))
-        if dt == 0 and _oracle_flags(D, scale):
-            contracts.append((fo.PRESCALE_Q | fo.LSUM_P16, LSE_TOL))
-    elif dt == 0 and _oracle_flags(D, scale):        # head dim 128, fp16: the hand-scheduled body folds the scale too (f32 row sums)
-        contracts.append((fo.PRESCALE_Q, LSE_TOL))
+def _oracle_flags_of(contract):
+    """FA2_CONTRACT_* bits (include/fa2_gfx950.h) -> the oracle's flags for the same contract."""
+    return (fo.PRESCALE_Q if contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q else 0) | (fo.LSUM_P16 if contract & _fa2_lib.FA2_CONTRACT_LSUM_P16 else 0)
+
+
+def _oracle_flags(q, k, causal, scale=None):
+    """Oracle flags of the (single-launch) call fa2_fwd*(q, k, ...)."""
+    pl = _plan(q, k, causal, scale)
+    assert pl.heads_main == q.shape[0] * q.shape[1], "two launches: ask _plan() per head range"
+    return _oracle_flags_of(pl.contract)
+
+
+def _assert_close_to_oracle(o, lse, q, k, v, dt, causal, scale=None, plan=None, head=None):
+    """Against the oracle run under THE contract of the kernel that served the call, as fa2_fwd_plan names it (one contract per launch;
+    a call of two launches — head dims <= 64 with a nearly empty last round — is checked per head range).
+      plan   the plan of the call that produced o (default: the plan of fa2_fwd*(q, k, v, causal, scale) itself — right whenever the
+             tensors handed in ARE the call's tensors and no workspace was involved);
+      head   o, lse, q, k, v are the [1, 1, ...] slice of flattened head `head` of that call.
+    Tolerances: conftest (bf16 row sums of rounded P — LSUM_P16: 4e-3 of LSE; the kernel rounds P against its deferred reference maximum, the
+    oracle against the running one: 2^-9 relative noise per term, a row with one to three visible keys shows all of it)."""
+    B, H = q.shape[0], q.shape[1]
+    if plan is None:
+        assert head is None
+        plan = _plan(q, k, causal, scale)
     got = o.float().cpu().numpy()
     assert np.isfinite(got).all()
-    worst = []
-    for flags, lse_tol in contracts:
-        o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), dt, causal, scale=scale, flags=flags)
+    lse_np = lse.cpu().numpy()
+    if head is not None:
+        assert B == 1 and H == 1
+        ranges = [(0, 1, plan.contract if head < plan.heads_main else plan.contract_tail)]
+    else:
+        assert plan.heads_main <= B * H
+        ranges = [(0, plan.heads_main, plan.contract)]
+        if plan.heads_main < B * H:
+            ranges.append((plan.heads_main, B * H, plan.contract_tail))
+    qb, kb, vb = (_bits(t).reshape((1, B * H) + tuple(t.shape[2:])) for t in (q, k, v))
+    got = got.reshape((1, B * H) + got.shape[2:])
+    lse_np = lse_np.reshape((1, B * H) + lse_np.shape[2:])
+    for lo, hi, contract in ranges:
+        flags = _oracle_flags_of(contract)
+        lse_tol = 4e-3 if (dt == 1 and flags & fo.LSUM_P16) else LSE_TOL
+        o_ref_bits, lse_ref = fo.fwd_c(np.ascontiguousarray(qb[:, lo:hi]), np.ascontiguousarray(kb[:, lo:hi]), np.ascontiguousarray(vb[:, lo:hi]),
+                                       dt, causal, scale=scale, flags=flags)
         o_ref = fo.bits_to_f32(o_ref_bits, dt)
-        bad = np.abs(got - o_ref) > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
-        lse_err = np.abs(lse.cpu().numpy() - lse_ref).max()
-        if not bad.any() and lse_err <= lse_tol:
-            return
-        worst.append((flags, float(np.abs(got - o_ref).max()), float(lse_err)))
-    raise AssertionError("no documented contract matches: (oracle flags, max |O diff|, max |LSE diff|) = %s" % worst)
+        diff = np.abs(got[:, lo:hi] - o_ref)
+        bad = diff > ATOL[dt] + RTOL[dt] * np.abs(o_ref)
+        lse_err = np.abs(lse_np[:, lo:hi] - lse_ref).max()
+        assert not bad.any() and lse_err <= lse_tol, \
+            "heads [%d, %d) under contract %d (kernel %d / %d): max |O diff| %.3g, max |LSE diff| %.3g (tol %.3g)" % (
+                lo, hi, contract, plan.kernel, plan.kernel_tail, float(diff.max()), float(lse_err), lse_tol)
 
 
 # ---------------------------------------------------------------- golden fixtures
@@ -149,7 +166,9 @@ def test_explicit_and_negative_scale():
     g = torch.Generator(device="cpu").manual_seed(3)
     q, k, v = (torch.randn((1, 2, 200, 64), generator=g).half().to(_dev()) for _ in range(3))
     lib = _fa2_lib.load(build_if_missing=False)
-    assert lib.fa2_fwd_prescales_q(64, 1.5) == 1 and lib.fa2_fwd_prescales_q(128, 1.5) == 1 and lib.fa2_fwd_prescales_q(64, -1.0) == 0 and lib.fa2_fwd_prescales_q(256, 1.5) == 0
+    # the coarse query: MAY fold at head dims 64 / 128 while 0 < scale * log2(e) <= 1 (the prescaled Q stays inside fp16's range)
+    assert lib.fa2_fwd_prescales_q(64, 0.5) == 1 and lib.fa2_fwd_prescales_q(128, 0.5) == 1 and lib.fa2_fwd_prescales_q(64, 1.5) == 0
+    assert lib.fa2_fwd_prescales_q(64, -1.0) == 0 and lib.fa2_fwd_prescales_q(256, 0.5) == 0
     for scale in (0.3, -0.2, 1.5, -2.0):
         for causal in (False, True):
             o, lse = _cabi_forward(q, k, v, causal, scale=scale)
@@ -239,10 +258,18 @@ def test_large_logits_and_forced_rescale(D):
     assert np.isfinite(got).all()
     # folded-scale build (opt-in): Q * scale*log2e is rounded to 16 bits, which on logits of several hundred is ~1e-2 in O and
     # ~0.1 in the log2 LSE against the float64 truth (measured 1.3e-2); the same-contract oracle below stays at the usual tolerance
-    folded = _oracle_flags(D) != 0
+    folded = _oracle_flags(q, k, False) & fo.PRESCALE_Q
     assert np.all(np.abs(got - o_true) <= (3e-2 if folded else 2e-3) + 4e-3 * np.abs(o_true))
     assert np.abs(lse.cpu().numpy() - lse_true).max() <= (0.3 if folded else 2e-2)
     _assert_close_to_oracle(o, lse, q, k, v, 0, False)
+    # option "fold" = 0: every launch scales the f32 product like the reference kernel (kernel_fp16.cu:164) — the tight truth bounds hold
+    with _fa2_lib.options(fold=0):
+        assert _oracle_flags(q, k, False) & fo.PRESCALE_Q == 0
+        o, lse = _cabi_forward(q, k, v, False)
+        got = o.float().cpu().numpy()
+        assert np.all(np.abs(got - o_true) <= 2e-3 + 4e-3 * np.abs(o_true))
+        assert np.abs(lse.cpu().numpy() - lse_true).max() <= 2e-2
+        _assert_close_to_oracle(o, lse, q, k, v, 0, False)
 
 
 # ---------------------------------------------------------------- operator contract (reference quirks)
@@ -262,7 +289,7 @@ def test_return_contract_shapes_without_padding_copies():
     assert q_pad.data_ptr() == q.data_ptr() and k_pad.data_ptr() == k.data_ptr() and v_pad.data_ptr() == v.data_ptr()
     assert O_fwd.data_ptr() == O.data_ptr() and L.dtype == torch.float32 and L.device == q.device
     assert float(O[:, :, 100:].abs().max()) == 0.0 and float(L[:, :, 100:].abs().max()) == 0.0
-    o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), 0, False, flags=_oracle_flags(40))
+    o_ref_bits, lse_ref = fo.fwd_c(_bits(q), _bits(k), _bits(v), 0, False, flags=_oracle_flags(q, k, False, 40 ** -0.5))
     assert np.all(np.abs(O_fwd.float().cpu().numpy() - fo.bits_to_f32(o_ref_bits, 0)) <= 2e-3)
     assert np.abs(L[:, :, :100].cpu().numpy() - lse_ref).max() <= LSE_TOL
     # a head dim that is not a multiple of 8 is the one case that is still zero-padded (to the next multiple of 8)
@@ -271,7 +298,7 @@ def test_return_contract_shapes_without_padding_copies():
     torch.cuda.synchronize()
     assert O_fwd.shape == q5.shape and O.shape == (2, 3, 128, 40) and q_pad.shape == (2, 3, 100, 40) and k_pad.shape == (2, 3, 77, 40)
     assert O_fwd.data_ptr() == O.data_ptr()
-    o_ref_bits, lse_ref = fo.fwd_c(_bits(q5), _bits(k5), _bits(v5), 0, True, flags=_oracle_flags(37))
+    o_ref_bits, lse_ref = fo.fwd_c(_bits(q5), _bits(k5), _bits(v5), 0, True, flags=_oracle_flags(q_pad, k_pad, True, 37 ** -0.5))
     assert np.all(np.abs(O_fwd.float().cpu().numpy() - fo.bits_to_f32(o_ref_bits, 0)) <= 2e-3)
     assert np.abs(L[:, :, :100].cpu().numpy() - lse_ref).max() <= LSE_TOL
 
@@ -472,10 +499,13 @@ def test_full_size_config_properties(name):
     q, k, v = (torch.rand((B, H, N, D), generator=g, device=_dev(), dtype=torch.float32).to(TORCH_DT[dt]) for _ in range(3))
     o, lse = _cabi_forward(q, k, v, causal)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    # the BASELINE configurations run the hand-scheduled body (fp16: folded scale; bf16: f32 scale), one launch
+    plan = _plan(q, k, causal)
+    assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.heads_main == B * H and plan.contract == (_fa2_lib.FA2_CONTRACT_PRESCALE_Q if dt == 0 else 0)
     # sampled heads against the oracle (first, last, one in the middle)
     for (b, h) in {(0, 0), (B - 1, H - 1), (B // 2, H // 3)}:
         sl = (slice(b, b + 1), slice(h, h + 1))
-        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal)
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal, plan=plan, head=b * H + h)
     # (a) head slice recomputed alone: bit-identical as long as the library picks the same kernel shape for the slice
     #     (it switches to 128-row workgroups when B*H*ceil(Nq/256) <= 96: 8 heads keep this slice above that)
     o_h, lse_h = _cabi_forward(q[:, 3:11].contiguous(), k[:, 3:11].contiguous(), v[:, 3:11].contiguous(), causal)
@@ -587,6 +617,28 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
         assert rec["collectives"]["backend"] == "gloo" and rec["collectives"]["scatter_qkv_ms"] > 0     # host-staged edge transfers ran (and were verified)
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` with NO torch.distributed.run around it (the command shape the driver records): bench.py
+    re-executes itself under the launcher on a free loopback port, the two ranks (both on cuda:0 over gloo here — NCCL refuses two
+    ranks on one device) run the c2 shard each and rank 0 prints the one JSON line with n_gpus = 2 and the ranks the group saw."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2",
+           "--backend", "gloo", "--same-device", "--steady-launches", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak"
+    assert rec["dist"]["world_size"] == 2 and sorted(r["rank"] for r in rec["dist"]["ranks"]) == [0, 1]
+
+
 def test_bench_runs_the_rccl_path_with_one_rank():
     """`bench.py --force-dist --collectives` on the one GPU of this box: init_process_group("nccl", device_id=...), the device
     barriers, the MAX all-reduce of the timings and scatter_batch / gather_batch on DEVICE tensors all go through RCCL with a
@@ -622,9 +674,13 @@ def test_tail_split_launches_cover_every_head(shape):
     q, k, v = (torch.randn((B, H, N, D), generator=g).half().to(_dev()) for _ in range(3))
     o, lse = _cabi_forward(q, k, v, False)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    plan = _plan(q, k, False)
+    if shape == (2, 17, 4096, 64):          # 544 workgroups: two full rounds of the hand-scheduled body + the last 2 heads as 128-row workgroups
+        assert plan.heads_main == 32 and plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.kernel_tail == _fa2_lib.FA2_KERNEL_HIP_128
+        assert plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16 and plan.contract_tail == 0
     for (b, h) in {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2)}:
         sl = (slice(b, b + 1), slice(h, h + 1))
-        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False)
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False, plan=plan, head=b * H + h)
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (D ** -0.5)
     truth = torch.matmul(torch.softmax(s, -1), v.float())
     assert float((o.float() - truth).abs().max()) <= FLOOR[0] * 2
@@ -776,6 +832,8 @@ def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
     lib = _fa2_lib.load(build_if_missing=False)
     assert lib.fa2_fwd_prescales_q(64, 0.125) == 1
     B, H, N, D = 2, 16, 2048, 64                         # 256 workgroups of 256 rows: the hand-scheduled body
+    pl = _fa2_lib.fwd_plan(torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), False)
+    assert pl.kernel == _fa2_lib.FA2_KERNEL_ASM and pl.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16
     for amp, o_tol, lse_tol in ((1.0, 1e-3, 1e-3), (3.0, 3e-2, 0.3)):
         g = torch.Generator(device="cpu").manual_seed(int(amp * 10))
         q = (torch.randn((B, H, N, D), generator=g) * amp).half().to(_dev())
@@ -816,9 +874,12 @@ def test_padded_row_pitch_on_grids_wide_enough_for_the_hand_scheduled_kernels(D,
         assert float((o.float() - truth).abs().max()) <= FLOOR[dt] * 2, pads
         lse = flash_attn_wmma.forward(q, k, v, 64, 128, False, D ** -0.5, False)[5]
         assert float((lse - torch.logsumexp(s, -1) * fo.LOG2E).abs().max()) <= LSE_TRUTH_TOL[dt], pads
+        plan = _plan(q, k, False)
+        if pads[1]:                          # a padded K pitch: never the hand-scheduled body (asm_pitch_ok)
+            assert plan.kernel == _fa2_lib.FA2_KERNEL_HIP_256 and plan.contract == 0
         for (b, h) in ((0, 0), (1, 15)):
             sl = (slice(b, b + 1), slice(h, h + 1))
-            _assert_close_to_oracle(o[sl].detach(), lse[sl], q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dt, False)
+            _assert_close_to_oracle(o[sl].detach(), lse[sl], q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dt, False, plan=plan, head=b * H + h)
             qd, kd, vd = (t[sl].double().requires_grad_(True) for t in (q, k, v))
             torch.nn.functional.scaled_dot_product_attention(qd, kd, vd).backward(do[sl].double())
             for name, got, want in (("dq", qa.grad, qd.grad), ("dk", ka.grad, kd.grad), ("dv", va.grad, vd.grad)):

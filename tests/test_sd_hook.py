@@ -149,7 +149,10 @@ def test_install_webui_patches_cross_attention(hook, monkeypatch):
             self.to_out = torch.nn.Sequential(torch.nn.Linear(heads * dim_head, dim), torch.nn.Dropout(0.0))
 
         def forward(self, x, context=None, mask=None):
+            # ldm's own mask semantics (ldm/modules/attention.py): a boolean PER-KEY mask [B, ...] -> [B, Nkv], shared by heads and query rows
             context = x if context is None else context
+            if mask is not None:
+                mask = mask.reshape(mask.shape[0], 1, 1, -1)
             return self.to_out(_sdpa_flat(self.to_q(x), self.to_k(context), self.to_v(context), self.heads, mask))
 
     for name in ("ldm", "ldm.modules", "ldm.modules.attention"):
@@ -159,15 +162,25 @@ def test_install_webui_patches_cross_attention(hook, monkeypatch):
     torch.manual_seed(3)
     layer, self_layer = CrossAttention(40, 24, 4, 8), CrossAttention(40, 40, 4, 8)
     x, ctx = torch.randn(2, 30, 40), torch.randn(2, 11, 24)
-    want_self, want_cross = self_layer(x), layer(x, ctx)
+    key_mask = torch.ones(2, 11, dtype=torch.bool)
+    key_mask[0, -3:] = False                                 # padded prompt tokens of batch 0
+    want_self, want_cross, want_masked = self_layer(x), layer(x, ctx), layer(x, ctx, mask=key_mask)
     originals = hook.install_webui()
     assert list(originals) == ["ldm.modules.attention"]
     try:
         assert torch.allclose(self_layer(x), want_self, atol=1e-5) and torch.allclose(layer(x, context=ctx), want_cross, atol=1e-5)
         assert _FakeFn.calls == ["apply", "apply"]
-        xg = x.clone().requires_grad_(True)              # masked + gradient: the kernels (head dim 8)
-        layer(xg, context=ctx, mask=torch.ones(2, 30, 11, dtype=torch.bool)).sum().backward()
+        xg = x.clone().requires_grad_(True)              # masked + gradient: the kernels (head dim 8), with ldm's [B, Nkv] mask as [B, 1, 1, Nkv]
+        got = layer(xg, context=ctx, mask=key_mask)
+        assert torch.allclose(got, want_masked, atol=1e-5) and not torch.allclose(got, want_cross, atol=1e-3)
+        got.sum().backward()
         assert xg.grad is not None and _FakeFn.calls == ["apply", "apply", "masked"]
+        # B == Nq must not turn the per-key mask into a query-by-key one: [B, Nkv] = [2, 11] with Nq = 2
+        x2 = torch.randn(2, 2, 40)
+        CrossAttention.forward, patched = originals["ldm.modules.attention"], CrossAttention.forward
+        want2 = layer(x2, ctx, mask=key_mask)
+        CrossAttention.forward = patched
+        assert torch.allclose(layer(x2, context=ctx, mask=key_mask), want2, atol=1e-5)
     finally:
         CrossAttention.forward = originals["ldm.modules.attention"]
 

@@ -67,3 +67,38 @@ def test_two_rank_scatter_compute_gather(B):
     results = mgr.dict()
     mp.spawn(_worker, args=(world, port, B, results), nprocs=world, join=True)
     assert dict(results) == {0: "ok", 1: "ok"}
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_becomes_its_own_launcher(monkeypatch, capsys):
+    """bench.py --gpus N without a launcher: (a) asks for N visible GPUs (none here -> a clear refusal, not a hang); (b) with
+    --same-device it replaces itself by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>` (os.execv intercepted here)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    if torch.cuda.device_count() < 8:
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"])
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert "only" in str(e.value) and "--gpus 8" in str(e.value)
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert a[a.index("--nproc-per-node") + 1] == "2" and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(a[a.index("--master-port") + 1]) <= 65535
+    i = a.index(os.path.join(root, "bench.py"))
+    assert a[i + 1:] == ["--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"]

@@ -284,3 +284,40 @@ def test_backward_with_a_negative_scale_on_ragged_and_causal_shapes(D, dt):
             assert np.isfinite(got).all(), (name, N, Nkv, causal)
             assert np.abs(got - g_true).max() <= GRAD_TOL[dt] * max(1.0, np.abs(g_true).max()), (name, N, Nkv, causal, np.abs(got - g_true).max())
         _check_vs_oracle(q, k, v, do, o, lse, grads, dt, causal, scale=scale)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_reference_precision_shape_backward(causal):
+    """precision_test.py:34-39, :63, :72-98 of the reference: (B, H, N, D) = (3, 7, 1537, 111), Nkv = 1234, bf16, inputs * 1.2, through
+    FlashAttentionFunction.apply(q, k, v, None, causal, None, False) and autograd with the reference's upstream gradient — ones, column 0 set
+    to -2 — and its three comparisons: dQ, dK, dV.  (D = 111 is zero-padded to 112 by the operator, the one kind of head dim that is; the
+    reference prints max differences and asserts nothing: the bounds here are the suite's.)  Checked against the C oracle's backward on sampled
+    heads (whole tensor: 21 heads x 1.9 M scores would take the oracle minutes) and against float64 autograd on the whole tensor."""
+    dt = 1
+    g = torch.Generator(device="cpu").manual_seed(32)
+    q = (torch.rand((3, 7, 1537, 111), generator=g) * 1.2).bfloat16().to(_dev())
+    k = (torch.rand((3, 7, 1234, 111), generator=g) * 1.2).bfloat16().to(_dev())
+    v = (torch.rand((3, 7, 1234, 111), generator=g) * 1.2).bfloat16().to(_dev())
+    do = torch.ones_like(q)
+    do[..., 0] = -2                                                    # precision_test.py:72-74
+    qa, ka, va = (t.detach().requires_grad_(True) for t in (q, k, v))
+    o = FlashAttentionFunction.apply(qa, ka, va, None, causal, None, False)
+    o.backward(do)
+    torch.cuda.synchronize()
+    assert o.shape == q.shape and all(t.grad.shape == t.shape and t.grad.dtype == t.dtype for t in (qa, ka, va))
+    # float64 autograd, whole tensor, on the device
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.matmul(qd, kd.transpose(-1, -2)) * (111 ** -0.5)
+    if causal:
+        s = s.masked_fill(torch.ones(1537, 1234, dtype=torch.bool, device=_dev()).triu(1), float("-inf"))
+    torch.matmul(torch.softmax(s, -1), vd).backward(do.double())
+    for name, got, want in (("dq", qa.grad, qd.grad), ("dk", ka.grad, kd.grad), ("dv", va.grad, vd.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        err = float((got.double() - want).abs().max())
+        assert err <= GRAD_TOL[dt] * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
+    # the C oracle's backward (the reference's recurrences, kernel_fp16.cu:547-740) on sampled heads, fed the kernel's own O and LSE of those heads
+    ret = flash_attn_wmma.forward(q, k, v, 64, 128, causal, 111 ** -0.5, False)
+    lse = ret[5][:, :, :1537]
+    for (b, h) in ((0, 0), (2, 6), (1, 3)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _check_vs_oracle(q[sl], k[sl], v[sl], do[sl], o[sl].detach(), lse[sl], [t.grad[sl] for t in (qa, ka, va)], dt, causal, scale=111 ** -0.5)

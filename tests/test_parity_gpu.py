@@ -175,6 +175,47 @@ def test_explicit_and_negative_scale():
             _assert_close_to_oracle(o, lse, q, k, v, 0, causal, scale=scale)
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_large_scale_and_large_q_stay_finite_on_the_hand_scheduled_grid(D):
+    """scale * log2(e) > 1 with |Q| near the top of fp16's range: a body that folded the scale into Q would round q * c to inf; the plan
+    keeps the f32-scale body of the same schedule for such a scale (host.cpp: asm_folds) and the reference kernel's arithmetic (scale applied to
+    the f32 product, kernel_fp16.cu:164) stays finite.  On a grid wide enough for the hand-scheduled kernel; K is tiny so the logits stay moderate."""
+    B, H, N = 2, 16, 2048
+    g = torch.Generator(device="cpu").manual_seed(91 + D)
+    q = (torch.randn((B, H, N, D), generator=g) * 12000).clamp(-60000, 60000).half().to(_dev())
+    k = (torch.randn((B, H, N, D), generator=g) * 2e-5).half().to(_dev())
+    v = torch.randn((B, H, N, D), generator=g).half().to(_dev())
+    for scale in (1.0, 2.5):
+        plan = _plan(q, k, False, scale)
+        assert plan.contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q == 0, plan.as_dict()
+        if D == 128:
+            assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM
+        o, lse = _cabi_forward(q, k, v, False, scale=scale)
+        assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+        for (b, h) in ((0, 0), (1, 15)):
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False, scale=scale, plan=plan, head=b * H + h)
+
+
+def test_option_fold_2_folds_bf16_launches_too():
+    """Option "fold" = 2: bf16 launches of the hand-scheduled bodies round Q * scale*log2(e) once to bf16 (opt-in: an 8-bit mantissa costs ~6e-3 of
+    log2 LSE against float64) — config 3's shape, against the oracle under THAT contract at the usual tolerance, and back to the f32-scale body after."""
+    B, H, N, D = 2, 16, 4096, 128
+    g = torch.Generator(device=_dev()).manual_seed(55)
+    q, k, v = (torch.rand((B, H, N, D), generator=g, device=_dev(), dtype=torch.float32).bfloat16() for _ in range(3))
+    o0, lse0 = _cabi_forward(q, k, v, True)
+    with _fa2_lib.options(fold=2):
+        plan = _plan(q, k, True)
+        assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+        o, lse = _cabi_forward(q, k, v, True)
+        for (b, h) in ((0, 0), (1, 15)):
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 1, True, plan=plan, head=b * H + h)
+    assert float((lse - lse0).abs().max()) <= 2e-2 and float((o.float() - o0.float()).abs().max()) <= 2 * FLOOR[1]
+    o1, lse1 = _cabi_forward(q, k, v, True)
+    assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
+
+
 def test_scale_zero_is_the_uniform_softmax():
     """scale == 0: every score is 0, O = mean of the visible V rows, LSE = log2(count) — what the reference's
     arithmetic gives (kernel_fp16.cu:449-479 with scale' = 0)."""

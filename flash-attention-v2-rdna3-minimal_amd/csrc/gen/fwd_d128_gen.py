@@ -53,6 +53,9 @@ from isa import A, S, V, Arg, Ins, Label, M0, Neg, OFF, Program, VCC, mk  # noqa
 
 THR = 8.0            # deferred rescale threshold, log2 units (FA2_DEFER_THR of the HIP kernel)
 NEG_INF = float("-inf")
+# "sum check" fast bodies (no row-max stream): a lane's partial row sum of one tile — formed anyway — bounds every P of that lane, so
+# `tile sum <= PSUM_MAX` proves that no P overflows the 16-bit type it is rounded to (fp16: 65504) without looking at the scores
+PSUM_MAX = 32768.0
 
 # ---- inline-asm operands (order = the operand list of the asm statement in fa2_fwd_d128.hip.h)
 A_LSE0, A_LSE1 = Arg(0), Arg(1)                    # "=&v" outputs: log2-domain LSE of this lane's row in q block 0 / 1
@@ -71,6 +74,7 @@ A_EPI = Arg(21)                                    # per-lane LDS byte address o
 # persistent workgroups: the asm statement runs once per (head, q block) item of the workgroup's list; the last two bodies of
 # an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
 A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles; bit 3: this item is a KV-split part
+                                                   # bit 4: safe mode — no fast bodies (the redo of an item whose sum check met a non-finite P: see Gen.rare_sum)
 A_NQO0, A_NQO1 = Arg(23), Arg(24)                  # the next item's Q offsets / head base / K and V descriptors
 A_NQB = Arg(25, "s", 2)
 A_NKRS, A_NVRS = Arg(26, "s", 4), Arg(27, "s", 4)
@@ -104,10 +108,12 @@ FSC = [V(232), V(233)]                             # pending O rescale factor
 MC = [V(234), V(235)]                              # reference max in log2 units (m * c)
 TMP = [V(236 + i) for i in range(8)]               # scratch: row-max chains, rescale block, epilogue
 EP_LT, EP_T, EP_INV = FSC[0], FSC[1], V(244)       # epilogue scratch (the softmax state above is dead by then)
+DSH = [V(245), V(246)]                             # sum-check bodies: pending shift of the next tile's scores (see S_FIX)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
 S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
 S_NOVM, S_PF = S(66), S(67)                          # next item's loads are in flight (do not drain vmcnt) / this item came prefetched
+S_FIX = S(68)                                        # sum-check bodies, folded scale: bit qb = the scores of the NEXT tile of q block qb were formed against the old reference (shift in DSH)
 S_TA, S_TB, S_TC = S(74, 2), S(76, 2), S(78, 2)      # "trace" builds: s_memtime samples (body start, phase boundary, body end)
 S_SUM = [S(80), S(81), S(82), S(83)]                 # cycle sums over the fast bodies: PV phase, QK phase, barrier, bodies
 S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, first main body, epilogue start, block end
@@ -132,7 +138,8 @@ class Geo:
         self.K_SLOT, self.V_BASE = 0, 2 * self.SLOT_B
         self.EPI_ROWB = self.ROWB + 16      # bytes per staged O row (padded: conflict-free column writes and row reads)
         self.EPI_BASE = 4 * self.SLOT_B     # the epilogue image sits above the K / V rings: they hold the next item's first tiles by then
-        self.LDS_BYTES = self.EPI_BASE + 4 * 64 * self.EPI_ROWB
+        self.FAIL_OFF = self.EPI_BASE + 4 * 64 * self.EPI_ROWB     # one word: a wave met a non-finite P in a sum-check body -> the shell redoes the item in safe mode
+        self.LDS_BYTES = self.FAIL_OFF + 16
         self.QF0 = 32 * self.NDT            # accumulator file: O[qb][dt] | Q[qb][ks] | K[kvb][ks]
         self.KF0 = self.QF0 + 8 * self.NKS
         self.LA0 = self.KF0 + 8 * self.NKS  # "lmfma": the row sums as two more accumulator tiles (row 0 of each)
@@ -200,6 +207,10 @@ class Gen:
     DEFAULTS = {"m": (2.0, 10.0), "e": (10.0, 64.0), "vread": (33.0, 40.0), "kread": (0.0, 16.0), "dma": (10.0, 28.0),
                 "mmask": (2.0, 24.0), "abl": (), "opt": (), "trace": (0.0, 0.0), "syn": (), "stagger": (0.0, 0.0),
                 "kread_ct": (16.0, 32.0),   # "ct" kernels: gap window of the K reads of k-steps 0..3 (4..7 follow their pool slots)
+                # sum-check fast bodies (head dim 128): exp + row sums + check of q block 0 / 1, then the pair packing of q block 0 / 1.  Measured
+                # (tools/kbench.py, one box, c2 / c4 TF; max-first bodies 1230 / 1245): check of q block 0 before MFMA 32 (no late shift for it)
+                # 0:31 31:46 18:58 58:64 -> 1232 / 1251; 0:40 40:52 12:58 58:64 -> 1235 / 1251; 4:56 56:62 6:60 60:64 -> 1238 / 1256; these -> 1245 / 1264
+                "se0": (0.0, 48.0), "se1": (8.0, 60.0), "sc0": (48.0, 58.0), "sc1": (60.0, 64.0),
                 "vsplit": (0.0, 0.0),       # timing probe (wrong results): 16 of the 32 V^T reads go into this PV-phase window
                 "shift": (0.0, 0.0),
                 "dmaw": (0.0, 0.0)}      # (width, step) > 0: one copy of the fast loop per wave, wave w stages in gaps [dma0 + w*step, +width)     # code-placement probe: (n s_nop before the fast loop, log2 alignment of its first instruction)
@@ -240,6 +251,8 @@ class Gen:
         # v_add_f32 per tile go, 8 MFMAs come.  Default at head dim 64, where the body is VALU-bound (32 MFMAs per tile for the same
         # softmax work as at 128); at 128 the round-2 measurement of the idea in the 8-wave kernel was -3 %.
         self.lmfma = ("lmfma" in self.opt) or (hd == 64 and "nolmfma" not in self.opt)
+        # "sum check" fast bodies (default at head dim 128; opt=maxfirst keeps the row-max stream everywhere): see stream_exp_sum
+        self.sumchk = hd == 128 and not self.lmfma and "maxfirst" not in self.opt
         self.lacc = lambda qb: A(g.LA0 + 16 * qb, 16)
         self.npv = 8 * g.NDT + (8 if self.lmfma else 0)   # MFMAs of the PV phase (both q blocks) ...
         self.nqk = 4 * g.NKS              # ... and of the QK phase
@@ -318,6 +331,150 @@ class Gen:
             else:
                 out += F + E + Ad + C
         return out
+
+    def stream_exp_sum(self, qb, par):
+        """Fast bodies without a row-max stream.  P = 2^(S*c - m*c) against the CURRENT reference m (folded-scale kernels: P = 2^S) for the whole
+        q block, the two row-sum chains started afresh for the tile (TA, TB), the tile sums added to the running sums — and ONE check: this lane's
+        partial row sum of the tile, TA + TB, bounds each of its 32 P from above, so `TA + TB <= PSUM_MAX` (2^15) proves that every P fits the
+        16-bit type it is about to be rounded to (fp16 overflows at 65504) and that none is inf / NaN — the reference may then stay where it is:
+        rounding is relative, a P of 2^15 is as exact as a P of 1, O and l are f32.  The 16 v_max3 + exchange + decision of the max-first bodies
+        (stream_max: ~22 instructions per q block and tile) become 3; the reference moves, out of line (rare_sum), only when the check fails.
+        The pair packing (stream_pack) follows the check: the rare block needs the unpacked f32 P."""
+        b = SB(qb, par)
+        ta, tb, ts = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2]
+        out = []
+        for k in range(16 + 2):
+            F, E, Ad = [], [], []
+            if k < 16 and not self.fold:                       # stage 0: x = s*c - m*c
+                e = 2 * k
+                F.append(mk("v_fma_f32", b[e], b[e], A_C, Neg(MC[qb]), tag="valu"))
+                F.append(mk("v_fma_f32", b[e + 1], b[e + 1], A_C, Neg(MC[qb]), tag="valu"))
+            if 0 <= k - 1 < 16:                               # stage 1: 2^x
+                e = 2 * (k - 1)
+                E.append(mk("v_exp_f32", b[e], b[e], tag="trans"))
+                E.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
+            if 1 <= k - 2 < 16:                               # stage 2: the tile's two sum chains (pair 0 enters with pair 1)
+                e = 2 * (k - 2)
+                if k - 2 == 1:
+                    Ad.append(mk("v_add_f32", ta, b[0], b[2], tag="valu"))
+                    Ad.append(mk("v_add_f32", tb, b[1], b[3], tag="valu"))
+                else:
+                    Ad.append(mk("v_add_f32", ta, ta, b[e], tag="valu"))
+                    Ad.append(mk("v_add_f32", tb, tb, b[e + 1], tag="valu"))
+            out += F + E + Ad
+        out.append(mk("v_add_f32", LA[qb], LA[qb], ta, tag="valu"))
+        out.append(mk("v_add_f32", LB[qb], LB[qb], tb, tag="valu"))
+        out.append(mk("v_add_f32", ts, ta, tb, tag="valu"))
+        lab = self.p.fresh("rare_s")
+        # not (limit >= sum): also true for a NaN sum (the literal has to be src0 of a VOPC).  (a list inside a stream is an atomic group: the branch and its return label stay together)
+        out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_nge_f32", VCC, PSUM_MAX, ts, tag="valu"),
+                    mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+        self.pending_rare_sum.append((lab, qb, par))
+        return out
+
+    def stream_pack(self, qb, par):
+        b = SB(qb, par)
+        return [mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu") for e in range(0, 32, 2)]
+
+    def rare_sum(self, lab, qb, par, fix):
+        """Out of line, sum-check bodies: a lane's tile sum of q block qb exceeded PSUM_MAX.  All 32 f32 P of the tile are still unpacked in the bank:
+        the row maximum of P (both lane halves) gives the growth d = max(0, ceil(log2 max P)) of the reference, and everything at the old reference —
+        this tile's P, the running sums (this tile's share included), the O accumulators (all of PV(t) of this q block was issued gaps ago) — is
+        multiplied by 2^-d, an exact power of two.  Folded-scale kernels also rewrite the C tuple of the coming QK^T products; `fix`: the first k-step
+        of the NEXT tile's QK^T has been issued with the old tuple already, so those scores get the shift at the start of the next body (S_FIX, DSH).
+        A non-finite maximum (a score more than 2^7 log2 units above the reference: P overflowed f32 — or a NaN input) cannot be repaired here:
+        the wave raises the workgroup's flag word in LDS and goes on; the shell runs the item again in safe mode (A_FLAGS bit 4: max-first bodies only)."""
+        b = SB(qb, par)
+        mxa, mxb, t, t2 = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2], TMP[4 * qb + 3]
+        g = self.g
+        assert not self.lmfma
+        scr = [ONESF[j] for j in range(4)]          # v[248:251]: free without "lmfma" (the other q block's TMP registers hold its live sum chains)
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("v_mov_b32", t2, t))                            # t = TMP[4qb+2] is the tile sum the check read: it carries an inf / NaN the maximum may drop
+        for (mx, off) in ((mxa, 0), (mxb, 16)):                     # (mxa, mxb: the tile's sum chains, already added to the running sums)
+            r.append(mk("v_max3_f32", mx, b[off], b[off + 1], b[off + 2]))
+        for i in range(6):
+            for (mx, off) in ((mxa, 0), (mxb, 16)):
+                r.append(mk("v_max3_f32", mx, mx, b[off + 3 + 2 * i], b[off + 4 + 2 * i]))
+        r.append(mk("v_max3_f32", mxa, mxa, b[15], b[31]))
+        r.append(mk("v_max_f32", mxa, mxa, mxb))
+        r.append(mk("v_mov_b32", t, mxa))
+        r.append(mk("s_nop", 1))
+        r.append(mk("v_permlane32_swap_b32", mxa, t))
+        r.append(mk("v_max_f32", mxa, mxa, t))                      # row maximum of P
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", t2, t2, mxa))
+        fail = lab + "_fail"
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_cmp_ngt_f32", VCC, float("inf"), t2))        # not (inf > x): inf or NaN in some lane
+        r.append(mk("s_cbranch_vccnz", Label(fail)))
+        r.append(mk("v_log_f32", t, mxa))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_max_f32", t, 0, t))                          # rows that stayed below their reference keep it (d = 0)
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_ceil_f32", t, t))                            # d: a whole number of octaves -> every factor below is an exact power of two
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_exp_f32", t2, Neg(t)))                       # 2^-d
+        r.append(mk("v_add_f32", MC[qb], MC[qb], t))                # the reference moves up by d
+        r.append(mk("s_nop", 0))
+        for e in range(32):
+            r.append(mk("v_mul_f32", b[e], b[e], t2))
+        r.append(mk("v_mul_f32", LA[qb], LA[qb], t2))
+        r.append(mk("v_mul_f32", LB[qb], LB[qb], t2))
+        if self.ct:
+            r.append(mk("v_sub_f32", mxb, 0, MC[qb]))
+            r.append(mk("s_nop", 0))
+            for i in range(16):
+                r.append(mk("v_mov_b32", CT[qb][i], mxb))
+            if fix:
+                r.append(mk("v_mov_b32", DSH[qb], t))
+                r.append(mk("s_or_b32", S_FIX, S_FIX, 1 << qb))
+        # O[qb] *= 2^-d (the MFMAs of PV(t) on these accumulators were issued at least a dozen gaps ago; the nops cover the last one's latency)
+        r.append(mk("s_nop", 15))
+        r.append(mk("s_nop", 15))
+        for dt in range(g.NDT):
+            acc = self.oacc(qb, dt)
+            for i in range(0, 16, 4):
+                for j in range(4):
+                    r.append(mk("v_accvgpr_read_b32", scr[j], acc[i + j]))
+                r.append(mk("s_nop", 1))
+                for j in range(4):
+                    r.append(mk("v_mul_f32", scr[j], scr[j], t2))
+                r.append(mk("s_nop", 1))
+                for j in range(4):
+                    r.append(mk("v_accvgpr_write_b32", acc[i + j], scr[j]))
+        r.append(mk("s_nop", 7))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        r.append(Ins("label", (Label(fail),)))
+        r.append(mk("v_mov_b32", t, S_WAVE))                         # this wave's own flag word (four words: no two waves write the same bytes)
+        r.append(mk("v_mov_b32", t2, 1))
+        r.append(mk("v_lshlrev_b32", t, 2, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_u32", t, g.FAIL_OFF, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("ds_write_b32", t, t2))
+        r.append(mk("s_waitcnt", lgkmcnt=0))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
+
+    def rare_fix(self, lab, par):
+        """Out of line, start of a body (folded-scale sum-check kernels): q blocks flagged in S_FIX had their reference moved after the first QK^T
+        k-step of THIS body's softmax tile had been issued with the old C tuple: shift those scores by the pending amount."""
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("s_nop", 15))                  # the QK^T MFMAs that wrote the bank ended the previous body
+        r.append(mk("s_nop", 15))
+        for qb in range(2):
+            skip = self.p.fresh("fix_skip")
+            r.append(mk("s_bitcmp1_b32", S_FIX, qb))
+            r.append(mk("s_cbranch_scc0", Label(skip)))
+            b = SB(qb, par)
+            for e in range(32):
+                r.append(mk("v_sub_f32", b[e], b[e], DSH[qb]))
+            r.append(Ins("label", (Label(skip),)))
+        r.append(mk("s_mov_b32", S_FIX, 0))
+        r.append(mk("s_nop", 1))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
 
     def stream_max(self, qb, par, masked, first=False):
         """mask (tail bodies) -> row max of the 32 scores of this lane -> half-wave exchange -> rescale decision."""
@@ -523,7 +680,20 @@ class Gen:
             p.emit("s_nop", 15)
         load = [0.0] * ng
         slots = [[] for _ in range(ng)]
-        if s1:
+        # fast bodies of the sum-check kernels carry no row-max stream (stream_exp_sum); head / tail / guarded bodies keep it — they also are the
+        # whole sweep of an item that is redone in safe mode
+        sumchk = self.sumchk and fast and s1 and not masked and not first and not abl
+        self.pending_rare_sum = []
+        if s1 and self.sumchk and self.ct and not first:
+            # scores formed against a reference that moved after their first k-step was issued (rare_sum, `fix`) get their shift before anything reads them
+            lab = p.fresh("rare_f")
+            p.emit("s_cmp_lg_u32", S_FIX, 0)
+            p.emit("s_cbranch_scc1", Label(lab))
+            p.label(lab + "_ret")
+            self.rare.append(self.rare_fix(lab, par ^ 1))
+        if s1 and sumchk:
+            self.place(load, slots, self.stream_exp_sum(0, par ^ 1), cfg["se0"][0], cfg["se0"][1], 0)
+        elif s1:
             mw = cfg["mmask"] if masked else cfg["m"]
             ew = W((mw[1], cfg["e"][1]))
             if "max" not in abl:
@@ -551,7 +721,11 @@ class Gen:
             self.place(load, slots, vr[:16], W(cfg["vread"])[0], W(cfg["vread"])[1], 4)
         elif s1 and "vread" not in abl:
             self.place(load, slots, self.stream_vread(par ^ 1), W(cfg["vread"])[0], W(cfg["vread"])[1], 4)
-        if s1 and "exp" not in abl:
+        if s1 and sumchk:
+            self.place(load, slots, self.stream_exp_sum(1, par ^ 1), cfg["se1"][0], cfg["se1"][1], 1)
+            self.place(load, slots, self.stream_pack(0, par ^ 1), cfg["sc0"][0], cfg["sc0"][1], 5)
+            self.place(load, slots, self.stream_pack(1, par ^ 1), cfg["sc1"][0], cfg["sc1"][1], 6)
+        elif s1 and "exp" not in abl:
             self.place(load, slots, self.stream_exp(0, par ^ 1), ew[0], ew[1] - 1.0, 5)
             self.place(load, slots, self.stream_exp(1, par ^ 1), ew[0], ew[1], 6)
         self.last_load = load
@@ -595,10 +769,27 @@ class Gen:
                         slots[g].append((g, 0, ins))
         for g in range(ng):
             slots[g].sort(key=lambda x: (x[0], x[1]))
+        # sum-check bodies: where did each q block's check land?  Its rare block rewrites the C tuple CT[qb] that the MFMAs 32 + 2 qb (+1) read
+        # (first QK^T k-step of the next tile); a check in a later gap leaves those scores at the old reference -> `fix` (S_FIX, rare_fix)
+        for (lab, qb, rpar) in self.pending_rare_sum:
+            gap = [g for g in range(ng) for (_, _, it) in slots[g] if isinstance(it, list) and any(
+                x.op == "s_cbranch_vccnz" and x.ops[0].name == lab for x in it)]
+            assert len(gap) == 1, (lab, gap)
+            # PV(t) of this q block (MFMAs 16 qb .. 16 qb + 15) must be issued: the rare block rescales its accumulators
+            assert gap[0] >= 16 * qb + 15, "sum check of q block %d in gap %d: its PV MFMAs are not all issued" % (qb, gap[0])
+            self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= 32 + 2 * qb))
+            self.check_gaps = getattr(self, "check_gaps", {})
+            self.check_gaps[(name, qb)] = gap[0]
         # emit: gap g fillers come AFTER mfma g
         body_start = len(p.ins)
         for g in range(ng):
-            if g == self.npv:
+            if g == self.npv and sumchk:
+                # (no pending O rescale can exist in a sum-check fast body: its rare blocks rescale at once, the head body before it sets no flag)
+                if s2 and "wait32" not in abl:
+                    p.emit("s_waitcnt", lgkmcnt=0)
+                if trace:
+                    p.emit("s_memtime", S_TB)
+            elif g == self.npv:
                 # phase boundary: all of PV(t) is issued.  Rare O rescale, then K(t+2) fragments must have landed.
                 lab = p.fresh("rare_r")
                 p.emit("s_cmp_lg_u32", S_FLAG, 0)
@@ -732,6 +923,7 @@ class Gen:
         p.emit("s_mov_b32", S_T, -2)
         p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mov_b32", S_FLAG, 0)
+        p.emit("s_mov_b32", S_FIX, 0)
         for r in S_SUM:
             p.emit("s_mov_b32", r, 0)
         p.emit("s_mov_b32", S_KOFF, 0)
@@ -841,6 +1033,9 @@ class Gen:
         p.label("main")
         if tr:
             p.emit("s_memtime", S_MARK[1])
+        if self.sumchk:
+            p.emit("s_bitcmp1_b32", A_FLAGS, 4)           # safe mode (the redo of an item whose sum check met a non-finite P): max-first bodies only
+            p.emit("s_cbranch_scc1", Label("dispatch"))
         p.emit("s_sub_u32", S_NFAST, A_NTW, 3)            # number of fast bodies (t = 0 .. ntw-4), if positive
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc0", Label("dispatch"))

@@ -25,7 +25,10 @@ CASES = [
     (512, 512, 1, True, False, False),        # causal: waves finish at different tiles
     (300, 300, 1, True, True, False),
     (256, 77, 0, True, False, False),         # causal + short KV
-    (256, 704, 0, False, False, True),        # spiked K rows: the rescale branch late in the sweep
+    (256, 704, 0, False, False, True),        # spiked K rows (scores > 2^7 log2 units above the reference: a sum-check body meets P = inf -> the item is redone in safe mode)
+    (256, 704, 0, False, False, 2),           # moderate spikes (15 .. 127 log2 units): the in-place repair of the sum-check bodies, q block 0 and 1, twice in one row
+    (256, 704, 0, False, True, 2),
+    (512, 768, 1, True, False, 2),            # ... with waves that finish at different tiles
 ]
 
 
@@ -46,8 +49,37 @@ def test_generated_block_matches_dense_attention(case, variant):
     nq, nkv, qblk, causal, bf16, spike = case
     err, lse_err, m = harness.check(nq, nkv, qblk, causal, bf16=bf16, spike=spike, seed=nq + nkv, verbose=False)
     assert not m.errors, m.errors[:5]
-    assert err <= (4e-3 if bf16 else (2e-3 if spike else 1e-3)), err
+    # (spiked rows: O is one V row of magnitude 2 .. 4, whose 16-bit rounding alone is 1e-3 / 8e-3)
+    assert err <= ((1.6e-2 if spike else 4e-3) if bf16 else (3e-3 if spike else 1e-3)), err
     assert lse_err <= 1e-4, lse_err
+    # the head-dim-128 fast bodies are sum-check bodies: P = inf (the hard spikes) must have sent the item through the safe-mode redo, once;
+    # everything else — the moderate spikes included — is repaired in place
+    assert m.redos == (1 if spike is True else 0), m.redos
+
+
+def test_sum_check_bodies_drop_the_row_max_stream():
+    """What the sum-check variant is for: the fast bodies of the head-dim-128 kernels issue no v_max3 and no v_permlane32_swap (the row-max stream of
+    the max-first bodies: 2 x 22 instructions per tile), three instructions per q block decide instead; opt=maxfirst restores the old bodies."""
+    import fwd_d128_gen as gen
+    for opt in ((), ("ct",)):
+        new, old = gen.Gen(False, opt=opt), gen.Gen(False, opt=opt + ("maxfirst",))
+        pn, po = new.build(), old.build()
+
+        def fast_loop(prog):
+            names = [i.ops[0].name if i.op == "label" else None for i in prog.ins]
+            a, b = names.index("fast0"), names.index("dispatch")
+            return prog.ins[a:b]
+        fn, fo_ = fast_loop(pn), fast_loop(po)
+        count = lambda body, op: sum(1 for i in body if i.op == op)  # noqa: E731
+        assert count(fn, "v_max3_f32") == 0 and count(fn, "v_permlane32_swap_b32") == 0
+        assert count(fo_, "v_max3_f32") == 2 * 2 * 15 and count(fn, "v_exp_f32") == count(fo_, "v_exp_f32") == 2 * 64
+        assert count(fn, "v_mfma_f32_32x32x16_f16") == count(fo_, "v_mfma_f32_32x32x16_f16") == 128
+        n_new = sum(1 for i in fn if i.op not in ("label", "raw"))
+        n_old = sum(1 for i in fo_ if i.op not in ("label", "raw"))
+        assert n_old - n_new >= 2 * 36, (n_old, n_new)                   # two bodies, >= 36 issue slots each
+        # a check lands after its q block's PV MFMAs (the rare block rescales those accumulators); when it lands past MFMA 32 + 2 qb the next tile's
+        # scores were formed with the old C tuple and get their shift at the start of the next body (S_FIX / rare_fix): both cases are emulated above
+        assert all(g >= 16 * qb + 15 for (name, qb), g in new.check_gaps.items())
 
 
 SEAMS = [

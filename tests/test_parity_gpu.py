@@ -313,6 +313,49 @@ def test_large_logits_and_forced_rescale(D):
         _assert_close_to_oracle(o, lse, q, k, v, 0, False)
 
 
+@pytest.mark.parametrize("dt,causal", [(0, False), (1, False), (0, True)])
+@pytest.mark.parametrize("kind", ["repair", "redo"])
+def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind):
+    """The fast bodies of the hand-scheduled head-dim-128 kernels keep no running row maximum: a lane's row sum of a tile proves that no P of the
+    tile overflows, and the reference moves, out of line, only when that check fails (csrc/gen/fwd_d128_gen.py: stream_exp_sum / rare_sum).
+      repair  a key row raises some rows' scores 15 .. 127 log2 units above everything before it, late in the sweep: the reference is moved in
+              place — rows of q block 0 and of q block 1 (whose next-tile scores get their shift a body later), one row twice;
+      redo    ... by more than 2^7 log2 units: P overflows f32 itself, the wave raises the workgroup's flag and the shell runs the item again in
+              safe mode (max-first bodies) — here on a grid with more items than workgroups, so that items redone are first items, second
+              (prefetched) items and items with a successor.
+    Both against float64 attention and the oracle under the planned contract (tests/test_asm_emu.py emulates the same two paths instruction by instruction)."""
+    B, H, N = 1, 66, 1024                                   # 264 items of 256 rows on 256 CUs: eight workgroups run two items
+    g = torch.Generator(device="cpu").manual_seed(700 + dt + 2 * causal)
+    q, k, v = (torch.randn((B, H, N, 128), generator=g) for _ in range(3))
+    if kind == "repair":
+        k[:, :, 200] = q[:, :, 5] * 2.7
+        k[:, :, 300] = q[:, :, 40] * 2.7
+        k[:, :, 130] = q[:, :, 41] * 1.5
+        k[:, :, 330] = q[:, :, 41] * 3.0
+        k[:, :, 700] = q[:, :, 900] * 2.7                 # (a row of the last q block; causal: visible to it)
+    else:
+        q, k = q * 3, k * 3
+        k[:, :, 200] = q[:, :, 5] * 4
+        k[:, :, 70] = q[:, :, 40] * 2
+        k[:, :, 600] = q[:, :, 800] * 4
+    q, k, v = (t.to(TORCH_DT[dt]).to(_dev()) for t in (q, k, v))
+    plan = _plan(q, k, causal)
+    assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.heads_main == B * H, plan.as_dict()
+    o, lse = _cabi_forward(q, k, v, causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    o2, lse2 = _cabi_forward(q, k, v, causal)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)            # the redo is deterministic too
+    for (b, h) in ((0, 0), (0, 7), (0, 33), (0, 65)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal, plan=plan, head=b * H + h)
+        o_true, lse_true = fo.fwd_numpy(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), causal)
+        got = o[sl].float().cpu().numpy()
+        folded = plan.contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+        o_tol = (3e-2 if folded and kind == "redo" else 4e-3) if dt == 0 else 3e-2
+        assert np.all(np.abs(got - o_true) <= o_tol + 4e-3 * np.abs(o_true)), (h, float(np.abs(got - o_true).max()))
+        assert np.abs(lse[sl].cpu().numpy() - lse_true).max() <= ((0.3 if folded else 2e-2) if kind == "redo" else 2e-2), h
+
+
 # ---------------------------------------------------------------- operator contract (reference quirks)
 
 def test_return_contract_shapes_without_padding_copies():

@@ -490,10 +490,20 @@ class Machine:
         elif op in ("v_cmp_gt_i32", "v_cmp_le_i32", "v_cmp_ge_i32"):
             x, y = self.rd32(w, ops[1]).view(np.int32), self.rd32(w, ops[2]).view(np.int32)
             w.vcc = {"v_cmp_gt_i32": x > y, "v_cmp_le_i32": x <= y, "v_cmp_ge_i32": x >= y}[op]
-        elif op == "v_cmp_lt_f32":
+        elif op in ("v_cmp_lt_f32", "v_cmp_nge_f32", "v_cmp_ngt_f32"):
             x, y = self.rdf(w, ops[1]), self.rdf(w, ops[2])
             with np.errstate(invalid="ignore"):
-                w.vcc = x < y
+                w.vcc = {"v_cmp_lt_f32": x < y, "v_cmp_nge_f32": ~(x >= y), "v_cmp_ngt_f32": ~(x > y)}[op]      # (n..: true for NaN operands)
+        elif op == "v_ceil_f32":
+            with np.errstate(invalid="ignore"):
+                self.wr32(w, ops[0], np.ceil(self.rdf(w, ops[1])).astype(np.float32))
+        elif op == "ds_write_b32":
+            addr = self.rd32(w, ops[0]).astype(np.int64) + ins.mods.get("offset", 0)
+            src = R(1)
+            self.check_read(w, src.kind, src.idx, 1, "valu")
+            data = np.ascontiguousarray(self.regfile(w, src.kind)[src.idx:src.idx + 1].T).view(np.uint8)   # [64, 4]
+            self.lds_write(w, addr, data)
+            w.lgkm.append(lambda: None)
         elif op == "v_cndmask_b32":
             self.wr32(w, ops[0], np.where(w.vcc, self.rd32(w, ops[2]), self.rd32(w, ops[1])))
         elif op == "v_cmp_eq_u32":

@@ -58,8 +58,11 @@ def build(specs):
     for s in specs:
         name, _, flags = s.partition(":")
         fl = [f for f in flags.split(",") if f]
-        extra = [f for f in fl if not f.startswith(("gen=", "bgen="))]
+        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "only="))]
         only = None if extra else ["fwd_asm", "bwd_asm"]          # generator-only variants: recompile just the units that include the bodies
+        for f in fl:
+            if f.startswith("only="):                            # only=fwd_asm+host: -D flags that matter to these units alone
+                only = f[5:].split("+")
         opts = {}
         for f in fl:
             if f.startswith("gen="):

@@ -57,9 +57,43 @@ def _flat(items):
 class BodyEmitter:
     """What the bodies of both backward kernels share: fillers placed into MFMA gaps, counted LDS waits, the end-of-body sync."""
 
-    def emit_body(self, p, mfmas, slots, pre=(), boundary=None, post=()):
+    def check_running_state(self, body, bookkeeping, name):
+        """Legality of a placed body.  The filler streams are written against the running state a body is ENTERED with — the tile counter, the source
+        offsets of the LDS-DMA pieces, M0's ring slot, the moving LDS read addresses; the book-keeping instructions that advance that state for the
+        next body ride in late gaps.  A schedule window that lets a stream instruction land BEHIND the book-keeping it depends on makes it stage or
+        read the next tile's slot while this tile's readers are still on it: wrong gradients, silently (profiles/r09_experiments.txt item 1: every
+        LDS-DMA window of the dK / dV pass that reaches the book-keeping gaps).  Raises ValueError for such a schedule."""
+        bk = set(id(i) for i in bookkeeping)
+        stale = {}                                   # (kind, index) -> the book-keeping instruction that advanced it
+        for ins in body:
+            if ins.op in ("label", "raw", "s_waitcnt", "s_barrier", "s_nop"):
+                continue
+            rd, wr = [], []
+            for j, o in enumerate(ins.ops):
+                if isinstance(o, Neg):
+                    o = o.reg
+                if hasattr(o, "kind") and hasattr(o, "idx"):
+                    rng = [(o.kind, o.idx + t) for t in range(o.n)]
+                    writes_first = not (ins.op.startswith("s_cmp") or ins.op.startswith("s_bitcmp") or ins.op.startswith("v_cmp") or
+                                        ins.op.startswith("buffer_load") or ins.op.startswith("ds_write") or ins.op.startswith("s_cbranch"))
+                    (wr if (j == 0 and writes_first) else rd).extend(rng)
+                    if j == 0 and ins.op.startswith("v_permlane"):
+                        rd.extend(rng)
+            if id(ins) in bk:
+                for r in wr:
+                    stale[r] = ins
+                continue
+            for r in rd:
+                if r in stale:
+                    raise ValueError("%s: illegal schedule — `%s` reads %s%d after the book-keeping `%s` advanced it for the next body (a stream window "
+                                     "reaches past the book-keeping gaps)" % (name, ins.text(), r[0], r[1], stale[r].text()))
+            for r in wr:
+                stale.pop(r, None)
+
+    def emit_body(self, p, mfmas, slots, pre=(), boundary=None, post=(), bookkeeping=(), name="body"):
         """mfmas: list (None = no MFMA in that gap); slots[g]: [(key, stream id, item)]; boundary: {gap: [instructions emitted in
-        front of that gap's MFMA]}.  The LDS-wait pass runs over the whole body."""
+        front of that gap's MFMA]}.  The LDS-wait pass runs over the whole body; bookkeeping: the instructions that advance the running state
+        for the next body (check_running_state)."""
         start = len(p.ins)
         p.ins.extend(pre)
         for g in range(len(mfmas)):
@@ -70,6 +104,8 @@ class BodyEmitter:
             for (_, _, item) in sorted(slots[g], key=lambda x: (x[0], x[1])):
                 p.ins.extend(item if isinstance(item, list) else [item])
         p.ins.extend(post)
+        if bookkeeping and "nocheck" not in getattr(self, "opt", ()):
+            self.check_running_state(p.ins[start:], _flat(bookkeeping), name)
         p.ins[start:] = sched.lds_waits(p.ins[start:])
 
 
@@ -294,7 +330,7 @@ class GenDQ(BodyEmitter):
         post = [mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
         if "barrier" not in abl:
             post.append(mk("s_barrier"))
-        self.emit_body(p, mf, slots, pre=pre, boundary=boundary, post=post)
+        self.emit_body(p, mf, slots, pre=pre, boundary=boundary, post=post, bookkeeping=bk, name="dQ body " + name)
 
     # ------------------------------------------------------------------ whole block
     def build(self):
@@ -741,7 +777,7 @@ class GenDKV(BodyEmitter):
         post = [mk("s_waitcnt", vmcnt=0, lgkmcnt=0)]
         if "barrier" not in abl:
             post.append(mk("s_barrier"))
-        self.emit_body(p, mf, slots, pre=pre, post=post)
+        self.emit_body(p, mf, slots, pre=pre, post=post, bookkeeping=bk1 + bk2, name="dK/dV body %s (%s side)" % (name, "P" if P else "dS"))
 
     # ------------------------------------------------------------------ one role's sweep
     def role_code(self, role):

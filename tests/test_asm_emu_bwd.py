@@ -123,3 +123,28 @@ def test_backward_blocks_with_a_negative_scale(causal):
     assert not m.errors, m.errors[:5]
     for got, want in ((dk, ref["dk"]), (dv, ref["dv"])):
         assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * max(1.0, float(np.abs(want).max()))
+
+
+def test_generator_rejects_schedules_that_stage_behind_the_book_keeping():
+    """A schedule window is an input of the generators (window sweeps: tools/kbench.py, tools/bwd_bench.py).  The filler streams are written against
+    the running state a body is entered with — tile offsets of the LDS-DMA pieces, M0's ring slot, the moving read addresses — and the book-keeping
+    that advances it rides in late gaps: an LDS-DMA window that reaches those gaps stages the NEXT tile's data into a slot this tile's readers are
+    still on.  Round 3 found that by wrong gradients on the GPU (profiles/r09_experiments.txt item 1); now the generator refuses the schedule
+    (BodyEmitter.check_running_state), and — with the check switched off — the emulator run shows what it would have computed."""
+    import bwd_d128_gen as gen
+    for bf16 in (False, True):                       # the shipped windows are legal
+        gen.GenDQ(bf16).build()
+        gen.GenDKV(bf16).build()
+    gen.GenDKV(False, dma=(8.0, 20.0)).build()       # ... and so is a later window that stays clear of the book-keeping gaps (20..31)
+    for cls, kw in ((gen.GenDKV, dict(dma=(14.0, 26.0))), (gen.GenDKV, dict(dma=(20.0, 31.0))), (gen.GenDQ, dict(dma=(40.0, 48.0)))):
+        with pytest.raises(ValueError, match="illegal schedule"):
+            cls(False, **kw).build()
+    # the emulator on the rejected dK / dV schedule, check off: no modelled hazard fires (the instruction stream is self-consistent), the gradients are wrong
+    saved = dict(harness._PROGS)
+    try:
+        harness._PROGS[("dkv", False)] = gen.GenDKV(False, dma=(14.0, 26.0), opt=("nocheck",)).build()
+        ek, ev, m, ref = harness.check_dkv(640, 128, 0, False, seed=1, verbose=False)
+        assert max(ek, ev) > 0.1 * max(1.0, float(abs(ref["dk"]).max()))
+    finally:
+        harness._PROGS.clear()
+        harness._PROGS.update(saved)

@@ -32,10 +32,11 @@ Rank 0 prints ONE JSON line.
                timed steps (the contract) -> K launches with per-launch events -> steady re-timing ->
                informational backward -> CPU baseline.  The timed region carries no event between launches (one costs
                1.6 %, tools/event_overhead.py).
-  settle       `--settle N` (default 150) launches of the same call before the warm-up, checked bit-identical to the
-               gate's output: the chip's power management needs ~100 launches (25 ms) of this kernel's load to find
-               its steady clock after idle (profiles/r03_clock_settling.txt) — five warm-up launches measure the
-               transient, not the kernel (round 3: 7 % under `steady`).  `--settle 0` reproduces that cold-start number.
+  settle       before the warm-up the same call is launched in chunks of 25 until four consecutive chunks agree within
+               1 % (at most `--settle N` launches, default 2000; checked bit-identical to the gate's output): after idle
+               the chip boosts, overshoots its power budget, throttles and recovers over 100 .. 400 launches
+               (profiles/r03_clock_settling.txt) — five warm-up launches measure that transient, not the kernel
+               (round 3: 7 % under `steady`).  `--settle 0` reproduces the cold-start number.
   launch_ms    min / median / max / first / last of K per-launch durations measured straight after the timed
                region (HIP events on the launch stream, one event between consecutive launches).
   steady       the same loop re-timed for --steady-launches launches AFTER the contractual region
@@ -158,9 +159,10 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (dry run of the multi-rank path on one GPU)")
     ap.add_argument("--no-backward", action="store_true")
-    ap.add_argument("--settle", type=int, default=150,
-                    help="launches of the operator issued (and checked bit-identical) BEFORE the W warm-up steps, so that the chip's power management "
-                         "has settled on this kernel's load when the contractual region starts (0 = none: the cold-start number)")
+    ap.add_argument("--settle", type=int, default=2000,
+                    help="upper bound of the launches of the operator issued (and checked bit-identical) BEFORE the W warm-up steps: chunks of 25 until four "
+                         "consecutive chunks agree within 1 %%, i.e. until the chip's power management has settled on this kernel's load (0 = none: "
+                         "the cold-start number)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group, barriers, reductions and --collectives even with ONE rank (executes the RCCL path on a 1-GPU box)")
     args = ap.parse_args()
@@ -241,16 +243,29 @@ def main():
     assert gate_err <= check_tol, "output differs from dense fp32 attention before timing: %g" % gate_err
 
     # ---- settling, stated plainly: after idle the chip boosts, overshoots its power budget, throttles and needs ~100 launches (25 ms) of THIS load to
-    #      find its steady clock (profiles/r03_clock_settling.txt: the first 30 launches of a process run 15 % slower than the 100th).  Five warm-up
-    #      launches cannot cover that, so the operator is run `--settle` times first — doubling as a determinism gate: the last result must equal the
-    #      first bit for bit.  `--settle 0` gives the cold-start number; the line reports which one was measured.
-    settle_info = {"launches": args.settle}
+    #      find its steady clock (profiles/r03_clock_settling.txt: the first 30 launches of a process run 15 % slower than the 100th; on other boxes
+    #      the dip comes later: profiles/r12_bench_driver_args_fixed150.json — 150 launches ahead put the 20 timed ones INTO it, 0.2506 ms against
+    #      0.2099 steady).  Five warm-up launches cannot cover that, so the operator is first run in chunks of 25 until four consecutive chunks agree
+    #      within 1 % (at most `--settle` launches) — doubling as a determinism gate: the last result must equal the first bit for bit.
+    #      `--settle 0` gives the cold-start number; the line reports what was done.
+    settle_info = {"max_launches": args.settle, "launches": 0}
     if args.settle > 0:
-        for _ in range(args.settle):
-            o_s = attn(q, k, v, None, causal)
-        torch.cuda.synchronize()
+        chunk, times = 25, []
+        while settle_info["launches"] < args.settle:
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(chunk):
+                o_s = attn(q, k, v, None, causal)
+            c1.record()
+            torch.cuda.synchronize()
+            times.append(c0.elapsed_time(c1) / chunk)
+            settle_info["launches"] += chunk
+            # settled: the last four chunks agree within 1 % (the transient — boost, throttle, recovery — moves the launch time by 5 .. 15 %)
+            if len(times) >= 6 and max(times[-4:]) <= 1.01 * min(times[-4:]):
+                break
         assert torch.equal(o_s, o), "the operator is not deterministic run to run (settling phase)"
-        settle_info["bit_identical_to_gate_output"] = True
+        settle_info.update({"bit_identical_to_gate_output": True, "chunk": chunk, "first_chunk_ms": round(times[0], 5), "slowest_chunk_ms": round(max(times), 5),
+                            "last_chunk_ms": round(times[-1], 5), "converged": len(times) >= 6 and max(times[-4:]) <= 1.01 * min(times[-4:])})
         del o_s
 
     # ---- contractual region: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize

@@ -382,7 +382,7 @@ class Gen:
         this tile's P, the running sums (this tile's share included), the O accumulators (all of PV(t) of this q block was issued gaps ago) — is
         multiplied by 2^-d, an exact power of two.  Folded-scale kernels also rewrite the C tuple of the coming QK^T products; `fix`: the first k-step
         of the NEXT tile's QK^T has been issued with the old tuple already, so those scores get the shift at the start of the next body (S_FIX, DSH).
-        A non-finite maximum (a score more than 2^7 log2 units above the reference: P overflowed f32 — or a NaN input) cannot be repaired here:
+        A maximum at or beyond 2^120 (a score 120+ log2 units above the reference: P at, or past, the edge of f32 — or a NaN input) is not repaired here:
         the wave raises the workgroup's flag word in LDS and goes on; the shell runs the item again in safe mode (A_FLAGS bit 4: max-first bodies only)."""
         b = SB(qb, par)
         mxa, mxb, t, t2 = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2], TMP[4 * qb + 3]
@@ -406,7 +406,9 @@ class Gen:
         r.append(mk("v_add_f32", t2, t2, mxa))
         fail = lab + "_fail"
         r.append(mk("s_nop", 0))
-        r.append(mk("v_cmp_ngt_f32", VCC, float("inf"), t2))        # not (inf > x): inf or NaN in some lane
+        # not (2^120 > tile sum + row maximum): inf or NaN in some lane — or a growth close to 2^7 octaves: the factor 2^-d must stay a NORMAL f32
+        # (v_exp_f32 flushes denormal results to zero: 2^-127, 2^-128 would wipe the row — found on the GPU by rows whose maximum sat in (2^126, 2^128))
+        r.append(mk("v_cmp_ngt_f32", VCC, float(2.0 ** 120), t2))
         r.append(mk("s_cbranch_vccnz", Label(fail)))
         r.append(mk("v_log_f32", t, mxa))
         r.append(mk("s_nop", 0))

@@ -29,6 +29,8 @@ CASES = [
     (256, 704, 0, False, False, 2),           # moderate spikes (15 .. 127 log2 units): the in-place repair of the sum-check bodies, q block 0 and 1, twice in one row
     (256, 704, 0, False, True, 2),
     (512, 768, 1, True, False, 2),            # ... with waves that finish at different tiles
+    (256, 704, 0, False, False, 3),           # growth of 119 .. 127.4 octaves: at the edge of f32 the repair factor 2^-d is no normal number any more -> redo
+    (256, 704, 0, False, True, 3),
 ]
 
 
@@ -54,7 +56,7 @@ def test_generated_block_matches_dense_attention(case, variant):
     assert lse_err <= 1e-4, lse_err
     # the head-dim-128 fast bodies are sum-check bodies: P = inf (the hard spikes) must have sent the item through the safe-mode redo, once;
     # everything else — the moderate spikes included — is repaired in place
-    assert m.redos == (1 if spike is True else 0), m.redos
+    assert m.redos == (1 if spike in (True, 3) else 0), m.redos
 
 
 def test_sum_check_bodies_drop_the_row_max_stream():

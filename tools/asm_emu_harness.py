@@ -234,7 +234,15 @@ def check(Nq, Nkv, qblk, causal, bf16=False, seed=0, kind="randn", spike=False, 
     rng = np.random.default_rng(seed)
     mk = (lambda s: rng.standard_normal(s)) if kind == "randn" else (lambda s: rng.random(s))
     q, k, v = mk((Nq, HD)), mk((Nkv, HD)), mk((Nkv, HD))
-    if spike == 2:
+    if spike == 3:
+        # growth of 121 .. 126.6 octaves over the row's reference (its tile-0 maximum), none past f32's range: the repair factor 2^-d of the sum-check
+        # bodies would be 2^-127 for the largest — no normal f32, v_exp_f32 returns 0 for it and the row would be wiped — so the item must be redone
+        for row, kv, grow in ((5, 200, 126.6), (40, 300, 126.3), (100, 333, 124.0), (77, 400, 121.0)):
+            qr = from_bits(to_bits(q[row], bf16), bf16).astype(np.float64)
+            k0 = from_bits(to_bits(k[:64], bf16), bf16).astype(np.float64)
+            ref = float((k0 @ qr).max()) * HD ** -0.5 * LOG2E
+            k[min(Nkv - 1, kv)] = q[row] * ((ref + grow) / (float((qr ** 2).sum()) * HD ** -0.5 * LOG2E))
+    elif spike == 2:
         # a reference that has to move by 15 .. 127 log2 units late in the sweep: the in-place repair of the sum-check bodies (rare_sum), q block 0
         # (row 5) and q block 1 (row 40: the next tile's scores get their shift at the start of the next body, rare_fix), and twice in a row (row 41)
         k[min(Nkv - 1, 200)] = q[5] * 2.7

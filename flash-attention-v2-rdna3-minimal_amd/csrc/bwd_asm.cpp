@@ -8,8 +8,16 @@
 namespace {
 
 // parts: bit 0 = dQ pass, bit 1 = dK/dV pass.  neg_delta: the dQ pass leaves -delta in the workspace (the hand-scheduled dK/dV pass follows).
+template <bool BF16, bool CAUSAL, bool KFOLD>
+int launch_dkv(const fa2::BwdParams& p, hipStream_t stream) {
+    constexpr auto kern = fa2::bwd_dkv_d128_kernel<BF16, CAUSAL, KFOLD>;
+    if (int rc = fa2::set_lds<kern>(fa2::kBwdKvLdsBytes)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), fa2::kBwdKvLdsBytes, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <bool BF16, bool CAUSAL>
-int launch_t(fa2::BwdParams p, int parts, bool neg_delta, hipStream_t stream) {
+int launch_t(fa2::BwdParams p, int parts, bool neg_delta, bool kfold, hipStream_t stream) {
     if (parts & 1) {        // dQ (+ delta): one workgroup per 256 Q rows
         p.nblk = (p.Nq + 255) / 256;
         const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nblk));
@@ -25,12 +33,9 @@ int launch_t(fa2::BwdParams p, int parts, bool neg_delta, hipStream_t stream) {
         if (int rc = (int)hipGetLastError()) return rc;
     }
     if (parts & 2) {        // dK / dV: one workgroup per 128 KV rows
-        constexpr auto kern = fa2::bwd_dkv_d128_kernel<BF16, CAUSAL>;
-        if (int rc = fa2::set_lds<kern>(fa2::kBwdKvLdsBytes)) return rc;
         p.nblk = (p.Nkv + 127) / 128;
         if ((int64_t)p.B * p.H * p.nblk > 0x7fffffffLL) return FA2_ERR_GRID;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), fa2::kBwdKvLdsBytes, stream, p);
-        if (int rc = (int)hipGetLastError()) return rc;
+        if (int rc = kfold ? launch_dkv<BF16, CAUSAL, true>(p, stream) : launch_dkv<BF16, CAUSAL, false>(p, stream)) return rc;
     }
     return 0;
 }
@@ -39,9 +44,9 @@ int launch_t(fa2::BwdParams p, int parts, bool neg_delta, hipStream_t stream) {
 
 namespace fa2 {
 
-int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, hipStream_t stream) {
-    if (bf16) return causal ? launch_t<true, true>(p, parts, neg_delta, stream) : launch_t<true, false>(p, parts, neg_delta, stream);
-    return causal ? launch_t<false, true>(p, parts, neg_delta, stream) : launch_t<false, false>(p, parts, neg_delta, stream);
+int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream) {
+    if (bf16) return causal ? launch_t<true, true>(p, parts, neg_delta, kfold, stream) : launch_t<true, false>(p, parts, neg_delta, kfold, stream);
+    return causal ? launch_t<false, true>(p, parts, neg_delta, kfold, stream) : launch_t<false, false>(p, parts, neg_delta, kfold, stream);
 }
 
 }  // namespace fa2

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
 constexpr int kBwdKvLdsBytes = 65536 + 16384;                // KV.LDS_BYTES: Q ring 32 KiB | dO ring 16 KiB | L, -delta 1 KiB (below 64 KiB: LDS-DMA targets) | P slots 16 KiB
 constexpr int kBwdKvLdBase = 49152, kBwdKvPSlots = 65536;
 
-template <bool BF16, bool CAUSAL>
+// KFOLD: the body whose P side folds scale * log2(e) into its K fragments (rounded once to the I/O dtype) and takes L as the C operand of the S product
+// (csrc/gen/bwd_d128_gen.py, option "kfold"; host: option "fold", bwd_folds in host.cpp).
+template <bool BF16, bool CAUSAL, bool KFOLD>
 __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -217,9 +219,21 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
       "s"(fbase), "s"(qrs), "s"(grs), "s"(lrs), "s"(c), "s"(oscale), "s"(n), "s"(qoff0), "s"(goff0), "s"(loff0), "s"(q_tile),     \
       "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role), "s"(ldm0)                                                      \
     :
-    if constexpr (BF16) {
+    if constexpr (BF16 && KFOLD) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_bf16_fold.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16) {
         asm volatile(
 #include FA2_BWD_INC(fa2_bwd_dkv_d128_bf16.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    } else if constexpr (KFOLD) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_f16_fold.inc)
             FA2_BWD_KV_OPERANDS
 #include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
         );

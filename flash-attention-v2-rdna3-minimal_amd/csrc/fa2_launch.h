@@ -129,7 +129,8 @@ FA2_HIDDEN int launch_bwd_bias_hip_f16(int HD, const BwdParams& p, bool causal, 
 FA2_HIDDEN int launch_bwd_bias_hip_bf16(int HD, const BwdParams& p, bool causal, hipStream_t stream);
 // hand-scheduled backward, head dim exactly 128 (bwd_asm.cpp); same `parts`
 // neg_delta: the dQ pass writes -delta (the hand-scheduled dK/dV pass reads it as such; the HIP dK/dV passes read +delta)
-FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, hipStream_t stream);
+// kfold: the dK / dV body whose P side folds scale * log2(e) into its K fragments (option "fold"; host.cpp: bwd_folds)
+FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream);
 
 constexpr int kBwdAsmParts = 3;      // passes the hand-scheduled backward covers: bit 0 = dQ, bit 1 = dK / dV
 

@@ -592,7 +592,7 @@ class KV:
 
 
 class GenDKV(BodyEmitter):
-    DEFAULTS = {"valu_p": (1.0, 31.0), "valu_s": (1.0, 31.0), "rowread": (0.0, 15.0), "trread": (16.0, 31.0), "dma": (1.0, 12.0), "lread": (20.0, 31.0), "opt": (), "abl": ()}
+    DEFAULTS = {"valu_p": (1.0, 31.0), "valu_s": (1.0, 31.0), "rowread": (0.0, 15.0), "trread": (16.0, 31.0), "dma": (1.0, 12.0), "lread": (20.0, 31.0), "lread_p": (1.0, 12.0), "opt": (), "abl": ()}
 
     def __init__(self, bf16=False, **cfg):
         self.cfg = dict(self.DEFAULTS)
@@ -602,6 +602,11 @@ class GenDKV(BodyEmitter):
         self.mfma = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if bf16 else "v_cvt_pk_f16_f32"
         self.p = Program()
+        # "kfold": the P side folds the scale into its K fragments — K * (-scale*log2e), rounded once to the I/O dtype as the fragments are loaded (the
+        # forward's folded-scale contract, on the other operand: pure_torch_ver.py:61 scales q, the product is the same up to one rounding) — and takes
+        # the tile's L as the C operand of the first k-step: the matrix pipe delivers L - S c, P = 2^-(that) is ONE v_exp_f32 with a negated source.
+        # The 32 v_fma_f32 per body go; the P side is the role every body waits for (it alone carries the 32 transcendentals).
+        self.kfold = "kfold" in self.opt
 
     # ------------------------------------------------------------------ MFMA lists (shared shapes, role-specific operands)
     def acc_mfmas(self, par):
@@ -630,19 +635,22 @@ class GenDKV(BodyEmitter):
         out = []
         if masked:      # causal: q (tile-local: (r&3) + 8(r>>2), + 4*hi folded into the limit) must be >= this lane's kv row
             t2 = KV.TMP[4 * kvb]         # (-inf, or +inf for a negative scale: see GenDQ.stream_valu)
-            out.append([mk("v_mov_b32", t2, KV.A_C, tag="valu"), mk("v_and_b32", t2, 0x80000000, t2, tag="valu"),
-                        mk("v_xor_b32", t2, 0xff800000, t2, tag="valu")])
+            if self.kfold:               # the bank holds L - S c: masked scores become +inf whatever the sign of the scale, P = 2^-inf = 0
+                out.append(mk("v_mov_b32", t2, 0x7f800000, tag="valu"))
+            else:
+                out.append([mk("v_mov_b32", t2, KV.A_C, tag="valu"), mk("v_and_b32", t2, 0x80000000, t2, tag="valu"),
+                            mk("v_xor_b32", t2, 0xff800000, t2, tag="valu")])
             for r in range(16):
                 out.append([mk("v_cmp_ge_i32", VCC, (r & 3) + 8 * (r >> 2), KV.LIMT[kvb], tag="valu"),
                             mk("v_cndmask_b32", s[r], t2, s[r], VCC, tag="valu")])
         for k in range(8 + 2):
             F, E, C = [], [], []
-            if k < 8:
+            if k < 8 and not self.kfold:
                 for e in (2 * k, 2 * k + 1):
                     F.append(mk("v_fma_f32", s[e], s[e], KV.A_C, Neg(L[e]), tag="valu"))
             if 0 <= k - 1 < 8:
                 for e in (2 * (k - 1), 2 * (k - 1) + 1):
-                    E.append(mk("v_exp_f32", s[e], s[e], tag="trans"))
+                    E.append(mk("v_exp_f32", s[e], Neg(s[e]) if self.kfold else s[e], tag="trans"))
             if 0 <= k - 2 < 8:
                 e = 2 * (k - 2)
                 C.append(mk(self.cvt, s[8 * (e // 8) + (e % 8) // 2], s[e], s[e + 1], tag="valu"))
@@ -717,7 +725,7 @@ class GenDKV(BodyEmitter):
         ng = 32
         P = role == 0
         if P:
-            mf = (self.acc_mfmas(par) if acc else [None] * 16) + (self.row_mfmas(par, False) if row else [None] * 16)
+            mf = (self.acc_mfmas(par) if acc else [None] * 16) + (self.row_mfmas(par, self.kfold) if row else [None] * 16)
         else:
             mf = (self.acc_mfmas(par ^ 1) if acc else [None] * 16) + (self.row_mfmas(par ^ 1, True) if row else [None] * 16)
         if "mfma" in abl:
@@ -734,7 +742,9 @@ class GenDKV(BodyEmitter):
                 pre.append(mk("v_subrev_u32", KV.LIMT[kvb], KV.S_TMP, KV.A_LIM0 if kvb == 0 else KV.A_LIM1))
         if "dma" not in abl:
             sched.place(load, slots, self.stream_dma(par), cfg["dma"][0], cfg["dma"][1], 2)
-            sched.place(load, slots, self.stream_lread(par), cfg["lread"][0], cfg["lread"][1], 8)
+            # (kfold, P side: L of tile t+2 is the C operand of this body's first S k-step, MFMA 16 — read it in the first phase)
+            lw = cfg["lread_p"] if (P and self.kfold) else cfg["lread"]
+            sched.place(load, slots, self.stream_lread(par), lw[0], lw[1], 8)
         if P:
             # Q rows of tile t+2 (Q ring, running address) for phase B; dO^T of tile t+1 (dO ring slot par^1) for the next body's phase A
             if rr and "rowread" not in abl:
@@ -925,6 +935,29 @@ class GenDKV(BodyEmitter):
         p.emit("s_cmp_eq_u32", KV.A_ROLE, 1)
         p.emit("s_cbranch_scc1", Label("role_s"))
         p.emit("s_waitcnt", vmcnt=0)
+        if self.kfold:
+            # K fragments * (-scale*log2e), rounded once to the I/O dtype (64 accumulator registers, once per workgroup)
+            T = KV.TMP
+            for i in range(64):
+                areg = A(128 + i)
+                t0, t1 = T[2 * (i & 1)], T[2 * (i & 1) + 1]
+                p.emit("v_accvgpr_read_b32", t0, areg)
+                p.emit("s_nop", 0)
+                if self.bf16:
+                    p.emit("v_and_b32", t1, 0xffff0000, t0)
+                    p.emit("v_lshlrev_b32", t0, 16, t0)
+                else:
+                    p.emit("v_lshrrev_b32", t1, 16, t0)
+                    p.emit("v_cvt_f32_f16", t0, t0)
+                    p.emit("v_cvt_f32_f16", t1, t1)
+                p.emit("s_nop", 0)
+                p.emit("v_mul_f32", t0, Neg(KV.A_C), t0)
+                p.emit("v_mul_f32", t1, Neg(KV.A_C), t1)
+                p.emit("s_nop", 0)
+                p.emit(self.cvt, t0, t0, t1)
+                p.emit("s_nop", 0)
+                p.emit("v_accvgpr_write_b32", areg, t0)
+            p.emit("s_nop", 1)
         p.emit("s_barrier")
         self.role_code(0)
         p.emit("s_branch", Label("epilogue"))
@@ -1017,10 +1050,14 @@ def main():
         write_atomic(os.path.join(a.out, "fa2_bwd_dq_d128_%s.inc" % dt),
                      "// GENERATED by csrc/gen/bwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog, "fa2dq"))
         print("fa2_bwd_dq_d128_%s.inc" % dt, len(prog.ins), "instructions")
-        prog = GenDKV(bf16, **cfgs["dkv"]).build()
-        write_atomic(os.path.join(a.out, "fa2_bwd_dkv_d128_%s.inc" % dt),
-                     "// GENERATED by csrc/gen/bwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog, "fa2dkv"))
-        print("fa2_bwd_dkv_d128_%s.inc" % dt, len(prog.ins), "instructions")
+        for fold in (False, True):      # two dK / dV bodies per dtype: scale applied to the f32 scores / folded into the K fragments ("kfold"; host: option "fold")
+            c = dict(cfgs["dkv"])
+            c["opt"] = tuple(o for o in c.get("opt", ()) if o != "kfold") + (("kfold",) if fold else ())
+            prog = GenDKV(bf16, **c).build()
+            fn = "fa2_bwd_dkv_d128_%s%s.inc" % (dt, "_fold" if fold else "")
+            write_atomic(os.path.join(a.out, fn),
+                         "// GENERATED by csrc/gen/bwd_d128_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + render_inline(prog, "fa2dkv"))
+            print(fn, len(prog.ins), "instructions")
     write_atomic(os.path.join(a.out, "fa2_bwd_dq_d128_clobbers.inc"),
                  "// GENERATED by csrc/gen/bwd_d128_gen.py — do not edit.\n" + clobber_list(DQ.VBASE, DQ.CLOBBER_S) + "\n")
     write_atomic(os.path.join(a.out, "fa2_bwd_dkv_d128_clobbers.inc"),

@@ -277,10 +277,15 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     // that is not the hand-scheduled one writes +delta, so the two only go together
     if ((asm_parts & 2) && !(asm_parts & 1)) asm_parts = 0;
     const bool neg_delta = (asm_parts & 2) != 0;
+    // Option "fold" reaches the backward too: the hand-scheduled dK / dV pass then recomputes P from K * scale*log2(e) rounded once to the I/O dtype
+    // (the forward's folded contract on the other operand of Q.K^T) with L as the C operand of the product — 32 v_fma fewer per body on the wave role
+    // every body waits for.  Same guard as the forward: |scale * log2(e)| <= 1 keeps the prescaled K inside the dtype's range.
+    const int fopt = fa2::options().fold.load(std::memory_order_relaxed);
+    const bool kfold = (bf16 ? fopt >= 2 : fopt >= 1) && std::fabs(p.c) <= 1.0f;
     for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
         if (!(want & part)) continue;
         int rc;
-        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, stream);
+        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, kfold, stream);
         else rc = bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, part, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, part, stream);
         if (rc) return rc;
     }

@@ -43,11 +43,13 @@ def main():
     ap.add_argument("--modes", default="3,1")
     ap.add_argument("--parts", type=int, default=3)
     ap.add_argument("--libs", default="base")
+    ap.add_argument("--folds", default="", help="settings of option 'fold' to compare, e.g. 1,0 (default: leave the option alone)")
     ap.add_argument("--fill", default="rand", choices=["rand", "randn"])
     a = ap.parse_args()
     libs = {n: load(n) for n in a.libs.split(",")}
     modes = [int(x) for x in a.modes.split(",")]
-    arms = [(ln, m) for ln in libs for m in modes]
+    folds = [int(x) for x in a.folds.split(",") if x] or [None]
+    arms = [(ln, m, f) for ln in libs for m in modes for f in folds]
     dev = torch.device("cuda", 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     mk = torch.rand if a.fill == "rand" else torch.randn
@@ -67,8 +69,10 @@ def main():
         outs = {}
 
         def bwd(arm, parts):
-            ln, mode = arm
+            ln, mode, fold = arm
             lib = libs[ln]
+            if fold is not None:
+                lib.fa2_set_option(b"fold", fold)
             dq, dk, dv = outs.setdefault(arm, tuple(torch.zeros_like(q) for _ in range(3)))
             lib.fa2_set_option(b"asm", mode)
             lib.fa2_set_option(b"bwd_parts", parts)
@@ -92,6 +96,8 @@ def main():
                 torch.cuda.synchronize()
                 times[arm].append(e0.elapsed_time(e1) / a.iters)
         for lib in libs.values():
+            if folds != [None]:
+                lib.fa2_set_option(b"fold", 1)
             lib.fa2_set_option(b"asm", 3)
             lib.fa2_set_option(b"bwd_parts", 3)
         fwd_flops = 4.0 * B * H * N * N * D * (0.5 if causal else 1.0)
@@ -100,8 +106,8 @@ def main():
         for arm in arms:
             med = statistics.median(times[arm])
             diff = max(float((x.float() - y.float()).abs().max()) for x, y in zip(outs[arm], ref))
-            print("   %-10s asm=%-2d median %8.1f us  best %8.1f us  executed %6.1f TF  (reference convention, 2.5x fwd: %6.1f TF)   max|grad - grad[last arm]| %.2e"
-                  % (arm[0], arm[1], med * 1e3, min(times[arm]) * 1e3, GEMMS[a.parts] / 2 * fwd_flops / med / 1e9,
+            print("   %-10s asm=%-2d fold=%-4s median %8.1f us  best %8.1f us  executed %6.1f TF  (reference convention, 2.5x fwd: %6.1f TF)   max|grad - grad[last arm]| %.2e"
+                  % (arm[0], arm[1], arm[2], med * 1e3, min(times[arm]) * 1e3, GEMMS[a.parts] / 2 * fwd_flops / med / 1e9,
                      2.5 * fwd_flops / med / 1e9 if a.parts == 3 else float("nan"), diff))
 
 

@@ -369,7 +369,7 @@ const char* fa2_error_string(int code) {
     return "fa2: unknown error code";
 }
 
-const char* fa2_version(void) { return "fa2_gfx950 0.8 (D=128 forward + backward and D=64 causal forward: hand-scheduled 4-wave asm bodies; other head dims up to 512: HIP kernels; mfma32x32x16, lds-dma; KV-split tail rounds; attention bias / mask, forward + backward)"; }
+const char* fa2_version(void) { return "fa2_gfx950 0.9 (D=128 forward (sum-check fast bodies) + backward and D=64 forward: hand-scheduled 4-wave asm bodies; other head dims up to 512: HIP kernels; mfma32x32x16, lds-dma; KV-split tail rounds; attention bias / mask, forward + backward)"; }
 
 static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
                     int Nq, int Nkv, int D, const int64_t q_strides[3], const int64_t k_strides[3],

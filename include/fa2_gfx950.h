@@ -312,7 +312,9 @@ int fa2_fwd_prescales_q(int D, float scale);
    "fold"      FA2_FOLD       1 (default) | 0 | 2 — which launches of the hand-scheduled forward bodies fold scale*log2(e) into Q
                               (FA2_CONTRACT_PRESCALE_Q above): 0 none — every launch scales the f32 product like the reference kernel
                               (kernel_fp16.cu:164); 1 fp16 launches; 2 bf16 launches too.  Never when scale*log2(e) > 1 (the prescaled Q could
-                              leave the dtype's range).  This one changes the numerical contract, within the bounds stated there.
+                              leave the dtype's range).  This one changes the numerical contract, within the bounds stated there.  It reaches the
+                              backward too: under the same conditions the hand-scheduled dK / dV pass (head dim 128) recomputes P from
+                              K * scale*log2(e) rounded once to the I/O dtype — the same rounding on the other operand of Q.K^T.
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

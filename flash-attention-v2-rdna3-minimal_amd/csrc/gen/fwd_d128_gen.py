@@ -217,13 +217,18 @@ class Gen:
 
     # HD = 64: half the MFMAs per tile for the same softmax work, so the windows are those of a 32-gap body
     # (with the row sums on the matrix pipe: 24 PV-phase + 16 QK-phase MFMAs)
-    DEFAULTS64 = {"m": (1.0, 8.0), "e": (8.0, 40.0), "vread": (25.0, 32.0), "kread": (0.0, 14.0), "dma": (4.0, 18.0), "mmask": (1.0, 18.0)}
+    DEFAULTS64 = {"m": (1.0, 8.0), "e": (8.0, 40.0), "vread": (25.0, 32.0), "kread": (0.0, 14.0), "dma": (4.0, 18.0), "mmask": (1.0, 18.0),
+                  # ("nolmfma" probe bodies of 32 MFMAs: the sum-check windows of a 32-gap body)
+                  "se0": (0.0, 24.0), "se1": (4.0, 30.0), "sc0": (24.0, 29.0), "sc1": (30.0, 32.0)}
+    DEFAULTS64_NOLMFMA = {"m": (1.0, 6.0), "e": (6.0, 32.0), "vread": (17.0, 24.0), "kread": (0.0, 12.0), "dma": (3.0, 15.0), "mmask": (1.0, 14.0)}
 
     def __init__(self, bf16=False, hd=128, **cfg):
         self.g = Geo(hd)
         self.cfg = dict(self.DEFAULTS)
         if hd == 64:
             self.cfg.update(self.DEFAULTS64)
+            if "lmfma" not in cfg.get("opt", ()):
+                self.cfg.update(self.DEFAULTS64_NOLMFMA)
         for k, v in cfg.items():          # "d64_<key>": a schedule tunable of the head-dim-64 body only (window sweeps, tools/kbench.py)
             if k.startswith("d64_"):
                 if hd == 64:
@@ -248,11 +253,14 @@ class Gen:
             self.vf = VF_ACC
             self.qf = QF_SPLIT if self.ct else QF_ARCH
         # "lmfma": the row sums ride the matrix pipe — one more accumulator tile per q block whose row 0 is sum_kv P (A = ONESF): the 64
-        # v_add_f32 per tile go, 8 MFMAs come.  Default at head dim 64, where the body is VALU-bound (32 MFMAs per tile for the same
+        # v_add_f32 per tile go, 8 MFMAs come.  Rounds 2-3: the default at head dim 64, where the body is VALU-bound (32 MFMAs per tile for the same
         # softmax work as at 128); at 128 the round-2 measurement of the idea in the 8-wave kernel was -3 %.
-        self.lmfma = ("lmfma" in self.opt) or (hd == 64 and "nolmfma" not in self.opt)
+        # Round 4: no longer the default anywhere.  With the sum-check bodies the 64 adds double as the overflow check and replace the 44-instruction
+        # row-max stream, and on a power-limited chip 8 MFMAs cost what ~180 VALU instructions do: head dim 64, fp16 B2 H16 N4096
+        # 1 029 -> 1 059 TF against the lmfma + max-first body (profiles/r13_kbench_d64_sumcheck_ab.txt); opt=lmfma builds the old body.
+        self.lmfma = "lmfma" in self.opt
         # "sum check" fast bodies (default at head dim 128; opt=maxfirst keeps the row-max stream everywhere): see stream_exp_sum
-        self.sumchk = hd == 128 and not self.lmfma and "maxfirst" not in self.opt
+        self.sumchk = not self.lmfma and "maxfirst" not in self.opt
         self.lacc = lambda qb: A(g.LA0 + 16 * qb, 16)
         self.npv = 8 * g.NDT + (8 if self.lmfma else 0)   # MFMAs of the PV phase (both q blocks) ...
         self.nqk = 4 * g.NKS              # ... and of the QK phase
@@ -355,15 +363,21 @@ class Gen:
                 E.append(mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans"))
             if 1 <= k - 2 < 16:                               # stage 2: the tile's two sum chains (pair 0 enters with pair 1)
                 e = 2 * (k - 2)
-                if k - 2 == 1:
+                if "pkadd" in self.opt:                       # probe: both chains in one packed add (same sums, same order: bit-identical results)
+                    tp = V(ta.idx, 2)
+                    Ad.append(mk("v_pk_add_f32", tp, b.sub(0, 2) if k - 2 == 1 else tp, b.sub(e, 2), tag="valu"))
+                elif k - 2 == 1:
                     Ad.append(mk("v_add_f32", ta, b[0], b[2], tag="valu"))
                     Ad.append(mk("v_add_f32", tb, b[1], b[3], tag="valu"))
                 else:
                     Ad.append(mk("v_add_f32", ta, ta, b[e], tag="valu"))
                     Ad.append(mk("v_add_f32", tb, tb, b[e + 1], tag="valu"))
             out += F + E + Ad
-        out.append(mk("v_add_f32", LA[qb], LA[qb], ta, tag="valu"))
-        out.append(mk("v_add_f32", LB[qb], LB[qb], tb, tag="valu"))
+        if "pkadd" in self.opt:
+            out.append(mk("v_pk_add_f32", LSUM[qb], LSUM[qb], V(ta.idx, 2), tag="valu"))
+        else:
+            out.append(mk("v_add_f32", LA[qb], LA[qb], ta, tag="valu"))
+            out.append(mk("v_add_f32", LB[qb], LB[qb], tb, tag="valu"))
         out.append(mk("v_add_f32", ts, ta, tb, tag="valu"))
         lab = self.p.fresh("rare_s")
         # not (limit >= sum): also true for a NaN sum (the literal has to be src0 of a VOPC).  (a list inside a stream is an atomic group: the branch and its return label stay together)
@@ -778,8 +792,8 @@ class Gen:
                 x.op == "s_cbranch_vccnz" and x.ops[0].name == lab for x in it)]
             assert len(gap) == 1, (lab, gap)
             # PV(t) of this q block (MFMAs 16 qb .. 16 qb + 15) must be issued: the rare block rescales its accumulators
-            assert gap[0] >= 16 * qb + 15, "sum check of q block %d in gap %d: its PV MFMAs are not all issued" % (qb, gap[0])
-            self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= 32 + 2 * qb))
+            assert gap[0] >= (self.npv // 2) * (qb + 1) - 1, "sum check of q block %d in gap %d: its PV MFMAs are not all issued" % (qb, gap[0])
+            self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= self.npv + 2 * qb))
             self.check_gaps = getattr(self, "check_gaps", {})
             self.check_gaps[(name, qb)] = gap[0]
         # emit: gap g fillers come AFTER mfma g

@@ -152,7 +152,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     const bool d64_asm = HD == 64 && (causal || fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
     if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
         asm_kv_len_ok(HD, bf16, p, causal))
-        return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (HD == 64 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold};
+        return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0), 256, fold};
     return {rows == 256 ? FA2_KERNEL_HIP_256 : FA2_KERNEL_HIP_128, 0, rows, false};
 }
 
@@ -207,7 +207,7 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             f.split = pl;
             f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
             const bool fold = f.split_asm && asm_folds(bf16, p);
-            f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (HD == 64 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}
+            f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0), 256, fold}
                                  : RangePlan{FA2_KERNEL_HIP_256, 0, 256, false};
             return f;
         }

@@ -123,7 +123,9 @@ D64_CASES = [
     (200, 333, 0, False, False, False),
     (512, 512, 1, True, False, False),
     (256, 77, 0, True, True, False),
-    (256, 704, 0, False, False, True),        # the rescale branch: the row-sum accumulators are rescaled with O
+    (256, 704, 0, False, False, True),        # hard spikes: the sum-check bodies (head dim 64 too since 0.9: f32 row sums, no lmfma) meet P = inf -> safe-mode redo
+    (256, 704, 0, False, False, 2),           # moderate spikes: repaired in place
+    (256, 704, 0, False, True, 3),            # growth of 121 .. 126.6 octaves: redo
 ]
 
 
@@ -144,8 +146,9 @@ def test_generated_d64_block_matches_dense_attention(case, hd64):
     nq, nkv, qblk, causal, bf16, spike = case
     err, lse_err, m = harness.check(nq, nkv, qblk, causal, bf16=bf16, spike=spike, seed=nq + nkv, verbose=False)
     assert not m.errors, m.errors[:5]
-    assert err <= (6e-3 if bf16 else (2e-3 if spike else 1e-3)), err
-    assert lse_err <= (4e-3 if bf16 else 1e-3), lse_err          # (the sums add the ROUNDED P: 2^-9 / 2^-11 relative noise per term)
+    assert err <= ((1.6e-2 if spike else 6e-3) if bf16 else (3e-3 if spike else 1e-3)), err
+    assert lse_err <= 1e-4, lse_err                                # (f32 row sums since 0.9; the lmfma bodies of 0.8 summed the ROUNDED P: 4e-3 / 1e-3)
+    assert m.redos == (1 if spike in (True, 3) else 0), m.redos
 
 
 def test_d64_persistent_items_and_causal_pairs(hd64):

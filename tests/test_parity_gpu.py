@@ -313,9 +313,9 @@ def test_large_logits_and_forced_rescale(D):
         _assert_close_to_oracle(o, lse, q, k, v, 0, False)
 
 
-@pytest.mark.parametrize("dt,causal", [(0, False), (1, False), (0, True)])
+@pytest.mark.parametrize("dt,causal,D", [(0, False, 128), (1, False, 128), (0, True, 128), (0, False, 64), (1, True, 64)])
 @pytest.mark.parametrize("kind", ["repair", "redo"])
-def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind):
+def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, D, kind):
     """The fast bodies of the hand-scheduled head-dim-128 kernels keep no running row maximum: a lane's row sum of a tile proves that no P of the
     tile overflows, and the reference moves, out of line, only when that check fails (csrc/gen/fwd_d128_gen.py: stream_exp_sum / rare_sum).
       repair  a key row raises some rows' scores 15 .. 127 log2 units above everything before it, late in the sweep: the reference is moved in
@@ -325,8 +325,12 @@ def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind
               (prefetched) items and items with a successor.
     Both against float64 attention and the oracle under the planned contract (tests/test_asm_emu.py emulates the same two paths instruction by instruction)."""
     B, H, N = (1, 33, 2048) if causal else (1, 66, 1024)    # 264 items of 256 rows on 256 CUs (causal: the hand-scheduled kernel from 1792 keys)
-    g = torch.Generator(device="cpu").manual_seed(700 + dt + 2 * causal)
-    q, k, v = (torch.randn((B, H, N, 128), generator=g) for _ in range(3))
+    if D == 64 and not causal:
+        H = 100                                             # (head dim 64 runs 128-row workgroups between 1 and 1.5 rounds: 400 items)
+    g = torch.Generator(device="cpu").manual_seed(700 + dt + 2 * causal + D)
+    q, k, v = (torch.randn((B, H, N, D), generator=g) for _ in range(3))
+    if D == 64:
+        q = q * 2 ** 0.5                                    # (the same logit statistics as at head dim 128: |q|^2 * scale = sqrt(D))
     if kind == "repair":
         k[:, :, 200] = q[:, :, 5] * 2.7
         k[:, :, 300] = q[:, :, 40] * 2.7
@@ -343,7 +347,7 @@ def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind
     q, k, v = (t.to(TORCH_DT[dt]) for t in (q, k, v))
     if kind == "redo":
         # growth of exactly 126.5 octaves over the row's tile-0 maximum: past what the in-place repair may take on (2^120), short of f32's range
-        c = 128 ** -0.5 * fo.LOG2E
+        c = D ** -0.5 * fo.LOG2E
         for h in range(0, H, 5):
             for row, kv in ((300, 520), (77, 333)):
                 qr = q[0, h, row].double()
@@ -354,11 +358,11 @@ def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind
     assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.heads_main == B * H, plan.as_dict()
     o, lse = _cabi_forward(q, k, v, causal)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
-    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * 128 ** -0.5          # every head against dense fp32 attention (coarse), sampled heads below
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * D ** -0.5          # every head against dense fp32 attention (coarse), sampled heads below
     if causal:
         s = s.masked_fill(torch.ones(N, N, dtype=torch.bool, device=_dev()).triu(1), float("-inf"))
     dense = torch.matmul(torch.softmax(s, -1), v.float())
-    assert float((o.float() - dense).abs().max()) <= (0.1 if kind == "redo" else 2e-2), float((o.float() - dense).abs().max())
+    assert float((o.float() - dense).abs().max()) <= (0.1 if kind == "redo" else (4e-2 if dt else 2e-2)), float((o.float() - dense).abs().max())
     del s, dense
     o2, lse2 = _cabi_forward(q, k, v, causal)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)            # the redo is deterministic too
@@ -374,7 +378,9 @@ def test_sum_check_bodies_repair_in_place_and_redo_in_safe_mode(dt, causal, kind
         o_true, lse_true = fo.fwd_numpy(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), causal)
         got = o[sl].float().cpu().numpy()
         folded = plan.contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q
-        o_tol = (3e-2 if folded and kind == "redo" else 4e-3) if dt == 0 else 3e-2
+        # (against float64 the folded contract's one rounding of Q shows in proportion to the logits: 60 .. 600 log2 units here — the same-contract
+        #  oracle above holds the usual tolerance; at head dim 64 this test's logits are sqrt(2) larger)
+        o_tol = ((6e-2 if kind == "redo" else 1e-2) if folded else 4e-3) if dt == 0 else 3e-2
         assert np.all(np.abs(got - o_true) <= o_tol + 4e-3 * np.abs(o_true)), (h, float(np.abs(got - o_true).max()))
         assert np.abs(lse[sl].cpu().numpy() - lse_true).max() <= ((0.3 if folded else 2e-2) if kind == "redo" else 2e-2), h
 
@@ -784,7 +790,7 @@ def test_tail_split_launches_cover_every_head(shape):
     plan = _plan(q, k, False)
     if shape == (2, 17, 4096, 64):          # 544 workgroups: two full rounds of the hand-scheduled body + the last 2 heads as 128-row workgroups
         assert plan.heads_main == 32 and plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.kernel_tail == _fa2_lib.FA2_KERNEL_HIP_128
-        assert plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16 and plan.contract_tail == 0
+        assert plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q and plan.contract_tail == 0
     for (b, h) in {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2)}:
         sl = (slice(b, b + 1), slice(h, h + 1))
         _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False, plan=plan, head=b * H + h)
@@ -940,7 +946,7 @@ def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
     assert lib.fa2_fwd_prescales_q(64, 0.125) == 1
     B, H, N, D = 2, 16, 2048, 64                         # 256 workgroups of 256 rows: the hand-scheduled body
     pl = _fa2_lib.fwd_plan(torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), False)
-    assert pl.kernel == _fa2_lib.FA2_KERNEL_ASM and pl.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16
+    assert pl.kernel == _fa2_lib.FA2_KERNEL_ASM and pl.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
     for amp, o_tol, lse_tol in ((1.0, 1e-3, 1e-3), (3.0, 3e-2, 0.3)):
         g = torch.Generator(device="cpu").manual_seed(int(amp * 10))
         q = (torch.randn((B, H, N, D), generator=g) * amp).half().to(_dev())
@@ -949,7 +955,7 @@ def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
         o, lse = _cabi_forward(q, k, v, False)
         for (b, h) in ((0, 0), (1, 15)):
             sl = (slice(b, b + 1), slice(h, h + 1))
-            o_ref_bits, lse_ref = fo.fwd_c(_bits(q[sl]), _bits(k[sl]), _bits(v[sl]), 0, False, flags=fo.PRESCALE_Q | fo.LSUM_P16)
+            o_ref_bits, lse_ref = fo.fwd_c(_bits(q[sl]), _bits(k[sl]), _bits(v[sl]), 0, False, flags=fo.PRESCALE_Q)
             o_ref = fo.bits_to_f32(o_ref_bits, 0)
             got = o[sl].float().cpu().numpy()
             assert np.all(np.abs(got - o_ref) <= ATOL[0] + RTOL[0] * np.abs(o_ref)), np.abs(got - o_ref).max()

@@ -28,6 +28,8 @@ CFGS = {
     "b8": (8, 16, 4096, 128, "f16", False),
     "d64": (2, 16, 4096, 64, "f16", False),
     "d64c": (2, 16, 4096, 64, "bf16", True),
+    "d64b": (2, 16, 4096, 64, "bf16", False),
+    "d64h": (1, 24, 5120, 64, "f16", False),
     "d256": (2, 16, 2048, 256, "f16", False),
     "d256c": (2, 16, 2048, 256, "bf16", True),
     "n2k": (4, 16, 2048, 128, "f16", False),

@@ -1,3 +1,6 @@
+"""One planted key per row gives it a log2 score of 20, 24, ... 136 late in the sweep (developer probe): which growth of the reference do the sum-check
+bodies of the hand-scheduled forward survive?  Prints, per target, the finite heads and the errors against float64 (found the f32 edge at 126 .. 128).
+    python tools/growth_scan.py"""
 import sys, os
 import torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))

@@ -1,3 +1,6 @@
+"""Sum-check bodies on 3x-amplitude inputs (developer probe): every head of a 66-head call against dense fp32 attention, under several options —
+finds rows the in-place repair or the safe-mode redo gets wrong (round 4: the rows that grew by 126 .. 127 octaves; profiles/r12_redo_probe_after_fix.txt).
+    python tools/redo_probe.py"""
 import sys, os, ctypes
 import torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))

@@ -193,7 +193,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
         lim[kvb] = CAUSAL ? kvrow - kBwdTile * tile0 - 4 * hi : -(1 << 30);
     }
     const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
-    const uint32_t qd0 = drow * q_rowb + ((dslot ^ bwd_swz(drow)) << 4), gd0 = drow * g_rowb + ((dslot ^ bwd_swz(drow)) << 4);
+    const uint32_t gd0 = drow * g_rowb + ((dslot ^ bwd_swz(drow)) << 4);
+#ifdef FA2_BWD_QSPLIT     // (bodies generated with option "qsplit": of a pair's four Q pieces the P side stages row quad 0, the dS side quads 1..3)
+    const uint32_t qrow0 = 16u * pair + (role ? 4u : 0u);
+#else
+    const uint32_t qrow0 = 8u * wave;
+#endif
+    const uint32_t qdrow = qrow0 + (lane >> 4);
+    const uint32_t qd0 = qdrow * q_rowb + ((dslot ^ bwd_swz(qdrow)) << 4);
     const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
     const uint32_t vr0 = trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
@@ -211,13 +218,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
     const float c = p.c, oscale = role ? p.scale : 1.0f;
     const uint32_t qoff0 = (uint32_t)tile0 * kBwdTile * q_rowb, goff0 = (uint32_t)tile0 * kBwdTile * g_rowb, loff0 = (uint32_t)tile0 * 128u;
     const uint32_t q_tile = kBwdTile * q_rowb, g_tile = kBwdTile * g_rowb, q_row4 = 4 * q_rowb - 1024, g_row4 = 4 * g_rowb - 1024;
-    const uint32_t ldsw = wave * 2048;
+    const uint32_t ldsw = wave * 2048, ldswq = __builtin_amdgcn_readfirstlane(qrow0 * 256u);
 
 #define FA2_BWD_KV_OPERANDS                                                                                                       \
     :                                                                                                                             \
     : "v"(fo[0]), "v"(fo[1]), "v"(qd0), "v"(gd0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(pxa), "v"(lda), "v"(l4), "v"(epi), \
       "s"(fbase), "s"(qrs), "s"(grs), "s"(lrs), "s"(c), "s"(oscale), "s"(n), "s"(qoff0), "s"(goff0), "s"(loff0), "s"(q_tile),     \
-      "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role), "s"(ldm0)                                                      \
+      "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role), "s"(ldm0), "s"(ldswq)                                          \
     :
     if constexpr (BF16 && KFOLD) {
         asm volatile(

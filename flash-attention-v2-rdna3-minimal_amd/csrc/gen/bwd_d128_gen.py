@@ -544,7 +544,8 @@ class KV:
     A_LDSW = Arg(26, "s")                          # wave * 2048: this wave's quarter of a tile image
     A_ROLE = Arg(27, "s")                          # 0: P side, 1: dS side
     A_LDM0 = Arg(28, "s")                          # pair 0 only (its waves stage L / -delta for the workgroup): LDS address of the role's array, parity 0; 0 = this wave does not
-    N_ARGS, N_VARGS = 29, 12
+    A_LDSWQ = Arg(29, "s")                         # LDS offset of the rows of a Q tile this wave stages (= A_LDSW unless the Q pieces are split by role: "qsplit")
+    N_ARGS, N_VARGS = 30, 12
     VBASE = 16
 
     @staticmethod
@@ -566,7 +567,7 @@ class KV:
     KR = [V(176 + i) for i in range(8)]            # row read addresses (P side: Q ring, moves every body; dS side: dO ring, static)
     VR = [V(184 + i) for i in range(4)]            # transposed read addresses, rows +0..3 (P side: dO ring, static; dS side: Q ring, moves)
     VRB = [V(188 + i) for i in range(4)]           # ... rows +8..11
-    QD = [V(192), V(193)]                          # LDS-DMA source offsets of this wave's 2 pieces of a Q tile
+    QD = [V(192), V(193), V(223)]                  # LDS-DMA source offsets of this wave's pieces of a Q tile (2; "qsplit": 1 on the P side, 3 on the dS side)
     GD = [V(194), V(195)]                          # ... dO tile
     PR = V(196, 16)                                # dS side: the pair's packed P words of a tile
     LIMT = [V(212), V(213)]                        # P side, masked bodies: the limit relative to the tile
@@ -607,6 +608,9 @@ class GenDKV(BodyEmitter):
         # the tile's L as the C operand of the first k-step: the matrix pipe delivers L - S c, P = 2^-(that) is ONE v_exp_f32 with a negated source.
         # The 32 v_fma_f32 per body go; the P side is the role every body waits for (it alone carries the 32 transcendentals).
         self.kfold = "kfold" in self.opt
+        # "qsplit": of the four 1-KiB pieces of a Q tile a wave pair stages, the P side takes one and the dS side three (dO stays two and two):
+        # LDS-DMA pieces are the dearest fillers (~60 issue cycles each) and the P side is the heavier role
+        self.qsplit = "qsplit" in self.opt
 
     # ------------------------------------------------------------------ MFMA lists (shared shapes, role-specific operands)
     def acc_mfmas(self, par):
@@ -695,11 +699,11 @@ class GenDKV(BodyEmitter):
                 out.append(mk("ds_read_b64_tr_b16", KV.TP(dt, ks).sub(2, 2), KV.VRB[dt], tag="lds", offset=base + (16 * ks + 8) * 256))
         return out
 
-    def stream_dma(self, par):
+    def stream_dma(self, par, P=True):
         """Q(t+3) -> Q ring slot (t+3) % 4 (M0 from the running slot counter), dO(t+2) -> dO ring slot t % 2 = par; pair 0's waves also
         stage the 32 L / -delta values of tile t+3 (one 4-byte-per-lane piece; lanes 32..63 bring the next tile's, which nobody reads)."""
         out = [[mk("s_mov_b32", M0, KV.S_M0Q, tag="salu"), mk("s_nop", 0, tag="salu")]]
-        for i in range(2):
+        for i in range((1 if P else 3) if self.qsplit else 2):
             out.append(mk("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, tag="dma", offen=True, offset=1024 * i, lds=True))
         out.append([mk("s_add_u32", M0, KV.A_LDSW, KV.G_RING + par * KV.SLOT, tag="salu"), mk("s_nop", 0, tag="salu")])
         for i in range(2):
@@ -741,7 +745,7 @@ class GenDKV(BodyEmitter):
                 pre.append(mk("s_lshl_b32", KV.S_TMP, KV.S_TMP, 5))
                 pre.append(mk("v_subrev_u32", KV.LIMT[kvb], KV.S_TMP, KV.A_LIM0 if kvb == 0 else KV.A_LIM1))
         if "dma" not in abl:
-            sched.place(load, slots, self.stream_dma(par), cfg["dma"][0], cfg["dma"][1], 2)
+            sched.place(load, slots, self.stream_dma(par, P), cfg["dma"][0], cfg["dma"][1], 2)
             # (kfold, P side: L of tile t+2 is the C operand of this body's first S k-step, MFMA 16 — read it in the first phase)
             lw = cfg["lread_p"] if (P and self.kfold) else cfg["lread"]
             sched.place(load, slots, self.stream_lread(par), lw[0], lw[1], 8)
@@ -776,7 +780,7 @@ class GenDKV(BodyEmitter):
                mk("s_sub_u32", KV.S_BUMP, KV.SLOT, KV.S_BUMP, tag="salu"),
                # the DMA slot runs one ahead of the P side's row-read slot
                mk("s_add_u32", KV.S_TMP2, KV.S_QSLOT, 1, tag="salu"), mk("s_and_b32", KV.S_TMP2, KV.S_TMP2, 3, tag="salu"),
-               mk("s_lshl_b32", KV.S_TMP2, KV.S_TMP2, 13, tag="salu"), mk("s_add_u32", KV.S_M0Q, KV.S_TMP2, KV.A_LDSW, tag="salu")]
+               mk("s_lshl_b32", KV.S_TMP2, KV.S_TMP2, 13, tag="salu"), mk("s_add_u32", KV.S_M0Q, KV.S_TMP2, KV.A_LDSWQ, tag="salu")]
         moving = KV.KR if P else KV.VR + KV.VRB
         bk2 = [mk("v_add_u32", r, KV.S_BUMP, r, tag="valu") for r in moving]
         if "bk" in abl:
@@ -904,18 +908,35 @@ class GenDKV(BodyEmitter):
         # DMA source offsets of piece 1: rows 4 further down flip bit 0 of the unified granule swizzle
         p.emit("v_mov_b32", KV.QD[0], KV.A_QD0)
         p.emit("v_mov_b32", KV.GD[0], KV.A_GD0)
-        p.emit("v_xor_b32", KV.QD[1], 16, KV.A_QD0)
+        if self.qsplit:
+            # dS side: its Q pieces are the row quads 1, 2, 3 of the pair's 16 rows — the unified swizzle's (row >> 2) & 3 term goes 1 -> 2 -> 3
+            p.emit("v_xor_b32", KV.QD[1], 0x30, KV.A_QD0)
+            p.emit("v_xor_b32", KV.QD[2], 0x20, KV.A_QD0)
+        else:
+            p.emit("v_xor_b32", KV.QD[1], 16, KV.A_QD0)
         p.emit("v_xor_b32", KV.GD[1], 16, KV.A_GD0)
         p.emit("v_mov_b32", KV.XA, KV.A_PXA)
         p.emit("v_add_u32", KV.QD[1], KV.A_QROW4, KV.QD[1])
         p.emit("v_add_u32", KV.GD[1], KV.A_GROW4, KV.GD[1])
+        if self.qsplit:
+            p.emit("v_add_u32", KV.QD[2], KV.A_QROW4, KV.QD[2])
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", KV.QD[2], KV.A_QROW4, KV.QD[2])
         p.emit("s_mov_b32", KV.S_T, -2)
         p.emit("s_mov_b32", KV.S_QOFF, KV.A_QOFF0)
         # Q(0) -> Q ring slot 0
-        p.emit("s_add_u32", M0, KV.A_LDSW, KV.Q_RING)
+        p.emit("s_add_u32", M0, KV.A_LDSWQ, KV.Q_RING)
         p.emit("s_nop", 0)
-        for i in range(2):
-            p.emit("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, offen=True, offset=1024 * i, lds=True)
+        if self.qsplit:
+            p.emit("buffer_load_dwordx4", KV.QD[0], KV.A_QRS, KV.S_QOFF, offen=True, offset=0, lds=True)
+            p.emit("s_cmp_eq_u32", KV.A_ROLE, 1)
+            p.emit("s_cbranch_scc0", Label("q0_one"))
+            for i in (1, 2):
+                p.emit("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, offen=True, offset=1024 * i, lds=True)
+            p.label("q0_one")
+        else:
+            for i in range(2):
+                p.emit("buffer_load_dwordx4", KV.QD[i], KV.A_QRS, KV.S_QOFF, offen=True, offset=1024 * i, lds=True)
         p.emit("s_mov_b32", KV.S_LOFF, KV.A_LOFF0)
         p.emit("s_cmp_eq_u32", KV.A_LDM0, 0)
         p.emit("s_cbranch_scc1", Label("no_ld0"))
@@ -929,7 +950,7 @@ class GenDKV(BodyEmitter):
         p.emit("s_mov_b32", KV.S_GOFF, KV.A_GOFF0)
         p.emit("s_add_u32", KV.S_LOFF, KV.S_LOFF, 128)
         p.emit("s_mov_b32", KV.S_QSLOT, 0)
-        p.emit("s_add_u32", KV.S_M0Q, KV.A_LDSW, KV.Q_RING + KV.SLOT)
+        p.emit("s_add_u32", KV.S_M0Q, KV.A_LDSWQ, KV.Q_RING + KV.SLOT)
         for i in range(128):
             p.emit("v_accvgpr_write_b32", A(i), 0)
         p.emit("s_cmp_eq_u32", KV.A_ROLE, 1)

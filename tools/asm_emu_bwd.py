@@ -16,6 +16,7 @@ from isa import Reg  # noqa: E402
 LOG2E = 1.4426950408889634
 DQ = gen.DQ
 _PROGS = {}
+QSPLIT = False          # mirror of the shell's -DFA2_BWD_QSPLIT (programs built with opt "qsplit")
 
 
 def program(kind, bf16):
@@ -180,6 +181,11 @@ def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
         v[6 + kvb] = lim.astype(np.int32).view(np.uint32)
     drow, dslot = 8 * w + (lane >> 4), lane & 15
     v[2] = v[3] = (drow * rb + ((dslot ^ gen.f_swz(drow)) << 4)).astype(np.uint32)
+    qrow0 = 8 * w
+    if QSPLIT:            # the Q pieces split by role: the P side stages row quad 0 of the pair's 16 rows, the dS side quads 1..3
+        qrow0 = 16 * pair + (4 if role else 0)
+        drow = qrow0 + (lane >> 4)
+        v[2] = (drow * rb + ((dslot ^ gen.f_swz(drow)) << 4)).astype(np.uint32)
     v[4] = (l31 * 256 + ((hi ^ gen.f_swz(l31)) << 4)).astype(np.uint32)
     i, j = pp >> 2, pp & 3
     trow = 4 * hi + i
@@ -203,6 +209,7 @@ def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
     args[26] = w * 2048
     args[27] = role
     args[28] = (KV.LD_BASE + role * 512) if pair == 0 else 0
+    args[29] = qrow0 * 256
     args["vregs"] = v
     return args
 

@@ -281,3 +281,23 @@ def test_option_fold_switches_the_contract_and_nothing_else():
     assert lib.fa2_get_option(b"fold") == 1 and lib.fa2_set_option(b"fold", 3) < 0
     p = _meta_plan(2, 16, 4096, 4096, 128)
     assert p.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+
+
+def test_plan_struct_in_the_header_matches_the_ctypes_structure():
+    """fa2_fwd_plan_t is the one struct of the C-ABI: its fields, their order and the FA2_KERNEL_* / FA2_CONTRACT_* values in include/fa2_gfx950.h
+    must be what rocwmma_fattn/_fa2_lib.py binds (all fields are `int`)."""
+    import re
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct fa2_fwd_plan_t \{(.*?)\} fa2_fwd_plan_t;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            assert decl.startswith("int "), decl
+            fields += [f.strip() for f in decl[4:].split(",")]
+    assert fields == [n for n, _ in _fa2_lib.FwdPlan._fields_]
+    consts = dict(re.findall(r"#define\s+(FA2_(?:KERNEL|CONTRACT)_\w+)\s+(\d+)", text))
+    for name, val in consts.items():
+        assert getattr(_fa2_lib, name) == int(val), name
+    assert set(consts) == {"FA2_KERNEL_HIP_256", "FA2_KERNEL_HIP_128", "FA2_KERNEL_ASM", "FA2_KERNEL_HIP_BIAS", "FA2_CONTRACT_PRESCALE_Q", "FA2_CONTRACT_LSUM_P16"}

@@ -586,7 +586,8 @@ class KV:
     S_NFAST, S_D, S_QSLOT, S_BUMP, S_M0Q = S(66), S(67), S(68), S(69), S(70)
     CLOBBER_S = list(range(60, 72))
 
-    # (LDS-DMA destinations must lie below 64 KiB: M0 carries a 16-bit LDS address; the P slots are written by ds_write and sit above)
+    # (the rings were laid out below 64 KiB on the assumption that M0 carries a 16-bit LDS address; tools/ubench/lds_dma_hi.hip, round 4, shows
+    #  LDS-DMA landing anywhere in the 160 KiB — the layout stays, the limit is not real; the P slots are written by ds_write and sit above)
     Q_RING, G_RING, LD_BASE, P_SLOTS, SLOT = 0, 32768, 49152, 65536, 8192      # LD_BASE: L[2 parities][64 floats] at +0, -delta likewise at +512
     EPI_ROWB = 272
     LDS_BYTES = 65536 + 16384                      # 81920 (the epilogue image, 4 x 64 rows of 272 B from 0, reuses the rings, which are dead by then)

@@ -117,7 +117,8 @@ S_FIX = S(68)                                        # sum-check bodies, folded 
 S_TA, S_TB, S_TC = S(74, 2), S(76, 2), S(78, 2)      # "trace" builds: s_memtime samples (body start, phase boundary, body end)
 S_SUM = [S(80), S(81), S(82), S(83)]                 # cycle sums over the fast bodies: PV phase, QK phase, barrier, bodies
 S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, first main body, epilogue start, block end
-CLOBBER_S = list(range(60, 94))
+S_MARKH = [S(94, 2), S(96, 2)]                        # trace 5 / 6: past the entry barrier, past the first head body
+CLOBBER_S = list(range(60, 98))
 CLOBBER_V = list(range(VBASE, 256))
 
 
@@ -1043,9 +1044,13 @@ class Gen:
             p.emit("s_waitcnt", vmcnt=g.NP)
             p.label("waited")
         p.emit("s_barrier")
+        if tr:
+            p.emit("s_memtime", S_MARKH[0])
 
         # ---- head bodies: t = -2 (parity 0): QK(0) only; t = -1 (parity 1): softmax of tile 0, QK(1) if there is a tile 1
         self.body(0, pv=False, s1=False, s2=True, name="H1", dma=False)
+        if tr:
+            p.emit("s_memtime", S_MARKH[1])
         p.emit("s_cmp_eq_u32", A_NTW, 1)
         p.emit("s_cbranch_scc1", Label("h2b"))
         self.body(1, pv=False, s1=True, s2=True, name="H2", first=True)
@@ -1181,6 +1186,14 @@ class Gen:
             elif tr == 3:    # entry -> first main body, epilogue
                 p.emit("s_sub_u32", S_TMP, S_MARK[1][0], S_MARK[0][0])
                 p.emit("s_sub_u32", S_TMP2, S_MARK[3][0], S_MARK[2][0])
+                a, b = S_TMP, S_TMP2
+            elif tr == 5:    # entry -> past the entry barrier, that barrier -> end of the first head body
+                p.emit("s_sub_u32", S_TMP, S_MARKH[0][0], S_MARK[0][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARKH[1][0], S_MARKH[0][0])
+                a, b = S_TMP, S_TMP2
+            elif tr == 6:    # second head body, tail bodies (main bodies minus ... see trace 4 / 1)
+                p.emit("s_sub_u32", S_TMP, S_MARK[1][0], S_MARKH[1][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARK[2][0], S_MARK[1][0])
                 a, b = S_TMP, S_TMP2
             else:            # whole block, main bodies (fast + tail)
                 p.emit("s_sub_u32", S_TMP, S_MARK[3][0], S_MARK[0][0])

@@ -25,9 +25,16 @@ rule): scatter_batch of q/k/v and gather_batch of o (rocwmma_fattn/shard.py).
 `--backend gloo --same-device` runs the multi-rank control flow with every rank on cuda:0 (NCCL
 refuses duplicate devices): the dry run the 1-GPU test suite uses; its numbers are not a scaling claim.
 
+Default workload: c2 with one rank; with N > 1 ranks and no --workload the run measures c5 — BASELINE.json's multi-GPU
+configuration (B = 64 split over the ranks, strong scaling) — as `value`, and then the c2 weak-scaling figure (every rank its own
+B2 shard) under the separate key `weak_c2`.
+
 Rank 0 prints ONE JSON line.
   value        whole-job TFLOPS: all ranks' FLOPs / max-over-ranks wall time of the K steps, bracketed
-               by barrier + synchronize (contract).
+               by barrier + synchronize (contract).  Measured AFTER the settle phase (below); `warmup` is the W of the command line,
+               `warmup_effective` every launch of the operator that preceded the timed region (gate + cold region + settle + W).
+  cold         the same W warm-up + K timed steps run straight after the parity gate, BEFORE any settling — the protocol of rounds 1-3
+               (and of a harness that only knows W): {"value", "ms_per_step", "kernel_ms"}; compare rounds on this key or on `steady`.
   sequence     what the process does, in order (also in the JSON line): parity gate -> settle -> W warm-up + K
                timed steps (the contract) -> K launches with per-launch events -> steady re-timing ->
                informational backward -> CPU baseline.  The timed region carries no event between launches (one costs
@@ -152,7 +159,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)   # past the DVFS ramp-up after idle
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default: c2 with one rank; c5 (+ the c2 weak-scaling figure under `weak_c2`) with --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-launches", type=int, default=400, help="launches of the post-region steady re-timing (0 = skip)")
     ap.add_argument("--collectives", action="store_true", help="also time scatter_batch / gather_batch (reported separately)")
@@ -219,109 +227,148 @@ def main():
 
     from rocwmma_fattn.FlashAttn import FlashAttentionFunction
     from rocwmma_fattn.shard import gather_batch, scatter_batch, shard_bounds
-
-    B, H, N, D, dtype, causal, scaling = WORKLOADS[args.workload]
-    if scaling == "strong":
-        lo, hi = shard_bounds(B, world, rank)
-        B_local, B_global = hi - lo, B
-    else:
-        B_local, B_global = B, B * world
-    cfg_idx = sorted(WORKLOADS).index(args.workload) + 1
-    g = torch.Generator(device=device).manual_seed(1234 + cfg_idx + rank)
-    q, k, v = (torch.rand((B_local, H, N, D), generator=g, device=device, dtype=torch.float32).to(dtype)
-               for _ in range(3))
     attn = FlashAttentionFunction.apply
 
-    # ---- parity gate BEFORE anything is timed: every (batch, head) of one forward call (a strided sample of 64 when there are
-    #      more) against dense fp32 attention on the GPU.  (Side effect, stated plainly: the chip has been busy for some tens of
-    #      milliseconds when the warm-up starts, so the timed region does not begin on a clock that is still ramping up from idle.)
-    check_tol = 2e-3 if dtype == torch.float16 else 1.6e-2
-    o = attn(q, k, v, None, causal)
-    n_heads = B_local * H
-    picks = list(range(n_heads)) if n_heads <= 64 else [int(i * n_heads / 64) for i in range(64)]
-    gate_err = max(dense_head_check(q, k, v, o, causal, i // H, i % H) for i in picks)
-    assert gate_err <= check_tol, "output differs from dense fp32 attention before timing: %g" % gate_err
+    default_multi = args.workload is None and world > 1      # N > 1 and no --workload: c5 (BASELINE.json configs[4]) is the line, c2 weak rides along
+    if args.workload is None:
+        args.workload = "c5" if world > 1 else "c2"
 
-    # ---- settling, stated plainly: after idle the chip boosts, overshoots its power budget, throttles and needs ~100 launches (25 ms) of THIS load to
-    #      find its steady clock (profiles/r03_clock_settling.txt: the first 30 launches of a process run 15 % slower than the 100th; on other boxes
-    #      the dip comes later: profiles/r12_bench_driver_args_fixed150.json — 150 launches ahead put the 20 timed ones INTO it, 0.2506 ms against
-    #      0.2099 steady; an idle gap of <= 1 ms does not restart the transient, 5 ms does: tools/settle_probe.py).  Five warm-up launches cannot cover
-    #      that, so the operator is first run in chunks of 25 for at least 150 ms AND until six consecutive chunks agree within 1 % (at most `--settle`
-    #      launches) — doubling as a determinism gate: the last result must equal the first bit for bit.
-    #      `--settle 0` gives the cold-start number; the line reports what was done.
-    settle_info = {"max_launches": args.settle, "launches": 0}
-    if args.settle > 0:
-        chunk, times = 25, []
-        while settle_info["launches"] < args.settle:
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            for _ in range(chunk):
-                o_s = attn(q, k, v, None, causal)
-            c1.record()
-            torch.cuda.synchronize()
-            times.append(c0.elapsed_time(c1) / chunk)
-            settle_info["launches"] += chunk
-            # settled: at least 150 ms under this load (the throttle episode comes 35 .. 50 ms after the load starts and lasts 10 .. 20 ms: a plateau
-            # before it fooled a pure convergence test, profiles/r12_bench_driver_args_settle_converged_early.json) AND the last six chunks agree
-            # within 1 % (the transient — boost, throttle, recovery — moves the launch time by 5 .. 18 %)
-            if sum(times) * chunk >= 150.0 and max(times[-6:]) <= 1.01 * min(times[-6:]):
-                break
-        # (the bit-identity check of o_s against the gate's output waits until the timed region is over: the FIRST launch of a kernel the process has not
-        #  run yet — torch.equal's compare — loads its code object, the GPU idles for milliseconds and the next ~40 attention launches run 10 .. 18 %
-        #  slower, tools/settle_probe.py: nothing that is new to the process may sit between here and the timed region)
-        o_settled = o_s
-        settle_info.update({"chunk": chunk, "first_chunk_ms": round(times[0], 5), "slowest_chunk_ms": round(max(times), 5),
-                            "last_chunk_ms": round(times[-1], 5), "gpu_ms": round(sum(times) * chunk, 1),
-                            "converged": sum(times) * chunk >= 150.0 and max(times[-6:]) <= 1.01 * min(times[-6:])})
-        del o_s
-
-    # ---- contractual region: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize
-    for _ in range(args.warmup):
-        o = attn(q, k, v, None, causal)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # torch's current stream == the stream the kernel is launched on
-    for i in range(args.steps):
-        o = attn(q, k, v, None, causal)
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    # per-launch durations: K further launches straight after the region, one event between consecutive launches (kept out
-    # of the region itself: an event between two launches costs 1.6 % — tools/event_overhead.py)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    evs[0].record()
-    for i in range(args.steps):
-        o2 = attn(q, k, v, None, causal)
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    per_launch = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-    assert torch.equal(o, o2), "the operator is not deterministic run to run"
-    if args.settle > 0:
-        assert torch.equal(o_settled, o), "the operator is not deterministic run to run (settling phase)"
-        settle_info["bit_identical_to_timed_output"] = True
-        del o_settled
-    assert torch.isfinite(o.float()).all(), "non-finite attention output"
-    check_err = dense_head_check(q, k, v, o, causal, B_local - 1, H - 1)
-    assert check_err <= check_tol, "timed output differs from dense fp32 attention: %g" % check_err
-
-    # ---- steady re-timing (evidence, not the metric): same loop, after the region, clock settled
-    steady = None
-    if args.steady_launches > 0:
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(args.steady_launches):
+    def timed_region(q, k, v, causal):
+        """The contract: W untimed steps, then exactly K timed steps between barrier + synchronize.  Returns (wall seconds, kernel ms per step
+        by HIP events on the launch stream, last output)."""
+        o = None
+        for _ in range(args.warmup):
             o = attn(q, k, v, None, causal)
-        s1.record()
         torch.cuda.synchronize()
-        steady_ms = s0.elapsed_time(s1) / args.steady_launches
-        steady = {"launches": args.steady_launches, "kernel_ms": round(steady_ms, 5),
-                  "tflops": round(attention_flops(B_local, H, N, N, D, causal) / (steady_ms * 1e-3) / 1e12, 2)}
+        barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                      # torch's current stream == the stream the kernel is launched on
+        for _ in range(args.steps):
+            o = attn(q, k, v, None, causal)
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / args.steps, o
+
+    def measure(workload, extras):
+        """gate -> cold region -> settle -> contractual region (-> per-launch events, steady: `extras`) of one workload on this rank's shard."""
+        B, H, N, D, dtype, causal, scaling = WORKLOADS[workload]
+        if scaling == "strong":
+            lo, hi = shard_bounds(B, world, rank)
+            B_local, B_global = hi - lo, B
+        else:
+            B_local, B_global = B, B * world
+        cfg_idx = sorted(WORKLOADS).index(workload) + 1
+        g = torch.Generator(device=device).manual_seed(1234 + cfg_idx + rank)
+        q, k, v = (torch.rand((B_local, H, N, D), generator=g, device=device, dtype=torch.float32).to(dtype)
+                   for _ in range(3))
+        r = {"workload": workload, "B": B, "H": H, "N": N, "D": D, "dtype": dtype, "causal": causal, "scaling": scaling,
+             "B_local": B_local, "B_global": B_global, "cfg_idx": cfg_idx, "q": q, "k": k, "v": v}
+
+        # ---- parity gate BEFORE anything is timed: every (batch, head) of one forward call (a strided sample of 64 when there are
+        #      more) against dense fp32 attention on the GPU.
+        check_tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        o = attn(q, k, v, None, causal)
+        n_heads = B_local * H
+        picks = list(range(n_heads)) if n_heads <= 64 else [int(i * n_heads / 64) for i in range(64)]
+        gate_err = max(dense_head_check(q, k, v, o, causal, i // H, i % H) for i in picks)
+        assert gate_err <= check_tol, "output differs from dense fp32 attention before timing: %g" % gate_err
+        o_gate = o
+        launches = 1
+
+        # ---- cold region: the contract's W + K straight after the gate, nothing settled — what rounds 1-3 reported as `value`, and what a harness
+        #      that only knows W warm-up launches sees.  Reported under `cold`; it also is the first stretch of load the settling below builds on.
+        cold_elapsed, cold_kernel_ms, _ = timed_region(q, k, v, causal)
+        launches += args.warmup + args.steps
+
+        # ---- settling, stated plainly: after idle the chip boosts, overshoots its power budget, throttles and needs ~100 launches (25 ms) of THIS load to
+        #      find its steady clock (profiles/r03_clock_settling.txt: the first 30 launches of a process run 15 % slower than the 100th; on other boxes
+        #      the dip comes later: profiles/r12_bench_driver_args_fixed150.json — 150 launches ahead put the 20 timed ones INTO it, 0.2506 ms against
+        #      0.2099 steady; an idle gap of <= 1 ms does not restart the transient, 5 ms does: tools/settle_probe.py).  Five warm-up launches cannot cover
+        #      that, so the operator is first run in chunks of 25 for at least 150 ms AND until six consecutive chunks agree within 1 % (at most `--settle`
+        #      launches) — doubling as a determinism gate: the last result must equal the first bit for bit.
+        #      `--settle 0` skips it (then `value` is a second cold region); the line reports what was done.
+        settle_info = {"max_launches": args.settle, "launches": 0}
+        o_settled = None
+        if args.settle > 0:
+            chunk, times = 25, []
+            while settle_info["launches"] < args.settle:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(chunk):
+                    o_s = attn(q, k, v, None, causal)
+                c1.record()
+                torch.cuda.synchronize()
+                times.append(c0.elapsed_time(c1) / chunk)
+                settle_info["launches"] += chunk
+                # settled: at least 150 ms under this load (the throttle episode comes 35 .. 50 ms after the load starts and lasts 10 .. 20 ms: a plateau
+                # before it fooled a pure convergence test, profiles/r12_bench_driver_args_settle_converged_early.json) AND the last six chunks agree
+                # within 1 % (the transient — boost, throttle, recovery — moves the launch time by 5 .. 18 %)
+                if sum(times) * chunk >= 150.0 and max(times[-6:]) <= 1.01 * min(times[-6:]):
+                    break
+            # (the bit-identity check of o_s against the gate's output waits until the timed region is over: the FIRST launch of a kernel the process has not
+            #  run yet — torch.equal's compare — loads its code object, the GPU idles for milliseconds and the next ~40 attention launches run 10 .. 18 %
+            #  slower, tools/settle_probe.py: nothing that is new to the process may sit between here and the timed region)
+            o_settled = o_s
+            settle_info.update({"chunk": chunk, "first_chunk_ms": round(times[0], 5), "slowest_chunk_ms": round(max(times), 5),
+                                "last_chunk_ms": round(times[-1], 5), "gpu_ms": round(sum(times) * chunk, 1),
+                                "converged": sum(times) * chunk >= 150.0 and max(times[-6:]) <= 1.01 * min(times[-6:])})
+            launches += settle_info["launches"]
+            del o_s
+
+        # ---- contractual region: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize
+        elapsed, kernel_ms, o = timed_region(q, k, v, causal)
+        launches += args.warmup
+        r.update({"elapsed": elapsed, "kernel_ms": kernel_ms, "cold_elapsed": cold_elapsed, "cold_kernel_ms": cold_kernel_ms,
+                  "settle": settle_info, "warmup_effective": launches, "gate_err": gate_err, "n_picks": len(picks), "n_heads": n_heads,
+                  "check_tol": check_tol})
+        assert torch.equal(o_gate, o), "the operator is not deterministic run to run (gate vs timed output)"
+        if o_settled is not None:
+            assert torch.equal(o_settled, o), "the operator is not deterministic run to run (settling phase)"
+            settle_info["bit_identical_to_timed_output"] = True
+        del o_settled, o_gate
+        if not extras:
+            assert torch.isfinite(o.float()).all(), "non-finite attention output"
+            r["check_err"] = dense_head_check(q, k, v, o, causal, B_local - 1, H - 1)
+            assert r["check_err"] <= check_tol, "timed output differs from dense fp32 attention: %g" % r["check_err"]
+            return r
+        # per-launch durations: K further launches straight after the region, one event between consecutive launches (kept out
+        # of the region itself: an event between two launches costs 1.6 % — tools/event_overhead.py)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record()
+        for i in range(args.steps):
+            o2 = attn(q, k, v, None, causal)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        r["per_launch"] = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+        assert torch.equal(o, o2), "the operator is not deterministic run to run"
+        assert torch.isfinite(o.float()).all(), "non-finite attention output"
+        r["check_err"] = dense_head_check(q, k, v, o, causal, B_local - 1, H - 1)
+        assert r["check_err"] <= check_tol, "timed output differs from dense fp32 attention: %g" % r["check_err"]
+
+        # ---- steady re-timing (evidence, not the metric): same loop, after the region, clock settled
+        r["steady"] = None
+        if args.steady_launches > 0:
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(args.steady_launches):
+                o = attn(q, k, v, None, causal)
+            s1.record()
+            torch.cuda.synchronize()
+            steady_ms = s0.elapsed_time(s1) / args.steady_launches
+            r["steady"] = {"launches": args.steady_launches, "kernel_ms": round(steady_ms, 5),
+                           "tflops": round(attention_flops(B_local, H, N, N, D, causal) / (steady_ms * 1e-3) / 1e12, 2)}
+        return r
+
+    m = measure(args.workload, True)
+    B, H, N, D, dtype, causal, scaling = (m[x] for x in ("B", "H", "N", "D", "dtype", "causal", "scaling"))
+    B_local, B_global, cfg_idx = m["B_local"], m["B_global"], m["cfg_idx"]
+    q, k, v = m["q"], m["k"], m["v"]
+    elapsed, kernel_ms, per_launch, steady, settle_info = m["elapsed"], m["kernel_ms"], m["per_launch"], m["steady"], m["settle"]
+    check_err, check_tol, gate_err = m["check_err"], m["check_tol"], m["gate_err"]
 
     # ---- edge transfers (SURVEY §8e timing rule): reported separately, never part of `value`
     coll = None
@@ -383,7 +430,21 @@ def main():
                "note": "bwd FLOPs = 2.5 x fwd (bench_with_sdpa.py:35-41); two deterministic passes (dQ: S, dP, dQ; dK/dV: S, dP, dV, dK) "
                        "recompute S and dP, so 7 GEMM-equivalents execute; time = wall of 30 autograd backward calls / 30 (HIP events)"}
 
-    elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms])
+    elapsed, kernel_ms, cold_elapsed, cold_kernel_ms = max_over_ranks([elapsed, kernel_ms, m["cold_elapsed"], m["cold_kernel_ms"]])
+    # ---- N > 1 with no --workload: the c2 weak-scaling figure (every rank its own B2 H16 N4096 D128 shard) next to the c5 line
+    weak = None
+    if default_multi:
+        del q, k, v
+        m.pop("q"), m.pop("k"), m.pop("v")
+        torch.cuda.empty_cache()
+        w = measure("c2", False)
+        w_el, w_km, w_cel = max_over_ranks([w["elapsed"], w["kernel_ms"], w["cold_elapsed"]])
+        w_flops = attention_flops(w["B_global"], w["H"], w["N"], w["N"], w["D"], w["causal"])
+        weak = {"workload": "c2: B2 H16 N4096 D128 f16 causal=False per GPU", "scaling": "weak", "global_batch": w["B_global"],
+                "value": round(w_flops * args.steps / w_el / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(w_el / args.steps * 1e3, 5),
+                "kernel_ms": round(w_km, 5), "cold_value": round(w_flops * args.steps / w_cel / 1e12, 2),
+                "pct_of_mfma_roofline": round(100.0 * w_flops * args.steps / w_el / 1e12 / (MFMA_PEAK_TFLOPS * world), 2),
+                "warmup_effective": w["warmup_effective"]}
     rank_info = None
     if use_dist:
         # which device every rank ran on, as the process group saw it (evidence that N ranks on N GPUs took part)
@@ -403,6 +464,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": read_json("hbm_traffic.json").get(args.workload, {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/hbm_traffic.json: the committed rocprofv3 --pmc passes of this workload (counters cannot be read inside this run)",
                 "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_local}
         if sustained:
             roof["sustained_peak"] = sustained
@@ -410,22 +472,28 @@ def main():
         line = {
             "metric": "fwd attention TFLOPS (and % MFMA roofline) at B2 H16 N4096 D128 fp16",
             "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_effective": m["warmup_effective"],
+            "cold": {"value": round(flops_global * args.steps / cold_elapsed / 1e12, 2), "ms_per_step": round(cold_elapsed / args.steps * 1e3, 5),
+                     "kernel_ms": round(cold_kernel_ms, 5), "frac": round(flops_local / (cold_kernel_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                     "note": "the same W + K region straight after the parity gate, before the settle phase: the protocol of rounds 1-3"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": "%s: B%d H%d N%d D%d %s causal=%s per GPU, BHND, torch.rand U[0,1)"
                                    % (args.workload, B_local, H, N, D, str(dtype)[6:], causal),
                        "global_batch": B_global, "parallelism": "batch-shard x%d (no data-path collective)" % world},
             "roofline": roof,
-            "sequence": ["parity_gate", "settle", "warmup", "timed", "per_launch_events", "steady", "backward_info", "cpu_baseline"],
+            "sequence": ["parity_gate", "cold_warmup", "cold_timed", "settle", "warmup", "timed", "per_launch_events", "steady", "backward_info", "cpu_baseline"],
             "settle": settle_info,
             "pct_of_mfma_roofline": round(100.0 * value / (MFMA_PEAK_TFLOPS * world), 2),
             "launch_ms": {"min": round(min(per_launch), 5), "median": round(statistics.median(per_launch), 5),
                           "max": round(max(per_launch), 5), "first": round(per_launch[0], 5), "last": round(per_launch[-1], 5)},
             "check": {"max_abs_err_vs_dense_fp32": round(check_err, 6), "tol": check_tol, "head": [B_local - 1, H - 1],
-                      "gate_before_timing": {"heads_checked": len(picks), "of": n_heads, "max_abs_err": round(gate_err, 6)}},
+                      "gate_before_timing": {"heads_checked": m["n_picks"], "of": m["n_heads"], "max_abs_err": round(gate_err, 6)}},
         }
         if steady is not None:
             line["steady"] = steady
+        if weak is not None:
+            line["weak_c2"] = weak
         if rank_info is not None:
             line["dist"] = rank_info
             if args.force_dist and world == 1:

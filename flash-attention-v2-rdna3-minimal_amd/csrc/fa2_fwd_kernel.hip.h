@@ -102,6 +102,7 @@ struct FwdParams {
     uint32_t k_bytes, v_bytes;           // addressable bytes of one head's K / V matrix
     int bh0, nbh;                        // this launch covers the flattened (batch*H + head) range [bh0, bh0 + nbh)
     int rows_hint;                       // host only: rows per workgroup the launcher must use (0 = its own heuristic)
+    int exact_scale;                     // host only: FA2_FLAG_EXACT_SCALE — this call never folds the scale into Q
     int persist;                         // hand-scheduled kernels: 1 = persistent workgroups (grid = work units, capped at the CU count), 0 = one item per workgroup
     // additive attention bias / boolean mask (BIAS kernels only; fa2_fwd_bias in include/fa2_gfx950.h): element (b,h,i,j) at
     // bias + b*bs[0] + h*bs[1] + i*bs[2] + j in elements of the bias type, strides may be 0 (broadcast)

@@ -24,6 +24,9 @@ struct Options {
     std::atomic<int> split{1};         // FA2_SPLIT: KV-split of the last, partly filled round of forward workgroups (fa2_fwd_ws)
     std::atomic<int> epoch{0};         // bumped by every fa2_set_option: callers that cache a plan (the compiled front end) key it on this
     std::atomic<int> fold{1};          // FA2_FOLD: 0 = the hand-scheduled forward bodies scale the f32 product, 1 = fp16 launches fold the scale into Q, 2 = bf16 too
+                                       // (never for calls flagged FA2_FLAG_EXACT_SCALE: the forward of a call that will be differentiated)
+    std::atomic<int> kfold{0};         // FA2_KFOLD: 1 = the hand-scheduled dK / dV pass folds the scale into its K fragments where `fold` would fold a forward of that
+                                       // dtype (round 4's default; off since round 5: profiles/r16_fold_evidence.txt, tests/test_backward_gpu.py large-logit case)
 };
 FA2_HIDDEN Options& options();
 FA2_HIDDEN int device_cus();           // compute units of the current device (cached per device index)

@@ -45,8 +45,10 @@ size_t cached_ws_bytes(int which, int dtype, int dev, int64_t b, int64_t h, int6
     return bytes;
 }
 
-std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_t Br, int64_t Bc, bool causal, double scale,
+std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_t Br, int64_t Bc, int64_t flags, double scale,
                                 bool permute_NH) {
+    // flags: the reference's `causal` (0 / 1; a Python bool converts), or the C-ABI's call flags FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE
+    const bool causal = (flags & FA2_FLAG_CAUSAL) != 0;
     (void)Bc;
     TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)");
     TORCH_CHECK(q.is_cuda() && k.is_cuda() && v.is_cuda(), "fa2: q, k, v must be on a ROCm device (no CPU path in this operator)");
@@ -109,7 +111,7 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     const size_t ws_bytes = causal ? 0 : cached_ws_bytes(0, dtype_code, q.device().index(), b, h, n, n_kv, d_kernel);
     if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, q.options().dtype(at::kByte));
     const int rc = fa2_fwd_ws(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
-                              (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, causal ? 1 : 0,
+                              (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, (int)(flags & 3),
                               ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);
     TORCH_CHECK(rc == 0, "fa2 call failed (", rc, "): ", fa2_error_string(rc));
     at::Tensor O_fwd = O;
@@ -165,7 +167,8 @@ struct AttentionNode : public torch::autograd::Function<AttentionNode> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor q, at::Tensor k, at::Tensor v, bool causal, double scale, bool permute_NH) {
         const int n_ax = permute_NH ? 1 : 2;
         const int64_t d = q.size(3), n = q.size(n_ax), n_kv = k.size(n_ax);
-        std::vector<at::Tensor> r = op_forward(q, k, v, d > 384 ? 32 : 64, 128, causal, scale, permute_NH);
+        // the forward of a call that will be differentiated: FA2_FLAG_EXACT_SCALE (the backward recomputes P from the scores L was formed from)
+        std::vector<at::Tensor> r = op_forward(q, k, v, d > 384 ? 32 : 64, 128, (causal ? FA2_FLAG_CAUSAL : 0) | FA2_FLAG_EXACT_SCALE, scale, permute_NH);
         ctx->save_for_backward({r[1], r[2], r[3], r[4], r[5]});
         ctx->saved_data["n"] = n;
         ctx->saved_data["n_kv"] = n_kv;
@@ -192,7 +195,7 @@ at::Tensor attention(at::Tensor q, at::Tensor k, at::Tensor v, bool causal, doub
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled front end of the gfx950 FlashAttention-2 operator (forward of the reference's flash_attn_wmma module)";
-    m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal, scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
+    m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal (bool, or the C-ABI's call flags), scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
     m.def("attention", &attention, "attention(q, k, v, causal, scale, permute_NH) -> O, differentiable (the C++ autograd node of FlashAttentionFunction)");
     m.def("backward", &backward, "backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH) -> [dQ, dK, dV]");
 }

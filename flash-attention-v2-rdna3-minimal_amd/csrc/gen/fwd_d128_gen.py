@@ -59,8 +59,12 @@ PSUM_MAX = 32768.0
 
 # ---- inline-asm operands (order = the operand list of the asm statement in fa2_fwd_d128.hip.h)
 A_LSE0, A_LSE1 = Arg(0), Arg(1)                    # "=&v" outputs: log2-domain LSE of this lane's row in q block 0 / 1
-A_QO0, A_QO1 = Arg(2), Arg(3)                      # byte offset of this lane's 16 Q bytes (k-step 0) in block 0 / 1 from the head base
-A_QB = Arg(4, "s", 2)                              # 64-bit address of this head's Q matrix
+# Q goes global -> LDS by LDS-DMA like a K tile (whole rows per instruction, the K image's granule swizzle on the source side) into the wave's
+# part of the epilogue image — idle until the item's epilogue — and from there into the fragment registers (ds_read_b128, the K fragment geometry):
+# the 16 fragment loads of 16 bytes per lane from 32 different rows each that did this before cost ~250 cycles of issue apiece (profiles/r16_*)
+A_QD0 = Arg(2)                                     # per-lane LDS-DMA source byte offset of piece 0 of a 16-row group of Q (row lane / G, swizzled granule)
+A_QW = Arg(3, "s")                                 # byte offset of this wave's first Q row from the head base
+A_QRS = Arg(4, "s", 4)                             # buffer descriptor of this head's Q matrix (rows >= Nq read as zeros)
 A_KRS, A_VRS = Arg(5, "s", 4), Arg(6, "s", 4)      # buffer descriptors of this head's K / V matrix
 A_KD0, A_VD0 = Arg(7), Arg(8)                      # per-lane LDS-DMA source byte offset (piece 0, tile 0), K / V
 A_KR0, A_VR0 = Arg(9), Arg(10)                     # per-lane LDS read offset of K fragment k-step 0 / V^T fragment d-block 0
@@ -75,8 +79,9 @@ A_EPI = Arg(21)                                    # per-lane LDS byte address o
 # an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
 A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles; bit 3: this item is a KV-split part
                                                    # bit 4: safe mode — no fast bodies (the redo of an item whose sum check met a non-finite P: see Gen.rare_sum)
-A_NQO0, A_NQO1 = Arg(23), Arg(24)                  # the next item's Q offsets / head base / K and V descriptors
-A_NQB = Arg(25, "s", 2)
+A_NQW = Arg(23, "s")                               # the next item: byte offset of this wave's first Q row; Q / K / V descriptors
+A_QT16 = Arg(24, "s")                              # 16 * Q row bytes: source stride between the 16-row groups of Q
+A_NQRS = Arg(25, "s", 4)
 A_NKRS, A_NVRS = Arg(26, "s", 4), Arg(27, "s", 4)
 # KV-split parts (flag bit 3; fa2_fwd_ws): the item sweeps a KV range of its (head, q block) and leaves a normalised f32 partial tile in the
 # caller's workspace instead of the 16-bit tile in LDS — float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e) of the tile for d = 32dt + 8g + 4hi + e,
@@ -109,16 +114,21 @@ MC = [V(234), V(235)]                              # reference max in log2 units
 TMP = [V(236 + i) for i in range(8)]               # scratch: row-max chains, rescale block, epilogue
 EP_LT, EP_T, EP_INV = FSC[0], FSC[1], V(244)       # epilogue scratch (the softmax state above is dead by then)
 DSH = [V(245), V(246)]                             # sum-check bodies: pending shift of the next tile's scores (see S_FIX)
+QD = [V(252 + i) for i in range(4)]                # LDS-DMA source offsets of the pieces of a 16-row group of Q (the seam reuses them as read addresses)
 
 S_T, S_KOFF, S_VOFF, S_FLAG, S_TMP, S_TMP2 = S(60), S(61), S(62), S(63), S(64), S(65)
 S_NFAST, S_D, S_WAVE = S(70), S(71), S(72)
 S_NOVM, S_PF = S(66), S(67)                          # next item's loads are in flight (do not drain vmcnt) / this item came prefetched
 S_FIX = S(68)                                        # sum-check bodies, folded scale: bit qb = the scores of the NEXT tile of q block qb were formed against the old reference (shift in DSH)
+# staging of the NEXT item's Q into this wave's part of the epilogue image, one half of a 16-row group per body from t = 0 on (Gen.qstage_group):
+S_QH = S(69)                                         # half groups staged so far (8 = all; also 8 when there is no next item); its parity is the body's
+S_QM0, S_QSOFF, S_QSB = S(73), S(58), S(59)        # LDS address / source offset of the group being staged; LDS address of the wave's Q image
 S_TA, S_TB, S_TC = S(74, 2), S(76, 2), S(78, 2)      # "trace" builds: s_memtime samples (body start, phase boundary, body end)
 S_SUM = [S(80), S(81), S(82), S(83)]                 # cycle sums over the fast bodies: PV phase, QK phase, barrier, bodies
 S_MARK = [S(86, 2), S(88, 2), S(90, 2), S(92, 2)]     # trace: block entry, first main body, epilogue start, block end
 S_MARKH = [S(94, 2), S(96, 2)]                        # trace 5 / 6: past the entry barrier, past the first head body
-CLOBBER_S = list(range(60, 98))
+S_MARKE = S(98, 2)                                    # trace 7: in front of the entry barrier (entry -> here = the wave's own entry work, here -> past the barrier = waiting for the others)
+CLOBBER_S = list(range(58, 100))      # (s100 and above are reserved by the compiler on gfx950)
 CLOBBER_V = list(range(VBASE, 256))
 
 
@@ -641,10 +651,13 @@ class Gen:
                 for i in range(g.NP):
                     r.append(mk("buffer_load_dwordx4", vd[i], nrs, A_KTILE, offen=True, offset=1024 * i, lds=True))
                 r.append(Ins("label", (Label(one),)))
-                for qb in range(2):
-                    for ks in range(g.NKS):
-                        r.append(mk("global_load_dwordx4", self.qf(qb, ks), A_NQO0 if qb == 0 else A_NQO1, A_NQB, offset=32 * ks))
+                r += self.seam_q_reads()
             r.append(mk("s_branch", Label(skip)))
+            if which == "k":
+                # groups of Q the bodies so far did not stage (a short item, a wave that left the fast loop early): now, AHEAD of the K tiles, so that one
+                # counted wait below covers them
+                at = [i for i, x in enumerate(r) if x.op == "s_mov_b32" and x.ops[0] is S_NOVM][0] + 1
+                r[at:at] = self.seam_q_rest()
             self.rare.append(r)
         out.append([mk("s_add_u32", M0, A_LDSW, base, tag="salu"), mk("s_nop", 0, tag="salu")])
         for i in range(g.NP):
@@ -657,11 +670,130 @@ class Gen:
             return [flat]         # one atomic group: the guard's SCC and branch must not be interleaved with other streams
         return out
 
+    # ------------------------------------------------------------------ the next item's Q through LDS
+    def q_group_loads(self, rs, soff, half=None):
+        """LDS-DMA pieces of ONE 16-row group of Q (M0 = LDS address of the group, soff = its source offset): all NP, or half 0 / 1 of them."""
+        g = self.g
+        idx = range(g.NP) if half is None else range(half * g.NP // 2, (half + 1) * g.NP // 2)
+        return [mk("buffer_load_dwordx4", QD[i], rs, soff, tag="dma", offen=True, offset=1024 * i, lds=True) for i in idx]
+
+    def qstage_group(self, par):
+        """Bodies t >= 0 of an item stage the NEXT item's Q: half a 16-row group per body (body parity = half), 8 bodies for the wave's 64 rows.
+        S_QH counts the halves (its parity is the body's: every body from t = 0 on carries this group); 8 = done, or nothing to stage."""
+        g = self.g
+        skip = self.p.fresh("qst_skip")
+        out = [mk("s_cmp_lt_u32", S_QH, 8, tag="salu"), mk("s_cbranch_scc0", Label(skip), tag="branch"),
+               mk("s_mov_b32", M0, S_QM0, tag="salu"), mk("s_add_u32", S_QH, S_QH, 1, tag="salu")]
+        out += self.q_group_loads(A_NQRS, S_QSOFF, half=par)
+        if par == 1:
+            out.append(mk("s_add_u32", S_QM0, S_QM0, g.NP * 1024, tag="salu"))
+            out.append(mk("s_add_u32", S_QSOFF, S_QSOFF, A_QT16, tag="salu"))
+        out.append(Ins("label", (Label(skip),)))
+        return [out]          # one atomic group
+
+    def q_prescale_reg(self, src, qreg, t0, t1):
+        """Folded scale: one register of Q fragments (two 16-bit values) * scale*log2(e), rounded ONCE to the I/O dtype — the reference oracle's
+        contract `scale * q_frags` (pure_torch_ver.py:61) — from src into the fragment register qreg (t0, t1: scratch)."""
+        r = []
+        wr = "v_accvgpr_write_b32" if qreg.kind == "a" else "v_mov_b32"
+        if not self.bf16 and "nomix" not in self.opt:
+            # fp16: each half straight through the mixed-precision fma — f16 x f32 scale, rounded once to f16 into its half of the word
+            r.append(mk("v_fma_mixlo_f16", t0, src, A_C, 0, tag="valu", op_sel="[0,0,0]", op_sel_hi="[1,0,0]"))
+            r.append(mk("v_fma_mixhi_f16", t0, src, A_C, 0, tag="valu", op_sel="[1,0,0]", op_sel_hi="[1,0,0]"))
+            r.append(mk("s_nop", 0, tag="salu"))
+            r.append(mk(wr, qreg, t0, tag="valu"))
+            return r
+        if self.bf16:
+            r.append(mk("v_lshlrev_b32", t0, 16, src, tag="valu"))
+            r.append(mk("v_and_b32", t1, 0xffff0000, src, tag="valu"))
+        else:
+            r.append(mk("v_lshrrev_b32", t1, 16, src, tag="valu"))
+            r.append(mk("v_cvt_f32_f16", t0, src, tag="valu"))
+            r.append(mk("v_cvt_f32_f16", t1, t1, tag="valu"))
+        r.append(mk("v_mul_f32", t0, A_C, t0, tag="valu"))
+        r.append(mk("v_mul_f32", t1, A_C, t1, tag="valu"))
+        r.append(mk("s_nop", 0, tag="salu"))
+        r.append(mk(self.cvt, t0, t0, t1, tag="valu"))
+        r.append(mk("s_nop", 0, tag="salu"))
+        r.append(mk(wr, qreg, t0, tag="valu"))
+        return r
+
+    def stream_qprescale(self):
+        """Folded-scale kernels, the body at t = ntwg - 1 of an item that has a successor (TC / ST variants `q`): the NEXT item's raw Q fragments — read
+        from the staged image at the seam, one body earlier — are prescaled in place between this body's MFMAs, so the next statement's entry finds
+        them final (1.8 k cycles of bare VALU work per item before: profiles/r16_*).  One atomic group per register, four scratch pairs in rotation."""
+        g = self.g
+        out = []
+        for i in range(8 * g.NKS):
+            qreg = self.qf(i // (4 * g.NKS), (i % (4 * g.NKS)) // 4)[i % 4]
+            t0, t1 = TMP[2 * (i & 3)], TMP[2 * (i & 3) + 1]
+            grp = [mk("v_accvgpr_read_b32" if qreg.kind == "a" else "v_mov_b32", t0 if (self.bf16 or "nomix" in self.opt) else t1, qreg, tag="valu"),
+                   mk("s_nop", 0, tag="salu")]
+            src = t0 if (self.bf16 or "nomix" in self.opt) else t1
+            if src is t0:      # the long form reads src after writing t0: give it its own register
+                grp = [mk("v_accvgpr_read_b32" if qreg.kind == "a" else "v_mov_b32", DSH[i & 1], qreg, tag="valu"), mk("s_nop", 0, tag="salu")]
+                src = DSH[i & 1]
+            out.append(grp + self.q_prescale_reg(src, qreg, t0, t1))
+        return out
+
+    def qpre_check(self, target):
+        """-> target when this is the item's last body (t = ntwg - 1) and a next item exists: its Q fragments were read at the seam, one body ago."""
+        p = self.p
+        no = p.fresh("qpre_no")
+        p.emit("s_add_u32", S_TMP2, S_T, 1)
+        p.emit("s_cmp_eq_u32", S_TMP2, A_NTWG)
+        p.emit("s_cbranch_scc0", Label(no))
+        p.emit("s_bitcmp1_b32", A_FLAGS, 1)
+        p.emit("s_cbranch_scc1", Label(target))
+        p.label(no)
+
+    def seam_q_rest(self):
+        """Seam (body ntwg - 2, out of line): 16-row groups of the next item's Q that are not fully staged yet are staged whole (a half-staged group is
+        staged again: same bytes)."""
+        g = self.g
+        r = []
+        for j in range(4):
+            sk = self.p.fresh("qrest_skip")
+            r.append(mk("s_cmp_ge_u32", S_QH, 2 * j + 2))
+            r.append(mk("s_cbranch_scc1", Label(sk)))
+            r.append(mk("s_add_u32", M0, S_QSB, j * g.NP * 1024))
+            r.append(mk("s_mov_b32", S_TMP, A_NQW))
+            for _ in range(j):
+                r.append(mk("s_add_u32", S_TMP, S_TMP, A_QT16))
+            r += self.q_group_loads(A_NQRS, S_TMP)
+            r.append(Ins("label", (Label(sk),)))
+        r.append(mk("s_mov_b32", S_QH, 8))
+        return r
+
+    def seam_q_reads(self):
+        """... and the fragments are read into the (idle) Q registers: everything older than the K tiles just issued has landed after one counted wait.
+        The read addresses are the K fragment ones moved to the wave's Q image; they take the DMA offset registers (dead: S_QH = 8)."""
+        g = self.g
+        r = []
+        two, waited = self.p.fresh("qrd_two"), self.p.fresh("qrd_waited")
+        r.append(mk("s_bitcmp1_b32", A_FLAGS, 2))
+        r.append(mk("s_cbranch_scc1", Label(two)))
+        r.append(mk("s_waitcnt", vmcnt=g.NP))
+        r.append(mk("s_branch", Label(waited)))
+        r.append(Ins("label", (Label(two),)))
+        r.append(mk("s_waitcnt", vmcnt=2 * g.NP))
+        r.append(Ins("label", (Label(waited),)))
+        for k0 in range(0, g.NKS, 4):
+            for i in range(4):
+                r.append(mk("v_add_u32", QD[i], S_QSB, KR[k0 + i]))
+            r.append(mk("s_nop", 0))
+            for qb in range(2):
+                for i in range(4):
+                    r.append(mk("ds_read_b128", self.qf(qb, k0 + i), QD[i], offset=qb * 32 * g.ROWB))
+            if k0 + 4 < g.NKS:
+                r.append(mk("s_nop", 0))
+        return r
+
     # ------------------------------------------------------------------ scheduler (shared with the backward generator: sched.py)
     place = staticmethod(sched.place)
 
     # ------------------------------------------------------------------ one body
-    def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True):
+    def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True, qpre=False):
         """B(t) with t & 1 == par.  pv: PV(t); s1: softmax of tile t+1 (M0, M1, E0, E1) and the V(t+1) reads; s2: K(t+2)
         reads and QK(t+2).  masked: tile t+1 is this wave's last one (causal diagonal / ragged tail masks); first: tile
         t+1 is tile 0.  Appends to self.p."""
@@ -679,8 +811,10 @@ class Gen:
         mf += self.qk_mfmas(par) if s2 else [None] * self.nqk
         if "mfma" in abl:
             mf = [None] * ng
-        trace = fast and cfg["trace"][0] > 0
-        if trace:
+        trace = fast and 0 < cfg["trace"][0] < 9
+        # trace 9 / 10: cycles of the tail bodies by kind (TA, TB | TC, ST), barrier included
+        tkind = {"TA": 0, "TB": 1, "TC": 2, "ST": 3}.get(name[:2]) if cfg["trace"][0] in (9.0, 10.0) else None
+        if trace or tkind is not None:
             p.emit("s_memtime", S_TA)
         if cfg["stagger"][0] > 0 and (pv or s1 or s2):
             # the four waves leave the barrier together and run the same stream: without a skew they meet at every LDS
@@ -718,6 +852,10 @@ class Gen:
                 self.place(load, slots, self.stream_max(1, par ^ 1, masked, first), mw[0], mw[1], 1)
         if dma and "dma" not in abl:
             grp = self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2)
+            if not name.startswith("H"):
+                # t >= 0: every such body carries the Q staging group (S_QH's parity must stay the body's) — at the head of the ONE stream that owns M0:
+                # the K / V groups of the fast bodies are not atomic, another stream writing M0 between their M0 write and their loads would misdirect them
+                grp = self.qstage_group(par) + grp
             self.place(load, slots, grp, cfg["dma"][0], cfg["dma"][1], 2)
         if s2 and "kread" not in abl and self.pool:
             # 32-register fragment pool: k-steps 0..3 are read during the PV phase, k-step ks >= 4 goes into the slot of ks - 4
@@ -745,6 +883,9 @@ class Gen:
         elif s1 and "exp" not in abl:
             self.place(load, slots, self.stream_exp(0, par ^ 1), ew[0], ew[1] - 1.0, 5)
             self.place(load, slots, self.stream_exp(1, par ^ 1), ew[0], ew[1], 6)
+        if qpre:
+            assert not s1 and not s2          # (the scratch registers of the softmax streams)
+            self.place(load, slots, self.stream_qprescale(), 0, ng, 8)
         self.last_load = load
         if fast and cfg["syn"]:
             # timing probe (wrong results): every gap of the fast bodies carries the same synthetic fillers, e.g.
@@ -794,6 +935,15 @@ class Gen:
             assert len(gap) == 1, (lab, gap)
             # PV(t) of this q block (MFMAs 16 qb .. 16 qb + 15) must be issued: the rare block rescales its accumulators
             assert gap[0] >= (self.npv // 2) * (qb + 1) - 1, "sum check of q block %d in gap %d: its PV MFMAs are not all issued" % (qb, gap[0])
+            if self.ct:
+                # `fix` treats the two first-k-step MFMAs of this q block (npv + 2 qb: kv half 0, npv + 2 qb + 1: kv half 1) as one event: a check between
+                # them would rewrite the C tuple for half of the scores only, and rare_fix shifts all 32 — refuse such a schedule
+                assert gap[0] != self.npv + 2 * qb, "sum check of q block %d in gap %d: between the two MFMAs that read its C tuple" % (qb, gap[0])
+            # the pair packing of this q block (stream_pack) rounds P in place; the rare block reads the unpacked f32 P -> no pack instruction ahead of the check
+            packs = [(g, pos) for g in range(ng) for (pos, sid, it) in slots[g] if sid == 5 + qb and not isinstance(it, list) and it.op == self.cvt]
+            chk = [(g, pos) for g in range(ng) for (pos, sid, it) in slots[g] if isinstance(it, list) and any(
+                x.op == "s_cbranch_vccnz" and x.ops[0].name == lab for x in it)]
+            assert packs and min(packs) > chk[0], "pair packing of q block %d starts at %s, ahead of its sum check at %s" % (qb, min(packs), chk[0])
             self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= self.npv + 2 * qb))
             self.check_gaps = getattr(self, "check_gaps", {})
             self.check_gaps[(name, qb)] = gap[0]
@@ -841,6 +991,11 @@ class Gen:
             p.emit("s_memtime", S_TC)
         if "barrier" not in abl:
             p.emit("s_barrier")
+        if tkind is not None:
+            p.emit("s_memtime", S(84, 2))
+            p.emit("s_waitcnt", lgkmcnt=0)
+            p.emit("s_sub_u32", S_TMP, S(84), S_TA[0])
+            p.emit("s_add_u32", S_SUM[tkind], S_SUM[tkind], S_TMP)
         if trace:       # sums of the low words: PV phase, QK phase (+ end-of-body wait), barrier
             p.emit("s_memtime", S(84, 2))
             p.emit("s_waitcnt", lgkmcnt=0)
@@ -901,29 +1056,43 @@ class Gen:
             p.emit("v_xor_b32", KR[ks], ks << 5, A_KR0)
         for dt in range(g.NDT):
             p.emit("v_xor_b32", VR[dt], dt << 6, A_VR0)
-        # Q fragments: 16 loads, unless the previous item of this persistent workgroup already fetched them (flag bit 0)
+        # The wave's 64 Q rows: LDS-DMA into its part of the epilogue image (four 16-row groups of NP pieces, whole rows per instruction), unless the
+        # previous item of this persistent workgroup staged them and read them into the fragment registers at its seam (flag bit 0)
+        p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
+        p.emit("s_mul_i32", S_QSB, S_WAVE, 64 * g.EPI_ROWB)
+        p.emit("s_add_u32", S_QSB, S_QSB, g.EPI_BASE)
+        # source offsets of piece i of a group: rows RPP * i further down, the granule swizzle follows the row (xor i << 6), the instruction offset that
+        # selects the LDS piece is taken back out of the source address (like KD / VD below)
+        p.emit("v_mov_b32", QD[0], A_QD0)
+        p.emit("s_lshr_b32", S_TMP2, A_QT16, (16 // g.RPP).bit_length() - 1)       # RPP * Q row bytes
+        p.emit("s_sub_u32", S_TMP2, S_TMP2, 1024)
+        p.emit("s_mov_b32", S_TMP, 0)
+        for i in range(1, g.NP):
+            p.emit("s_add_u32", S_TMP, S_TMP, S_TMP2)
+            p.emit("v_xor_b32", QD[i], i << 6, A_QD0)
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", QD[i], S_TMP, QD[i])
         p.emit("s_and_b32", S_PF, A_FLAGS, 1)
         p.emit("s_cmp_eq_u32", S_PF, 1)
         p.emit("s_cbranch_scc1", Label("have_q"))
+        p.emit("s_mov_b32", S_TMP, A_QW)
+        for j in range(4):
+            p.emit("s_add_u32", M0, S_QSB, j * g.NP * 1024)
+            if j:
+                p.emit("s_add_u32", S_TMP, S_TMP, A_QT16)
+            else:
+                p.emit("s_nop", 0)
+            for ins in self.q_group_loads(A_QRS, S_TMP):
+                p.ins.append(ins)
+        nq = 4 * g.NKS              # registers of one q block's fragments
+        qv = V(VBASE, 2 * nq)
         if not self.fold:
-            for qb in range(2):
-                for ks in range(g.NKS):
-                    p.emit("global_load_dwordx4", self.qf(qb, ks), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
             p.label("have_q")
         else:
             # folded scale: Q comes through the (still unused) S banks, is multiplied by c in f32 and rounded back ONCE —
             # the reference oracle's contract `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file
-            nq = 4 * g.NKS              # registers of one q block's fragments
-            qv = V(VBASE, 2 * nq)
-            for qb in range(2):
-                for ks in range(g.NKS):
-                    p.emit("global_load_dwordx4", qv.sub(nq * qb + 4 * ks, 4), A_QO0 if qb == 0 else A_QO1, A_QB, offset=32 * ks)
-            p.emit("s_branch", Label("q_issued"))
+            # (a prefetched item's fragments were prescaled in place by the previous item's last body: stream_qprescale)
             p.label("have_q")
-            for i in range(2 * nq):       # prefetched raw Q sits in the fragment registers: back through the S banks for the prescale
-                qreg = self.qf(i // nq, (i % nq) // 4)[i % 4]
-                p.emit("v_accvgpr_read_b32" if qreg.kind == "a" else "v_mov_b32", V(VBASE + i), qreg)
-            p.label("q_issued")
         # DMA source offsets of piece i: rows 4*i further down, the K granule swizzle follows the row (xor i<<6), and the
         # instruction offset 1024*i that selects the LDS piece is taken back out of the source address
         p.emit("v_mov_b32", KD[0], A_KD0)
@@ -938,7 +1107,6 @@ class Gen:
             p.emit("s_nop", 0)
             p.emit("v_add_u32", KD[i], S_TMP, KD[i])
         p.emit("s_mov_b32", S_T, -2)
-        p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mov_b32", S_FLAG, 0)
         p.emit("s_mov_b32", S_FIX, 0)
         for r in S_SUM:
@@ -968,7 +1136,29 @@ class Gen:
             for i in range(g.NP):
                 p.emit("buffer_load_dwordx4", KD[i], A_KRS, A_KTILE, offen=True, offset=1024 * i, lds=True)
             p.label("no_k1")
+        # Q (issued first: K(0), V(0) and K(1) — 3 or 2 x NP pieces behind it — keep flying) from the image into the fragment registers (f32-scale bodies) or
+        # into the still unused S banks (folded scale: the prescale below)
+        p.emit("s_cmp_lt_i32", A_NTWG, 2)
+        p.emit("s_cbranch_scc1", Label("qwait8"))
+        p.emit("s_waitcnt", vmcnt=3 * g.NP)
+        p.emit("s_branch", Label("qwaited"))
+        p.label("qwait8")
+        p.emit("s_waitcnt", vmcnt=2 * g.NP)
+        p.label("qwaited")
+        for ks in range(g.NKS):
+            p.emit("v_add_u32", TMP[ks], S_QSB, KR[ks])
+        p.emit("s_nop", 0)
+        for qb in range(2):
+            for ks in range(g.NKS):
+                p.emit("ds_read_b128", qv.sub(nq * qb + 4 * ks, 4) if self.fold else self.qf(qb, ks), TMP[ks], offset=qb * 32 * g.ROWB)
         p.label("staged")
+        if tr == 8:
+            p.emit("s_memtime", S_MARKH[1])
+        # staging state of the NEXT item's Q (qstage_group): nothing staged yet, or nothing to stage
+        p.emit("s_bitcmp1_b32", A_FLAGS, 1)
+        p.emit("s_cselect_b32", S_QH, 0, 8)
+        p.emit("s_mov_b32", S_QM0, S_QSB)
+        p.emit("s_mov_b32", S_QSOFF, A_NQW)
         p.emit("s_mov_b32", S_KOFF, A_KTILE)     # the running offsets are those of tile t+3 / t+2 of the body that uses them
         for qb in range(2):
             p.emit("v_mov_b32", MC[qb], 0.0 if self.fold else NEG_INF)
@@ -993,49 +1183,17 @@ class Gen:
                 for i in range(16):
                     p.emit("v_mov_b32", CT[qb][i], 0)              # C tuples: the reference starts at 0
         if self.fold:
-            if self.ct and early:
-                # the 16 Q loads were issued first: K(0), V(0) and K(1) (12 or 8 pieces behind them) keep flying during the prescale
-                p.emit("s_cmp_lt_i32", A_NTWG, 2)
-                p.emit("s_cbranch_scc1", Label("qwait8"))
-                p.emit("s_waitcnt", vmcnt=3 * g.NP)
-                p.emit("s_branch", Label("qwaited"))
-                p.label("qwait8")
-                p.emit("s_waitcnt", vmcnt=2 * g.NP)
-                p.label("qwaited")
-            else:
-                p.emit("s_waitcnt", vmcnt=0)                        # the 16 Q loads (and the staged tiles behind them)
+            p.emit("s_cmp_eq_u32", S_PF, 1)
+            p.emit("s_cbranch_scc1", Label("q_prescaled"))
+            p.emit("s_waitcnt", lgkmcnt=0)                          # the Q reads from the image
             for i in range(8 * g.NKS):
-                src, t0, t1 = V(VBASE + i), TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]
                 qreg = self.qf(i // (4 * g.NKS), (i % (4 * g.NKS)) // 4)[i % 4]
-                if not self.bf16 and "nomix" not in self.opt:
-                    # fp16: each half straight through the mixed-precision fma — f16 x f32 scale, rounded once to f16 into its half of the word:
-                    # 2 instructions per register instead of 6 (this runs once per ITEM: 64 registers, ~1 % of a config-2 item before)
-                    p.emit("v_fma_mixlo_f16", t0, src, A_C, 0, op_sel="[0,0,0]", op_sel_hi="[1,0,0]")
-                    p.emit("v_fma_mixhi_f16", t0, src, A_C, 0, op_sel="[1,0,0]", op_sel_hi="[1,0,0]")
-                    p.emit("s_nop", 0)
-                    p.emit("v_accvgpr_write_b32" if qreg.kind == "a" else "v_mov_b32", qreg, t0)
-                    continue
-                if self.bf16:
-                    p.emit("v_lshlrev_b32", t0, 16, src)
-                    p.emit("v_and_b32", t1, 0xffff0000, src)
-                else:
-                    p.emit("v_lshrrev_b32", t1, 16, src)
-                    p.emit("v_cvt_f32_f16", t0, src)
-                    p.emit("v_cvt_f32_f16", t1, t1)
-                p.emit("v_mul_f32", t0, A_C, t0)
-                p.emit("v_mul_f32", t1, A_C, t1)
-                p.emit("s_nop", 0)
-                p.emit(self.cvt, t0, t0, t1)
-                p.emit("s_nop", 0)
-                p.emit("v_accvgpr_write_b32" if qreg.kind == "a" else "v_mov_b32", qreg, t0)
-            if not (self.ct and early):
-                p.emit("s_waitcnt", vmcnt=0)
-        if self.fold and not (self.ct and early):
-            pass
-        elif not early:
-            p.emit("s_waitcnt", vmcnt=0)
-        else:
-            # Q and K(0) are needed now; V(0) and K(1) (8 or 4 pieces issued behind them) may keep flying until the end of B(-2)
+                for ins in self.q_prescale_reg(V(VBASE + i), qreg, TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]):
+                    p.ins.append(ins)
+            p.label("q_prescaled")
+        if True:
+            # K(0) is needed now (and the Q reads); V(0) and K(1) (8 or 4 pieces issued behind it) may keep flying until the end of B(-2)
+            p.emit("s_waitcnt", lgkmcnt=0)
             p.emit("s_cmp_lt_i32", A_NTWG, 2)
             p.emit("s_cbranch_scc1", Label("wait4"))
             p.emit("s_waitcnt", vmcnt=2 * g.NP)
@@ -1043,13 +1201,15 @@ class Gen:
             p.label("wait4")
             p.emit("s_waitcnt", vmcnt=g.NP)
             p.label("waited")
+        if tr:
+            p.emit("s_memtime", S_MARKE)
         p.emit("s_barrier")
         if tr:
             p.emit("s_memtime", S_MARKH[0])
 
         # ---- head bodies: t = -2 (parity 0): QK(0) only; t = -1 (parity 1): softmax of tile 0, QK(1) if there is a tile 1
         self.body(0, pv=False, s1=False, s2=True, name="H1", dma=False)
-        if tr:
+        if tr and tr != 8:
             p.emit("s_memtime", S_MARKH[1])
         p.emit("s_cmp_eq_u32", A_NTW, 1)
         p.emit("s_cbranch_scc1", Label("h2b"))
@@ -1115,8 +1275,14 @@ class Gen:
             p.emit("s_cbranch_scc1", Label("tb_" + suffix))
             p.emit("s_cmp_eq_u32", S_D, 1)
             p.emit("s_cbranch_scc1", Label("tc_" + suffix))
+            if self.fold:
+                self.qpre_check("stq_" + suffix)
             self.body(par, pv=False, s1=False, s2=False, name="ST%d" % par)     # this wave is done: stage + sync only
             p.emit("s_branch", Label("dispatch"))
+            if self.fold:
+                p.label("stq_" + suffix)
+                self.body(par, pv=False, s1=False, s2=False, name="STQ%d" % par, qpre=True)
+                p.emit("s_branch", Label("dispatch"))
             p.label("ta_" + suffix)
             self.body(par, name="TA%d" % par)                                   # like a fast body, staging guarded
             p.emit("s_branch", Label("dispatch"))
@@ -1124,7 +1290,13 @@ class Gen:
             self.body(par, s2=False, masked=True, name="TB%d" % par)            # tile t+1 is the last: masks
             p.emit("s_branch", Label("dispatch"))
             p.label("tc_" + suffix)
+            if self.fold:
+                self.qpre_check("tcq_" + suffix)
             self.body(par, s1=False, s2=False, name="TC%d" % par)
+            if self.fold:
+                p.emit("s_branch", Label("dispatch"))
+                p.label("tcq_" + suffix)
+                self.body(par, s1=False, s2=False, name="TCQ%d" % par, qpre=True)
             p.emit("s_branch", Label("dispatch"))
 
         # ---- epilogue: O / l -> 16 bit -> wave-private LDS image (rows of 272 B); LSE out
@@ -1190,6 +1362,18 @@ class Gen:
             elif tr == 5:    # entry -> past the entry barrier, that barrier -> end of the first head body
                 p.emit("s_sub_u32", S_TMP, S_MARKH[0][0], S_MARK[0][0])
                 p.emit("s_sub_u32", S_TMP2, S_MARKH[1][0], S_MARKH[0][0])
+                a, b = S_TMP, S_TMP2
+            elif tr == 9:    # tail bodies: TA, TB
+                a, b = S_SUM[0], S_SUM[1]
+            elif tr == 10:   # tail bodies: TC, ST
+                a, b = S_SUM[2], S_SUM[3]
+            elif tr == 8:    # entry -> the "staged" label (address set-up, Q / first tiles issued unless prefetched), from there to the entry barrier (state, zeroed accumulators, prescale, wait)
+                p.emit("s_sub_u32", S_TMP, S_MARKH[1][0], S_MARK[0][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARKE[0], S_MARKH[1][0])
+                a, b = S_TMP, S_TMP2
+            elif tr == 7:    # entry -> in front of the entry barrier, waiting at that barrier
+                p.emit("s_sub_u32", S_TMP, S_MARKE[0], S_MARK[0][0])
+                p.emit("s_sub_u32", S_TMP2, S_MARKH[0][0], S_MARKE[0])
                 a, b = S_TMP, S_TMP2
             elif tr == 6:    # second head body, tail bodies (main bodies minus ... see trace 4 / 1)
                 p.emit("s_sub_u32", S_TMP, S_MARK[1][0], S_MARKH[1][0])

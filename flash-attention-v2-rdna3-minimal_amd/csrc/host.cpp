@@ -13,6 +13,7 @@
 // (reference: kernel_fp16.cu:854-863).
 #include "fa2_launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,7 @@ Options& options() {
         if (const char* e = std::getenv("FA2_PERSIST")) o.persist = std::atoi(e);
         if (const char* e = std::getenv("FA2_SPLIT")) o.split = std::atoi(e) != 0;
         if (const char* e = std::getenv("FA2_FOLD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) o.fold = v; }
+        if (const char* e = std::getenv("FA2_KFOLD")) o.kfold = std::atoi(e) != 0;
         return true;
     }();
     (void)init;
@@ -113,7 +115,9 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
 // row (2 * HD bytes).  Contiguous BHND and BNHD tensors are; a column slice of a wider matrix is not and runs on the HIP kernels (found by the
 // randomised sweep, tools/fuzz_parity.py, once it drew grids wide enough for these kernels: profiles/r06_fuzz_parity_seed5.json).
 bool asm_pitch_ok(int64_t row_stride_elems, int HD) { return row_stride_elems % HD == 0; }
-bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq - 1) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32); }
+// (round 5) Q is staged by LDS-DMA like K: its row pitch has to be a multiple of one tile row too, and the byte offsets of the (up to 63) rows a
+// workgroup's last wave reads past Nq — zero-filled by the descriptor — must not wrap
+bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq + 64) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32) && p.qs[2] % (p.D > 0 ? p.D : 1) == 0; }
 // ... and pays a fixed head and tail per item (the Q tile through LDS, the first K / V tiles before any MFMA, the drain of the software pipeline):
 // over a short KV sweep (cross-attention, low-resolution self-attention) the compiler-scheduled kernels — two waves per SIMD hiding each
 // other's prologue — are faster.  tools/asm_kv_ab.py, one box, fp16, B4 H16 N4096, HIP time / hand-scheduled time at Nkv = 77, 256, 512,
@@ -134,7 +138,7 @@ bool asm_kv_len_ok(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
 // caller's Q holds (|q| * c <= |q|); a larger scale runs the f32-scale body of the same schedule (scale > 0.69 could overflow fp16).
 bool asm_folds(bool bf16, const fa2::FwdParams& p) {
     const int f = fa2::options().fold.load(std::memory_order_relaxed);
-    return (bf16 ? f >= 2 : f >= 1) && p.c <= 1.0f;
+    return (bf16 ? f >= 2 : f >= 1) && p.c <= 1.0f && !p.exact_scale;
 }
 
 // What one launch over the heads [p.bh0, p.bh0 + p.nbh) runs: the ONE place that decides it (launch_range executes the plan, fa2_fwd_plan reports it).
@@ -281,7 +285,10 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     // (the forward's folded contract on the other operand of Q.K^T) with L as the C operand of the product — 32 v_fma fewer per body on the wave role
     // every body waits for.  Same guard as the forward: |scale * log2(e)| <= 1 keeps the prescaled K inside the dtype's range.
     const int fopt = fa2::options().fold.load(std::memory_order_relaxed);
-    const bool kfold = (bf16 ? fopt >= 2 : fopt >= 1) && std::fabs(p.c) <= 1.0f;
+    // Round 5: off unless option "kfold" asks for it.  The forward of a differentiated call scales the f32 product (FA2_FLAG_EXACT_SCALE) and so do both
+    // backward passes: P is recomputed from the very scores L was formed from.  With the fold, gradients at logits of +-30 and more were 2-4x the
+    // suite's tolerance (tests/test_backward_gpu.py::test_hand_scheduled_backward_on_large_logits_under_both_fold_settings).
+    const bool kfold = fa2::options().kfold.load(std::memory_order_relaxed) && (bf16 ? fopt >= 2 : fopt >= 1) && std::fabs(p.c) <= 1.0f;
     for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
         if (!(want & part)) continue;
         int rc;
@@ -334,6 +341,7 @@ int fa2_set_option(const char* name, int value) {
     else if (!std::strcmp(name, "split")) o.split = value != 0;
     else if (!std::strcmp(name, "fold")) { if (value < 0 || value > 2) return FA2_ERR_BAD_SHAPE; o.fold = value; }
     else if (!std::strcmp(name, "bwd_parts")) { if (value < 1 || value > 3) return FA2_ERR_BAD_SHAPE; o.bwd_parts = value; }
+    else if (!std::strcmp(name, "kfold")) o.kfold = value != 0;
     else return FA2_ERR_BAD_SHAPE;
     o.epoch.fetch_add(1, std::memory_order_relaxed);
     return FA2_OK;
@@ -349,6 +357,7 @@ int fa2_get_option(const char* name) {
     if (!std::strcmp(name, "fold")) return o.fold.load();
     if (!std::strcmp(name, "epoch")) return o.epoch.load() & 0x3fffffff;
     if (!std::strcmp(name, "bwd_parts")) return o.bwd_parts.load();
+    if (!std::strcmp(name, "kfold")) return o.kfold.load();
     return FA2_ERR_BAD_SHAPE;
 }
 
@@ -376,6 +385,9 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
                     const int64_t v_strides[3], const int64_t o_strides[3], const int64_t lse_strides[2],
                     float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
                     void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr, fa2_fwd_plan_t* plan_out = nullptr) {
+    // `causal` carries the call's flags: bit 0 = causal mask, bit 1 = FA2_FLAG_EXACT_SCALE (this call scales the f32 product whatever option "fold" says)
+    const bool exact_scale = (causal & FA2_FLAG_EXACT_SCALE) != 0;
+    causal &= 1;
     // ws_need / plan_out: validate and plan only (fa2_fwd_workspace_bytes, fa2_fwd_plan) — the data pointers are stand-ins then
     const bool plan_only = ws_need || plan_out;
     if (ws_need) *ws_need = 0;
@@ -418,6 +430,7 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
     p.bh0 = 0;
     p.nbh = B * H;
     p.rows_hint = 0;
+    p.exact_scale = exact_scale ? 1 : 0;
     p.persist = 1;
     p.full_items = p.split_items = p.nsplit = p.blk0 = p.item_cap = 0;
     p.ws = nullptr;
@@ -456,15 +469,24 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         if (plan_out) {
             std::memset(plan_out, 0, sizeof(*plan_out));
             plan_out->kernel = FA2_KERNEL_HIP_BIAS;
-            plan_out->rows = p.bias_vec == 3 ? 256 : 128;
+            plan_out->rows = 0;       // unspecified: the load form (and with it 128- or 256-row workgroups) depends on the bias strides and alignment, which the query does not take
             plan_out->heads_main = B * H;
         }
         if (plan_only) return FA2_OK;
         return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal != 0, 128, true, stream) : fa2::launch_fwd_hip_f16(HD, p, causal != 0, 128, true, stream);
     }
     if (ws_need) {      // fa2_fwd_workspace_bytes
-        const fa2::SplitPlan pl = plan_split(p, HD, dtype == FA2_DTYPE_BF16, causal != 0);
-        if (pl.nsplit > 1) *ws_need = (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD);
+        // The size query has no scale argument, and the split plan depends on the scale at head dim 64 (a launch that folds the scale — c <= 1 — runs
+        // the parts inside the hand-scheduled kernel: other fixed costs, possibly another S): the answer is the larger of the two plans, so a
+        // workspace of this size serves the call whatever its scale (the callers' caches are keyed without the scale).
+        size_t need = 0;
+        for (const float c_try : {0.5f, 2.0f}) {
+            fa2::FwdParams pt = p;
+            pt.c = c_try;
+            const fa2::SplitPlan pl = plan_split(pt, HD, dtype == FA2_DTYPE_BF16, causal != 0);
+            if (pl.nsplit > 1) need = std::max(need, (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD));
+        }
+        *ws_need = need;
     }
     if (plan_out) {     // fa2_fwd_plan: what launch_fwd would do with a (16-byte aligned) workspace of ws_bytes bytes
         const FwdPlan f = plan_fwd(HD, bf16, p, causal != 0, ws_bytes > 0, ws_bytes);
@@ -548,6 +570,7 @@ static int bwd_impl(int dtype, const void* q, const void* k, const void* v, cons
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
             int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
             void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr) {
+    causal &= 1;          // (bit 1, FA2_FLAG_EXACT_SCALE, is what the backward does anyway unless option "kfold" is set)
     if (ws_need) *ws_need = 0;
     if (bias_kind != FA2_BIAS_NONE) {
         if (bias_kind != FA2_BIAS_IO_DTYPE && bias_kind != FA2_BIAS_F32 && bias_kind != FA2_BIAS_BOOL) return FA2_ERR_BIAS;

@@ -35,7 +35,7 @@ class _FlashAttnWmma:
         time per call instead of ~11) when it was built, else forward_py below."""
         fe = _frontend()
         if fe is not None:
-            return fe.forward(q, k, v, int(Br), int(Bc), bool(causal), float(scale), bool(permute_NH))
+            return fe.forward(q, k, v, int(Br), int(Bc), _fa2_lib.call_flags(causal), float(scale), bool(permute_NH))
         return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, causal, scale, permute_NH)
 
     @staticmethod
@@ -53,8 +53,11 @@ class _FlashAttnWmma:
         ragged Nq / Nkv and any D that is a multiple of 8 in-kernel, so q_pad, k_pad, v_pad are the inputs
         themselves (made contiguous if their strides require it; the reference returns padded copies,
         kernel_fp16.cu:767-779).  Only a D that is not a multiple of 8 is zero-padded, to the next multiple of 8.
-        Br sizes the N padding of O and L; Bc is accepted for signature compatibility."""
+        Br sizes the N padding of O and L; Bc is accepted for signature compatibility.  `causal`: the reference's bool, or the C-ABI's call flags
+        (_fa2_lib.FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE: the operator marks the forward of calls that will be differentiated)."""
         lib = _fa2_lib.load()
+        flags = _fa2_lib.call_flags(causal)
+        causal = bool(flags & _fa2_lib.FA2_FLAG_CAUSAL)
         if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
             raise RuntimeError("fa2: q, k, v must be 4-D ([B,H,N,D] or [B,N,H,D] with BNHD_fmt)")
         if not q.is_cuda or not k.is_cuda or not v.is_cuda:
@@ -115,7 +118,7 @@ class _FlashAttnWmma:
         dev = q.device.index
         args = (dtype_code, q_pad.data_ptr(), k_pad.data_ptr(), v_pad.data_ptr(), O.data_ptr(), L.data_ptr(),
                 b, h, n, n_kv, d_kernel, s3(q_pad), s3(k_pad), s3(v_pad), s3(O),
-                _fa2_lib.strides2(h * (n + nq_pad), n + nq_pad), float(scale), 1 if causal else 0)
+                _fa2_lib.strides2(h * (n + nq_pad), n + nq_pad), float(scale), flags)
         fn = lib.fa2_fwd
         if bias is not None:
             bias_t, kind, bstr = _prepare_bias(bias, b, h, n, n_kv, q_pad.dtype, q.device)
@@ -326,11 +329,15 @@ class FlashAttentionFunction(torch.autograd.Function):
             Br = 32
             Bc = 128
 
-        ret = flash_attn_wmma.forward(q, k, v, Br, Bc, bool(causal), scale, BNHD_fmt)
+        # a call that will be differentiated scales the f32 product (FA2_FLAG_EXACT_SCALE: the reference kernel's contract, kernel_fp16.cu:164) whatever
+        # option "fold" says: the backward then recomputes P from the very scores L was formed from
+        needs_grad = ctx is not None and q.requires_grad
+        flags = (_fa2_lib.FA2_FLAG_CAUSAL if causal else 0) | (_fa2_lib.FA2_FLAG_EXACT_SCALE if needs_grad else 0)
+        ret = flash_attn_wmma.forward(q, k, v, Br, Bc, flags if needs_grad else bool(causal), scale, BNHD_fmt)
 
         o, q_bwd, k_bwd, v_bwd, o_bwd, L = ret
 
-        if ctx is not None and q.requires_grad:       # (ctx is None on the inference fast path below, e.g. under torch.no_grad())
+        if needs_grad:       # (ctx is None on the inference fast path below, e.g. under torch.no_grad())
             ctx.args = (causal, scale, mask, N, Nkv, D, BNHD_fmt)
             ctx.save_for_backward(q_bwd, k_bwd, v_bwd, o_bwd, L)
         return o
@@ -382,7 +389,7 @@ class _MaskedAttentionFunction(torch.autograd.Function):
             if (q.shape[n_ax_] + 63) * k.shape[n_ax_] * (4 if mask.dtype == torch.float32 else 1 if mask.dtype == torch.bool else 2) >= 2 ** 31 - 1:
                 raise RuntimeError("fa2: one (batch, head) slice of the attention mask must span < 2 GiB for the masked backward (fa2_bwd_bias)")
         Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67
-        o, q_bwd, k_bwd, v_bwd, o_bwd, L = flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)
+        o, q_bwd, k_bwd, v_bwd, o_bwd, L = flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)     # (the biased kernels never fold)
         n_ax = 1 if BNHD_fmt else 2
         ctx.args = (causal, scale, q.shape[n_ax], k.shape[n_ax], D, BNHD_fmt)
         ctx.save_for_backward(q_bwd, k_bwd, v_bwd, o_bwd, L, mask)

@@ -151,14 +151,26 @@ class options:
         return False
 
 
+FA2_FLAG_CAUSAL, FA2_FLAG_EXACT_SCALE = 1, 2       # bits of the `causal` argument (include/fa2_gfx950.h)
+
+
+def call_flags(causal):
+    """The `causal` argument of the C-ABI from what a caller of the operator passed: a bool (the reference's argument), or the flags themselves —
+    bit 1, FA2_FLAG_EXACT_SCALE, marks the forward of a call that will be differentiated."""
+    if isinstance(causal, bool) or causal is None:
+        return FA2_FLAG_CAUSAL if causal else 0
+    return int(causal) & 3
+
+
 def fwd_plan(q, k, causal, scale=None, bias_kind=FA2_BIAS_NONE, workspace_bytes=0):
-    """fa2_fwd_plan for the call fa2_fwd*(q, k, ...) would be: which kernel(s) serve it and under which numerical contract."""
+    """fa2_fwd_plan for the call fa2_fwd*(q, k, ...) would be: which kernel(s) serve it and under which numerical contract.  `causal`: bool, or the
+    call's flags (FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE)."""
     B, H, Nq, D = q.shape
     dt = FA2_DTYPE_F16 if q.dtype == torch.float16 else FA2_DTYPE_BF16
     plan = FwdPlan()
     check(load().fa2_fwd_plan(dt, B, H, Nq, k.shape[2], D, strides3(q.stride(0), q.stride(1), q.stride(2)),
                               strides3(k.stride(0), k.stride(1), k.stride(2)), float(D ** -0.5 if scale is None else scale),
-                              int(bool(causal)), int(bias_kind), int(workspace_bytes), ctypes.byref(plan)))
+                              call_flags(causal), int(bias_kind), int(workspace_bytes), ctypes.byref(plan)))
     return plan
 
 

@@ -36,7 +36,10 @@
  *
  * Numerics contract (reference: kernel_fp16.cu:434-490, :510-543)
  *   S = (Q K^T) * scale * log2(e)   (f32 accumulate on MFMA)
- *   causal: (i, j) masked iff j > i, top-left aligned (kernel_fp16.cu:403-410)
+ *   causal: (i, j) masked iff j > i, top-left aligned (kernel_fp16.cu:403-410).  The `causal` argument of every entry point carries the call's
+ *   flags: bit 0 (FA2_FLAG_CAUSAL, i.e. the reference's 0 / 1) and bit 1, FA2_FLAG_EXACT_SCALE: this forward call scales the f32 product like the
+ *   reference kernel (kernel_fp16.cu:164) whatever option "fold" says — the operator sets it on the forward of calls that will be differentiated, so
+ *   that the backward recomputes P from the very scores the saved L was formed from; the backward entry points accept and ignore it
  *   online softmax in f32 (running max m, running sum l), P rounded to the I/O dtype (RNE) for P·V,
  *   O accumulated in f32 registers, O = O / l rounded once to the I/O dtype,
  *   lse[i] = m + log2(l)  — the LOG2-domain log-sum-exp of the scaled scores, i.e.
@@ -47,6 +50,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+
+#define FA2_FLAG_CAUSAL      1
+#define FA2_FLAG_EXACT_SCALE 2
 
 #ifdef __cplusplus
 extern "C" {
@@ -271,7 +277,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
  * Kernels.
  *   FA2_KERNEL_HIP_256 / _128     compiler-scheduled HIP kernel, 8-wave 256-row / 4-wave 128-row workgroups (csrc/fa2_fwd_kernel.hip.h)
  *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py), head dims exactly 64 and 128
- *   FA2_KERNEL_HIP_BIAS           the BIAS forms of the HIP kernel (fa2_fwd_bias)
+ *   FA2_KERNEL_HIP_BIAS           the BIAS forms of the HIP kernel (fa2_fwd_bias); `rows` is reported as 0 = unspecified for it: the load form, and with it
+ *                                 128- or 256-row workgroups, depends on the bias strides and alignment, which this query does not take
  * A call is at most two launches: heads [0, heads_main) of the flattened (b * H + h) order run `kernel` under `contract`, the others (head dims
  * <= 64 whose last round of workgroups is nearly empty: a second launch of 128-row workgroups) run `kernel_tail` under `contract_tail`.
  * nsplit > 1: with a workspace of `workspace_bytes` the `split_items` items of the last round run as nsplit KV-split parts each (fa2_fwd_ws), inside `kernel`.
@@ -313,9 +320,12 @@ int fa2_fwd_prescales_q(int D, float scale);
    "fold"      FA2_FOLD       1 (default) | 0 | 2 — which launches of the hand-scheduled forward bodies fold scale*log2(e) into Q
                               (FA2_CONTRACT_PRESCALE_Q above): 0 none — every launch scales the f32 product like the reference kernel
                               (kernel_fp16.cu:164); 1 fp16 launches; 2 bf16 launches too.  Never when scale*log2(e) > 1 (the prescaled Q could
-                              leave the dtype's range).  This one changes the numerical contract, within the bounds stated there.  It reaches the
-                              backward too: under the same conditions the hand-scheduled dK / dV pass (head dim 128) recomputes P from
-                              K * scale*log2(e) rounded once to the I/O dtype — the same rounding on the other operand of Q.K^T.
+                              leave the dtype's range), never for a call flagged FA2_FLAG_EXACT_SCALE.  This one changes the numerical contract,
+                              within the bounds stated there (measured against float64 per input class: profiles/r16_fold_evidence.txt — bf16, option
+                              value 2, leaves BASELINE.md's acceptance from logits of ~+-20 on, which is why it stays opt-in).
+   "kfold"     FA2_KFOLD      0 (default) | 1 — the hand-scheduled dK / dV pass (head dim 128) recomputes P from K * scale*log2(e) rounded once
+                              to the I/O dtype, for the dtypes "fold" covers (round 4's default; -1.8 % backward time, but gradients 2-4x
+                              the f32-scale pass's error at logits of +-30: off since round 5)
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

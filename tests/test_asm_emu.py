@@ -228,9 +228,9 @@ def test_generated_text_assembles_for_gfx950(opt, tmp_path):
     mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
     if not os.path.exists(mc):
         pytest.skip("llvm-mc not available")
-    subst = {0: "v0", 1: "v1", 2: "v2", 3: "v3", 4: "s[0:1]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
+    subst = {0: "v0", 1: "v1", 2: "v2", 3: "s2", 4: "s[36:39]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
              12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
-             23: "v13", 24: "v14", 25: "s[22:23]", 26: "s[24:27]", 27: "s[28:31]", 28: "s[32:33]"}
+             23: "s21", 24: "s3", 25: "s[40:43]", 26: "s[24:27]", 27: "s[28:31]", 28: "s[32:33]"}
     for bf16, hd in ((False, 128), (True, 128), (False, 64), (True, 64)):
         text = "\n".join(gen.Gen(bf16, hd=hd, opt=opt).build().text_lines())
         text = re.sub(r"%(\d+)", lambda m: subst[int(m.group(1))], text.replace("%=", "0"))

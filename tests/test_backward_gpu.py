@@ -329,3 +329,60 @@ def test_reference_precision_shape_backward(causal):
     for (b, h) in ((0, 0), (2, 6), (1, 3)):
         sl = (slice(b, b + 1), slice(h, h + 1))
         _check_vs_oracle(q[sl], k[sl], v[sl], do[sl], o[sl].detach(), lse[sl], [t.grad[sl] for t in (qa, ka, va)], dt, causal, scale=111 ** -0.5)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_differentiated_calls_scale_the_f32_product_on_large_logits(causal):
+    """Option `fold` = 1 (the fp16 default) lets forward launches of the hand-scheduled bodies round Q * scale * log2(e) to fp16 once, and round 4
+    let the dK / dV pass do the same to K (`kfold`): the P a backward pass recomputes then differs from the P behind the saved L by ~|logit| * 2^-11
+    relative — measured here at 3x the amplitude of the suite's other cases (logits of +-30 and more) on a grid that reaches the hand-scheduled
+    D = 128 passes: dQ 2.4e-3 .. 4.1e-3 of the largest gradient under fold = 1 against 0.7e-3 .. 1.1e-3 with every pass scaling the f32 product
+    (GRAD_TOL: 2e-3).  Since round 5 the operator flags the forward of a call that will be differentiated FA2_FLAG_EXACT_SCALE and
+    `kfold` is off by default: forward and both backward passes form P from the same scores.  Checked against float64 autograd — nothing of the
+    kernel enters the expectation — through the operator under the DEFAULT options, and the plan of the flagged call must say so."""
+    dt = 0
+    B, H, N, D = 2, 8, 1024, 128
+    g = torch.Generator(device="cpu").manual_seed(77 + int(causal))
+    q, k = (3.0 * torch.randn((B, H, N, D), generator=g)).half().to(_dev()), (3.0 * torch.randn((B, H, N, D), generator=g)).half().to(_dev())
+    v, do = torch.randn((B, H, N, D), generator=g).half().to(_dev()), torch.randn((B, H, N, D), generator=g).half().to(_dev())
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.matmul(qd, kd.transpose(-1, -2)) * (D ** -0.5)
+    assert float(s.detach().abs().max()) > 30.0                          # the logits this test is about
+    if causal:
+        s = s.masked_fill(torch.ones(N, N, dtype=torch.bool, device=_dev()).triu(1), float("-inf"))
+    torch.matmul(torch.softmax(s, -1), vd).backward(do.double())
+    with _fa2_lib.options(rows=256):                                     # (the hand-scheduled kernels on this grid; fold / kfold at their defaults)
+        assert _fa2_lib.load().fa2_get_option(b"fold") == 1 and _fa2_lib.load().fa2_get_option(b"kfold") == 0
+        plain = _fa2_lib.fwd_plan(q, k, causal)
+        flagged = _fa2_lib.fwd_plan(q, k, (_fa2_lib.FA2_FLAG_CAUSAL if causal else 0) | _fa2_lib.FA2_FLAG_EXACT_SCALE)
+        assert plain.kernel == flagged.kernel == _fa2_lib.FA2_KERNEL_ASM
+        assert plain.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q and flagged.contract == 0
+        qa, ka, va = (t.detach().requires_grad_(True) for t in (q, k, v))
+        o = FlashAttentionFunction.apply(qa, ka, va, None, causal)
+        o.backward(do)
+        o_inf = FlashAttentionFunction.apply(q, k, v, None, causal)      # the same call without gradients: the folded body
+        torch.cuda.synchronize()
+    for name, got, want in zip("qkv", (qa.grad, ka.grad, va.grad), (qd.grad, kd.grad, vd.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        err = float((got.double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert err <= GRAD_TOL[dt], (name, err)
+    # the two forward contracts differ by the rounding of Q * c, and only by that (profiles/r16_fold_evidence.txt has the table against float64)
+    assert not torch.equal(o.detach(), o_inf) and float((o.detach().float() - o_inf.float()).abs().max()) <= 2e-2
+
+
+def test_kfold_option_keeps_the_suite_tolerance_on_unit_scale_inputs():
+    """Option `kfold` = 1 (round 4's default, opt-in since round 5): the hand-scheduled dK / dV pass takes its P from K * scale * log2(e) rounded once to
+    fp16 (generator option `kfold`, emulated in tests/test_asm_emu_bwd.py).  On N(0,1) inputs — logits of a few units — it holds the suite's tolerance
+    against the C oracle fed the kernel's own O and L, and differs from the f32-scale pass."""
+    dt = 0
+    g = torch.Generator(device="cpu").manual_seed(91)
+    mk = lambda: torch.randn((1, 8, 1024, 128), generator=g).half().to(_dev())  # noqa: E731
+    q, k, v, do = mk(), mk(), mk(), mk()
+    res = {}
+    for kfold in (0, 1):
+        with _fa2_lib.options(kfold=kfold, rows=256):
+            o, lse, grads = _cabi_fwd_bwd(q, k, v, do, False)
+        _check_vs_oracle(q[:, :2], k[:, :2], v[:, :2], do[:, :2], o[:, :2], lse[:, :2], [t[:, :2] for t in grads], dt, False)
+        res[kfold] = grads
+    assert not torch.equal(res[0][1], res[1][1])              # dK came from another body
+    assert torch.equal(res[0][0], res[1][0])                  # the dQ pass is the same

@@ -733,22 +733,26 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2 ...` with NO torch.distributed.run around it (the command shape the driver records): bench.py
     re-executes itself under the launcher on a free loopback port, the two ranks (both on cuda:0 over gloo here — NCCL refuses two
-    ranks on one device) run the c2 shard each and rank 0 prints the one JSON line with n_gpus = 2 and the ranks the group saw."""
+    ranks on one device) run and rank 0 prints the one JSON line with n_gpus = 2 and the ranks the group saw.  With no --workload an
+    N > 1 run measures BASELINE.json's multi-GPU configuration — c5, B = 64 split over the ranks (strong scaling) — as `value` and
+    carries the c2 weak-scaling figure under `weak_c2`; the line states the cold (pre-settle) number and every launch that preceded the timed region."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--same-device", "--steady-launches", "0"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
-    assert rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 64 and rec["scaling"] == "strong" and rec["config"]["workload"].startswith("c5: B32 ")
+    assert rec["weak_c2"]["global_batch"] == 4 and rec["weak_c2"]["scaling"] == "weak" and rec["weak_c2"]["value"] > 0
+    assert rec["cold"]["value"] > 0 and rec["warmup_effective"] >= 1 + (1 + 3) + rec["settle"]["launches"] + 1
     assert rec["dist"]["world_size"] == 2 and sorted(r["rank"] for r in rec["dist"]["ranks"]) == [0, 1]
 
 

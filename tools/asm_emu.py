@@ -394,7 +394,8 @@ class Machine:
             sx = x - (1 << 32) if x & 0x80000000 else x
             sy = y - (1 << 32) if y & 0x80000000 else y
             w.scc = int({"s_cmp_eq_u32": x == y, "s_cmp_lg_u32": x != y, "s_cmp_lt_i32": sx < sy, "s_cmp_gt_i32": sx > sy,
-                         "s_cmp_ge_i32": sx >= sy, "s_cmp_le_i32": sx <= sy, "s_cmp_lt_u32": x < y}[op])
+                         "s_cmp_ge_i32": sx >= sy, "s_cmp_le_i32": sx <= sy, "s_cmp_lt_u32": x < y, "s_cmp_ge_u32": x >= y, "s_cmp_gt_u32": x > y,
+                         "s_cmp_le_u32": x <= y}[op])
         elif op == "s_cselect_b32":
             d = R(0)
             w.s[d.idx] = np.uint32(self.rds(w, ops[1]) if w.scc else self.rds(w, ops[2]))
@@ -638,7 +639,7 @@ class Machine:
                 o = int(off[l]) & 0xffffffff
                 if o + 4 <= nrec:
                     data[l] = self.gread(base + o, 4)
-            dst_addr = (w.m0 & 0xffff) + LANES * 4 + ins.mods.get("offset", 0)
+            dst_addr = (w.m0 & 0x3ffff) + LANES * 4 + ins.mods.get("offset", 0)
 
             def land(dst_addr=dst_addr, data=data):
                 self.lds_write(w, dst_addr, data)
@@ -680,7 +681,7 @@ class Machine:
                 o = int(off[l]) & 0xffffffff
                 if o + 16 <= nrec:
                     data[l] = self.gread(base + o, 16)
-            dst_addr = (w.m0 & 0xffff) + LANES * 16 + ins.mods.get("offset", 0)
+            dst_addr = (w.m0 & 0x3ffff) + LANES * 16 + ins.mods.get("offset", 0)
 
             def land(dst_addr=dst_addr, data=data):
                 self.lds_write(w, dst_addr, data)

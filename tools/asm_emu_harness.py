@@ -58,15 +58,10 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     args = {}
     v = np.zeros((24, 64), dtype=np.uint32)
 
-    def q_offsets(qblk_, Nq_):
-        out = []
-        for qb in range(2):
-            qrow = qblk_ * 256 + 64 * w + 32 * qb + l31
-            qr = np.minimum(qrow, Nq_ - 1)
-            out.append((qr.astype(np.int64) * row_bytes + hi * 16).astype(np.uint32))
-        return out
+    def q_wave_offset(qblk_, Nq_):          # byte offset of this wave's first Q row (a wave wholly past Nq stages rows 0..63: never stored)
+        r0 = qblk_ * 256 + 64 * w
+        return (r0 if r0 < Nq_ else 0) * row_bytes
 
-    v[2], v[3] = q_offsets(qblk, Nq)
     for qb in range(2):
         qrow = qw0 + 32 * qb + l31
         lim_c = qrow if causal else np.full(64, 0x3fffffff)
@@ -80,6 +75,8 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     slot = lane % gran
     gk = slot ^ ((row // rpb) & kmask)
     v[7] = (row * row_bytes + gk * 16).astype(np.uint32)
+    qrow = lane // gran                                 # Q: piece 0 of a 16-row group, the K image's swizzle
+    v[2] = (qrow * row_bytes + ((slot ^ ((qrow // rpb) & kmask)) * 16)).astype(np.uint32)
     gv = (((slot >> 2) ^ ((row // rpb) & vmask)) << 2) | (slot & 3)
     v[8] = (row * row_bytes + gv * 16).astype(np.uint32)
     v[9] = (l31 * g.ROWB + ((hi ^ ((l31 // rpb) & kmask)) << 4)).astype(np.uint32)
@@ -94,8 +91,8 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         return np.array([base & 0xffffffff, base >> 32], dtype=np.uint32)
 
     args[0], args[1] = Reg("v", 0), Reg("v", 1)
-    args[2], args[3] = Reg("v", 2), Reg("v", 3)
-    args[4] = pair(q_base)
+    args[2], args[3] = Reg("v", 2), q_wave_offset(qblk, Nq)
+    args[4] = srd(q_base, Nq)
     args[5], args[6] = srd(k_base, Nkv), srd(v_base, Nkv)
     for n in range(7, 13):
         args[n] = Reg("v", n)
@@ -106,13 +103,14 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     args[20] = w * (g.SLOT_B // 4)
     args[21] = Reg("v", 13)
     args[22] = flags
-    args[23], args[24] = Reg("v", 14), Reg("v", 15)
+    args[24] = 16 * row_bytes
     if nxt is not None:
         nqblk, nNq, nq_base, nk_base, nv_base, nNkv = nxt
-        v[14], v[15] = q_offsets(nqblk, nNq)
-        args[25], args[26], args[27] = pair(nq_base), srd(nk_base, nNkv), srd(nv_base, nNkv)
+        args[23] = q_wave_offset(nqblk, nNq)
+        args[25], args[26], args[27] = srd(nq_base, nNq), srd(nk_base, nNkv), srd(nv_base, nNkv)
     else:
-        args[25], args[26], args[27] = pair(q_base), args[5], args[6]
+        args[23] = args[3]
+        args[25], args[26], args[27] = args[4], args[5], args[6]
     # KV-split parts (flag bit 3): workspace tile of the part, this lane's row 64*w + l31 and half hi
     args[28] = pair(ws_base)
     args["vregs"] = v

@@ -177,9 +177,10 @@ def run(names, rounds, iters, cfgs, fill="rand"):
             if "trace" in var.name:     # developer builds of the d128 kernel that return cycle sums in the LSE tensor
                 var.fwd(q, k, v, o, lse, causal, stream)
                 torch.cuda.synchronize()
-                x = lse[0, 0].reshape(-1, 64)      # [q block * 4 + wave, 64]: first 32 = output 0, next 32 = output 1
-                print("   %s: per-wave sums (out0, out1) of q block 0: %s  last q block: %s" % (
-                    var.name, [(float(x[w, 0]), float(x[w, 32])) for w in range(4)], [(float(x[-4 + w, 0]), float(x[-4 + w, 32])) for w in range(4)]))
+                for (bb, hh) in ((0, 0), (B - 1, H - 1)):      # (c2: the heads of batch 1 are the workgroups' second items)
+                    x = lse[bb, hh].reshape(-1, 64)      # [q block * 4 + wave, 64]: first 32 = output 0, next 32 = output 1
+                    print("   %s: head (%d,%d) per-wave sums (out0, out1) of q block 0: %s  last q block: %s" % (
+                        var.name, bb, hh, [(float(x[w, 0]), float(x[w, 32])) for w in range(4)], [(float(x[-4 + w, 0]), float(x[-4 + w, 32])) for w in range(4)]))
         for name, ts in times.items():
             med, mn = statistics.median(ts), min(ts)
             print("   %-16s median %8.1f us  %7.1f TF (%4.1f%%)   best %8.1f us  %7.1f TF"

@@ -113,6 +113,34 @@ def test_persistent_workgroup_seams(seam, variant):
         assert np.abs(lse - lse_ref).max() <= 1e-4
 
 
+@pytest.mark.parametrize("hd", [128, 64])
+def test_tail_prescale_option_is_kept_correct(hd):
+    """opt=qpre (measured, not shipped — profiles/r16_kbench_eq2_tail_prescale_ab.txt): folded-scale kernels prescale the NEXT item's Q fragments between the
+    MFMAs of the item's last body (TCQ / STQ variants) and the next statement's entry skips its prescale.  Non-causal and causal seams (waves that
+    finish early run the STQ variant), items of one tile (the seam is a head body)."""
+    import numpy as np
+    saved = harness.HD, harness.OPT
+    harness.HD, harness.OPT = hd, ("ct", "qpre")
+    harness._PROGS.clear()
+    try:
+        rng = np.random.default_rng(hd + 7)
+        items = [(rng.standard_normal((512, hd)), rng.standard_normal((nkv, hd)), rng.standard_normal((nkv, hd)), qb) for nkv, qb in zip([640, 64, 200], [0, 1, 0])]
+        outs, m = harness.run_items(items, False)
+        assert not m.errors, m.errors[:5]
+        for (q, k, v, qb), (o, lse) in zip(items, outs):
+            o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256, pre=True)
+            assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-4
+        q, k, v = (rng.standard_normal((768, hd)) for _ in range(3))
+        outs, m = harness.run_items([(q, k, v, 2), (q, k, v, 0), (q, k, v, 1)], True)
+        assert not m.errors, m.errors[:5]
+        o_ref, _ = harness.dense(q, k, v, True, pre=True)
+        for qb, (o, _) in zip([2, 0, 1], outs):
+            assert np.abs(o - o_ref[qb * 256:qb * 256 + 256]).max() <= 1e-3
+    finally:
+        harness.HD, harness.OPT = saved
+        harness._PROGS.clear()
+
+
 D64_CASES = [
     # Nq, Nkv, q block, causal, bf16, spike: the head-dim-64 body of the same generator (hd=64: 16 + 8 PV-phase MFMAs — the row sums
     # ride the matrix pipe — and 16 QK-phase MFMAs per tile, 128-byte tile rows)

@@ -8,6 +8,8 @@
 // `backward` (unmasked calls) likewise: the Python backward costs ~50 us of host time per call, which SD-size training shapes are bound by.
 //
 // Host-only C++ (g++): no device code here, the kernels live in libfa2_gfx950.so.
+#include <mutex>
+#include <cstdlib>
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm presents its devices as "cuda": the masquerading guard / stream
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -43,6 +45,34 @@ size_t cached_ws_bytes(int which, int dtype, int dev, int64_t b, int64_t h, int6
     if (cache.size() >= 64) cache.clear();
     cache.push_back({key, bytes});
     return bytes;
+}
+
+// The split's scratch: ONE block per (device, stream), reused by every later call on that stream and grown when a call needs more (kernels of one
+// stream run in order: the merge of call n has read the tiles before the parts of call n + 1 write them).  The operator's footprint is then its outputs
+// plus at most 64 MiB per stream in use, not a fresh block per call in flight (the reference records peak memory on every run, bench_with_sdpa.py:34).
+// While the stream is being captured into a graph the block comes from the caching allocator (the capture's private pool keeps it alive for the
+// replays).  FA2_WS_POOL=0: per-call allocation.  Forward (caller's thread) and backward (the autograd engine's device thread) share the pool: a mutex.
+at::Tensor workspace(size_t bytes, const at::Tensor& like, hipStream_t stream) {
+    static const bool pool_on = [] { const char* e = std::getenv("FA2_WS_POOL"); return !(e && e[0] == '0'); }();
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!pool_on || (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone))
+        return at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+    struct Slot { int dev; hipStream_t stream; at::Tensor ws; };
+    static std::mutex mu;
+    static std::vector<Slot> pool;
+    const int dev = like.device().index();
+    std::lock_guard<std::mutex> lock(mu);
+    for (size_t i = 0; i < pool.size(); ++i)
+        if (pool[i].dev == dev && pool[i].stream == stream) {
+            if ((size_t)pool[i].ws.numel() < bytes) pool[i].ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+            Slot s = pool[i];
+            pool.erase(pool.begin() + i);
+            pool.push_back(s);                      // most recently used last
+            return s.ws;
+        }
+    if (pool.size() >= 8) pool.erase(pool.begin());  // least recently used stream
+    pool.push_back({dev, stream, at::empty({(int64_t)bytes}, like.options().dtype(at::kByte))});
+    return pool.back().ws;
 }
 
 std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_t Br, int64_t Bc, int64_t flags, double scale,
@@ -106,10 +136,10 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     s3(O, os);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream();
-    // scratch for the KV-split of a partly filled last round of workgroups (fa2_fwd_ws): from the caching allocator, per call
+    // scratch for the KV-split of a partly filled last round of workgroups (fa2_fwd_ws): the per-stream block above
     at::Tensor ws;
     const size_t ws_bytes = causal ? 0 : cached_ws_bytes(0, dtype_code, q.device().index(), b, h, n, n_kv, d_kernel);
-    if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, q.options().dtype(at::kByte));
+    if (ws_bytes) ws = workspace(ws_bytes, q, stream);
     const int rc = fa2_fwd_ws(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
                               (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, (int)(flags & 3),
                               ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);
@@ -148,7 +178,7 @@ std::vector<at::Tensor> backward(at::Tensor Q, at::Tensor K, at::Tensor V, at::T
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Q.device().index()).stream();
     at::Tensor ws;
     const size_t ws_bytes = causal ? 0 : cached_ws_bytes(1, dtype_code, Q.device().index(), b, h, act_n, act_nkv, dk);
-    if (ws_bytes) ws = at::empty({(int64_t)ws_bytes}, Q.options().dtype(at::kByte));
+    if (ws_bytes) ws = workspace(ws_bytes, Q, stream);
     const int rc = fa2_bwd_ws(dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr<float>(), dQ.data_ptr(),
                               dK.data_ptr(), dV.data_ptr(), delta.data_ptr<float>(), (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, qs, ks, vs, os, gs,
                               dqs, dks, dvs, ls, (float)scale, causal ? 1 : 0, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);

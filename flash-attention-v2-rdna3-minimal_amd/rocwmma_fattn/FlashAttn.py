@@ -191,7 +191,7 @@ class _FlashAttnWmma:
             # scratch for the split of a partly filled last round of workgroups (fa2_bwd_ws / fa2_bwd_bias_ws, the backward's twins of fa2_fwd_ws)
             need = (lib.fa2_bwd_workspace_bytes if bias is None else lib.fa2_bwd_bias_workspace_bytes)(dtype_code, b, h, act_n, act_nkv, dk, 0)
             if need:
-                ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
+                ws = _workspace(need, Q.device, Q.device.index, stream)
                 args += (ws.data_ptr(), need)
                 fn = lib.fa2_bwd_ws if bias is None else lib.fa2_bwd_bias_ws
         args += (stream,)
@@ -207,10 +207,40 @@ class _FlashAttnWmma:
         return [dQ[:, :, :act_n, :act_d], dK[:, :, :act_nkv, :act_d], dV[:, :, :act_nkv, :act_d]]
 
 
+_WS_POOL = {}            # (device index, raw stream) -> uint8 tensor: the split's scratch, allocated once per stream and reused (grown when a call needs more)
+_WS_POOL_MAX = 8         # streams with a pooled workspace (least recently used dropped beyond that)
+
+
+def _workspace(need, device, dev, stream):
+    """`need` bytes of scratch for a call on `stream`: ONE tensor per (device, stream), reused by every later call on that stream (kernels of one
+    stream run in order, so the merge of call n has read the tiles before the parts of call n + 1 write them) — the operator's memory footprint is
+    its outputs plus at most 64 MiB per stream in use, instead of a fresh block per call in flight (the reference records peak
+    memory on every run, bench_with_sdpa.py:34).  While a graph is being captured the block comes from the allocator (the capture's private pool
+    keeps it alive for the graph's replays); FA2_WS_POOL=0 restores per-call allocation."""
+    if not _POOL_ON or torch.cuda.is_current_stream_capturing():
+        return torch.empty(need, dtype=torch.uint8, device=device)
+    key = (dev, stream)
+    ws = _WS_POOL.pop(key, None)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        while len(_WS_POOL) >= _WS_POOL_MAX:
+            _WS_POOL.pop(next(iter(_WS_POOL)))
+    _WS_POOL[key] = ws       # (re-inserted: most recently used last)
+    return ws
+
+
+def workspace_pool_bytes():
+    """Bytes the per-stream scratch blocks of this process hold right now (tools/scan_bench.py reports it beside the peak)."""
+    return sum(t.numel() for t in _WS_POOL.values())
+
+
+_POOL_ON = os.environ.get("FA2_WS_POOL", "1") != "0"
+
+
 def _launch_fwd(lib, fn, args, dev, device, may_split):
     """The C-ABI call on torch's current stream.  Non-causal, unbiased launches go through fa2_fwd_ws when the library can use a
     workspace for this shape (KV-split of the last, partly filled round of workgroups: include/fa2_gfx950.h): scratch memory from
-    torch's caching allocator, taken per call — stream-ordered reuse and graph capture are then the allocator's business."""
+    the per-stream pool above."""
     if may_split:
         # (the size is a function of dtype, shape, device and the library's options: asked once per shape — _fa2_lib.options() and
         #  _fa2_lib.set_option() drop the cache; a stale entry would only cost the split, the library re-plans every call itself)
@@ -221,8 +251,9 @@ def _launch_fwd(lib, fn, args, dev, device, may_split):
                 _WS_CACHE.clear()
             need = _WS_CACHE[key] = lib.fa2_fwd_workspace_bytes(args[0], *args[6:11], 0)
         if need:
-            ws = torch.empty(need, dtype=torch.uint8, device=device)
-            return lib.fa2_fwd_ws(*args, ws.data_ptr(), need, _raw_stream(dev))
+            stream = _raw_stream(dev)
+            ws = _workspace(need, device, dev, stream)
+            return lib.fa2_fwd_ws(*args, ws.data_ptr(), need, stream)
     return fn(*args, _raw_stream(dev))
 
 

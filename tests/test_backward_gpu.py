@@ -279,7 +279,7 @@ def test_pinned_workgroup_shapes_and_kernel_families():
 def test_backward_with_a_negative_scale_on_ragged_and_causal_shapes(D, dt):
     """Negative scales through every backward kernel family (the hand-scheduled D = 128 passes, the fused D <= 64 pass, the wave-pair pass),
     with a ragged Nkv and with the causal mask: masked scores must stay masked whatever the sign of scale * log2(e)
-    (found by tools/fuzz_parity.py: the hand-scheduled passes turned them into +inf, profiles/r06_fuzz_parity_seed6.json)."""
+    (found by tools/fuzz_parity.py: the hand-scheduled passes turned them into +inf, profiles/fuzz_runs.md, row r06_fuzz_parity_seed6)."""
     for (N, Nkv, causal) in ((320, 300, False), (416, 416, True), (96, 77, False)):
         g = torch.Generator(device="cpu").manual_seed(N + D)
         q, do = (torch.randn((2, 3, N, D), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))

@@ -974,7 +974,7 @@ def test_padded_row_pitch_on_grids_wide_enough_for_the_hand_scheduled_kernels(D,
     """Column slices of wider matrices (row pitch D + 8 / D + 16 elements) on a grid of 256 workgroups of 256 rows.  The hand-scheduled bodies
     derive a wave's further LDS-DMA source offsets by flipping granule bits of the first, which only equals re-swizzling when the staged matrix's
     row pitch is a multiple of a tile row; host.cpp (asm_pitch_ok) sends other pitches to the HIP kernels.  The randomised sweep found the
-    missing check once it drew grids this wide (profiles/r06_fuzz_parity_seed5.json: LSE off by 2e-2 with a padded K).  Forward against the
+    missing check once it drew grids this wide (profiles/fuzz_runs.md, row r06_fuzz_parity_seed5: LSE off by 2e-2 with a padded K).  Forward against the
     oracle and dense fp32, backward against float64 autograd, with every operand padded in turn."""
     from conftest import GRAD_TOL
     B, H, N = 2, 16, 2048

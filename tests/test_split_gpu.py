@@ -299,8 +299,9 @@ def test_operator_backward_takes_the_split_path_and_option_turns_it_off():
 
 @pytest.mark.gpu
 def test_split_launches_are_graph_capturable_and_stream_safe():
-    """The operator takes the split's workspace from torch's caching allocator per call, so a captured graph owns its scratch memory (graph pool)
-    and two streams never share one: capture a forward of a split shape, replay it on new inputs, and run two streams concurrently."""
+    """The operator keeps ONE scratch block per (device, stream) for the split and takes a block from torch's caching allocator while a stream is being
+    captured, so a captured graph owns its scratch memory (graph pool) and two streams never share one: capture a forward of a split shape, replay
+    it on new inputs, and run two streams concurrently."""
     B, H, N, D = 2, 10, 4096, 64
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(9)
@@ -340,6 +341,50 @@ def test_split_launches_are_graph_capturable_and_stream_safe():
             outs.append(o)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], wa) and torch.equal(outs[1], wb)
+
+
+@pytest.mark.gpu
+def test_split_scratch_is_one_block_per_stream_not_one_per_call():
+    """the operator used to take the split's workspace (up to 64 MiB) from the allocator on every call.  Now one block per
+    (device, stream) is allocated on first use and reused: across 20 calls of a split shape the allocator's peak stays at inputs + one output
+    set + the one block, the block's address does not change, and a second stream gets its own."""
+    from rocwmma_fattn import FlashAttn
+    B, H, N, D = 1, 24, 3584, 64                     # the reference harness's N-scan shape (bench_with_sdpa.py:52, :201-224): 336 items -> split
+    dev = _dev()
+    q, k, v = (torch.rand((B, H, N, D), device=dev).half() for _ in range(3))
+    need = _fa2_lib.load(build_if_missing=False).fa2_fwd_workspace_bytes(0, B, H, N, N, D, 0)
+    assert need > 0
+    for python_front_end in (False, True):
+        saved = FlashAttn._FRONTEND[0]
+        if python_front_end:
+            FlashAttn._FRONTEND[0] = None
+        try:
+            FlashAttentionFunction.apply(q, k, v, None, False)       # first use: the block exists from here on
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            for _ in range(20):
+                o = FlashAttentionFunction.apply(q, k, v, None, False)
+            torch.cuda.synchronize()
+            out_bytes = o.numel() * 2 + B * H * N * 4
+            assert torch.cuda.max_memory_allocated() - base <= 2 * out_bytes + (1 << 20), (torch.cuda.max_memory_allocated() - base, out_bytes, need)
+            del o
+        finally:
+            FlashAttn._FRONTEND[0] = saved
+    assert FlashAttn.workspace_pool_bytes() >= need               # (the Python front end's pool; the compiled one keeps its own)
+    ptr = [t.data_ptr() for t in FlashAttn._WS_POOL.values()]
+    FlashAttn._FRONTEND[0], saved = None, FlashAttn._FRONTEND[0]
+    try:
+        FlashAttentionFunction.apply(q, k, v, None, False)
+        assert [t.data_ptr() for t in FlashAttn._WS_POOL.values()] == ptr
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            FlashAttentionFunction.apply(q, k, v, None, False)
+        torch.cuda.synchronize()
+        assert len(FlashAttn._WS_POOL) == len(ptr) + 1
+    finally:
+        FlashAttn._FRONTEND[0] = saved
 
 
 @pytest.mark.gpu

@@ -22,9 +22,12 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
         // Causal pair units against one item per workgroup in longest-first order, same box (tools/fwd_ab.py, MI355X): B8 H16 N4096 +5.2 %,
         // B1 H8 N16384 +1.4 %, B1 H32 N8192 +0.7 %, but B2 H16 N4096 -2.2 % and B4 H16 N2048 -2.0 %: with a single short unit per workgroup
         // the hardware's dynamic dispatch of single items is the better balancer.  Pairs when a workgroup gets several units or a head has >= 32 blocks.
+        // Round 5 (the next item's Q staged through LDS during the item, read at the seam): a grid of exactly one unit per CU is ahead with pairs too —
+        // B2 H16 N4096 bf16 112.7 -> 112.1 us, B4 H16 N2048 70.0 -> 69.4 (profiles/r16_kbench_pairs_ab.txt); fewer units than CUs keep single items
+        // (twice the workgroups: more of the chip busy).
         const int64_t units = (int64_t)p.nbh * ((p.nqblk + 1) / 2);
 #ifndef FA2_PAIRS_ALWAYS      // (developer A/B: tools/kbench.py build pairs:-DFA2_PAIRS_ALWAYS=1)
-        if (!(units > pg || p.nqblk >= 32)) p.persist = 0;
+        if (!(units >= pg || p.nqblk >= 32)) p.persist = 0;
 #endif
     }
     // work units: non-causal one per (head, q block); causal one per PAIR of q blocks of a head (fa2_fwd_d128.hip.h)

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Which MFMA shape should the forward body use on a POWER-LIMITED chip?  (developer probe, round 5)
+
+profiles/mfma_peak.json: a loop of nothing but v_mfma_f32_16x16x32_f16 sustains 1 969 TF on U[0,1) operands with two waves per SIMD where the
+32x32x16 form sustains 1 738 — the smaller tile moves half the accumulator bytes per FLOP — but only 1 531 with ONE wave per SIMD (a lone wave cannot
+issue a 16-cycle MFMA every 16 cycles).  The hand-scheduled forward is one wave per SIMD and is not MFMA-issue-bound but energy-bound (DESIGN
+section 3), so the question is what its BODY would do with the other shape: the same FLOPs as 128 MFMAs of 16 pipe cycles instead of 64 of 32, the
+same single-issue fillers (64 v_exp_f32, 64 v_add_f32, 32 v_cvt_pk, 16 ds_read_b128, 32 ds_read_b64_tr_b16 per 64 x 64 tile) spread over twice the
+gaps.  This script writes two synthetic kernels — a tile body of each shape in one inline-asm loop, accumulator chains like the real body (Q.K^T: short
+chains that restart from C = 0; P.V: long-lived accumulators), static U[0,1) fp16 operands, fillers on scratch registers — compiles them and, on the
+GPU, times them interleaved.  Results are not attention; cycle counts, clocks and energy are the point.
+
+    python tools/ubench/mfma_shape_probe.py build        (CPU container: writes mfma_shape_probe.hip and compiles tools/ubench/mfma_shape_probe)
+    tools/ubench/mfma_shape_probe                         (GPU box: prints one JSON line)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.realpath(__file__))
+
+FILL = {"exp": 64, "add": 64, "cvt": 32, "kread": 16, "vread": 32}
+
+
+def fillers(nofill=()):
+    """The body's single-issue work as a list of instruction strings, interleaved the way the generator's water-filling leaves them: evenly."""
+    out = []
+    streams = []
+    for kind, n in FILL.items():
+        if kind in nofill:
+            continue
+        lst = []
+        for j in range(n):
+            if kind == "exp":
+                lst.append("v_exp_f32 v%d, v%d" % (200 + j % 8, 208 + j % 8))
+            elif kind == "add":
+                lst.append("v_add_f32 v%d, v%d, v%d" % (216 + j % 2, 216 + j % 2, 200 + (j * 3) % 8))
+            elif kind == "cvt":
+                lst.append("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (220 + j % 4, 200 + (2 * j) % 8, 200 + (2 * j + 1) % 8))
+            elif kind == "kread":
+                lst.append("ds_read_b128 v[%d:%d], %%3 offset:%d" % (224 + 4 * (j % 4), 227 + 4 * (j % 4), 1024 * (j % 16)))
+            else:
+                lst.append("ds_read_b64_tr_b16 v[%d:%d], %%4 offset:%d" % (240 + 2 * (j % 4), 241 + 2 * (j % 4), 16384 + 512 * (j % 32)))
+        streams.append(lst)
+    total = sum(len(s) for s in streams)
+    pos = []
+    for s in streams:
+        for j, ins in enumerate(s):
+            pos.append(((j + 0.5) / len(s), ins))
+    pos.sort(key=lambda x: x[0])
+    return [ins for _, ins in pos], total
+
+
+def body(shape, nofill=()):
+    """One tile body: MFMAs with the fillers spread evenly over the gaps."""
+    fl, _ = fillers(nofill)
+    mf = []
+    if shape == 32:
+        # P.V-like: 8 accumulators x 4 k-steps (a[64:191]); Q.K^T-like: 4 accumulators x 8 k-steps, the first from C = 0 (a[0:63])
+        for ks in range(4):
+            for acc in range(8):
+                a0 = 64 + 16 * acc
+                mf.append("v_mfma_f32_32x32x16_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 15, 16 + 4 * ((acc + ks) % 8), 19 + 4 * ((acc + ks) % 8),
+                                                                                        48 + 4 * ((2 * ks + acc // 4) % 8), 51 + 4 * ((2 * ks + acc // 4) % 8), a0, a0 + 15))
+        for ks in range(8):
+            for acc in range(4):
+                a0 = 16 * acc
+                c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 15)
+                mf.append("v_mfma_f32_32x32x16_f16 a[%d:%d], v[%d:%d], v[%d:%d], %s" % (a0, a0 + 15, 16 + 4 * ((ks + acc) % 8), 19 + 4 * ((ks + acc) % 8),
+                                                                                  48 + 4 * ((ks + 2 * acc) % 8), 51 + 4 * ((ks + 2 * acc) % 8), c))
+    else:
+        # the same products as 16x16x32 tiles: P.V-like: 32 accumulators (4 registers) x 2 k-steps; Q.K^T-like: 16 accumulators x 4 k-steps
+        for ks in range(2):
+            for acc in range(32):
+                a0 = 64 + 4 * acc
+                mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
+                                                                                        48 + 4 * ((acc + 4 * ks) % 8), 51 + 4 * ((acc + 4 * ks) % 8), a0, a0 + 3))
+        for ks in range(4):
+            for acc in range(16):
+                a0 = 4 * acc
+                c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 3)
+                mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], %s" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
+                                                                                  48 + 4 * ((acc + ks) % 8), 51 + 4 * ((acc + ks) % 8), c))
+    n = len(mf)
+    lines = []
+    fi = 0
+    for g in range(n):
+        lines.append(mf[g])
+        want = (g + 1) * len(fl) // n
+        while fi < want:
+            lines.append(fl[fi])
+            fi += 1
+    lines.append("s_waitcnt lgkmcnt(0)")
+    return lines
+
+
+def kernel(name, shape, nofill=()):
+    # operands: %0 = result (out), %1 = iters (s), %2 = operand pointer (s, 64 bit), %3 / %4 = LDS read addresses (v), %5 = this thread's byte offset (v)
+    lines = ["s_mov_b32 s60, %1", "v_mov_b32 v250, %5"]
+    for i in range(16):          # 8 A + 8 B operand quads: U[0,1) fp16 data
+        lines.append("global_load_dwordx4 v[%d:%d], v250, %%2" % (16 + 4 * i, 19 + 4 * i))
+        lines.append("v_add_u32 v250, 0x1000, v250")
+    for i in range(8):
+        lines.append("v_mov_b32 v%d, 0xbf000000" % (208 + i))        # exp sources: -0.5
+        lines.append("v_mov_b32 v%d, 0" % (200 + i))
+    lines += ["v_mov_b32 v216, 0", "v_mov_b32 v217, 0"]
+    for i in range(192):
+        lines.append("v_accvgpr_write_b32 a%d, 0" % i)
+    lines.append("s_waitcnt vmcnt(0)")
+    lines.append(".Lprobe_%s_%%=:" % name)
+    lines += body(shape, nofill)
+    lines += ["s_sub_u32 s60, s60, 1", "s_cmp_gt_i32 s60, 0", "s_cbranch_scc1 .Lprobe_%s_%%=" % name]
+    lines.append("s_nop 7")
+    lines.append("v_accvgpr_read_b32 %0, a64")     # keep something observable
+    text = "\n".join('        "%s\\n"' % l for l in lines)
+    clob = ", ".join('"v%d"' % i for i in range(16, 256)) + ", " + ", ".join('"a%d"' % i for i in range(256)) + ', "s60", "vcc", "scc", "memory"'
+    return """
+__global__ __launch_bounds__(256, 1) void %s(const u32x4* __restrict__ ops, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 32768 / 16; i += 256) ((u32x4*)smem)[i] = ops[i & 1023];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t kaddr = lane * 16, vaddr = (lane & 15) * 8 + (lane >> 4) * 128, goff = threadIdx.x * 16;
+    float r;
+    asm volatile(
+%s
+        : "=v"(r) : "s"(iters), "s"(ops), "v"(kaddr), "v"(vaddr), "v"(goff)
+        : %s);
+    if (r == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+""" % (name, text, clob)
+
+
+HOST = r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+KERNELS
+typedef void (*kern_t)(const u32x4*, float*, int);
+int main() {
+    int dev = 0, n_cu = 0;
+    CHECK(hipGetDevice(&dev));
+    CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    std::vector<unsigned short> h(16 * 1024 * 8);
+    srand(1);
+    for (auto& x : h) { _Float16 v = (_Float16)((float)rand() / RAND_MAX); memcpy(&x, &v, 2); }
+    u32x4* d_ops; float* d_out;
+    CHECK(hipMalloc(&d_ops, h.size() * 2));
+    CHECK(hipMalloc(&d_out, (size_t)n_cu * 256 * 4));
+    CHECK(hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    const int iters = 128;      // tile bodies per workgroup and launch (config 2: 2 items x 64 tiles)
+    struct K { const char* name; kern_t fn; } ks[] = {NAMES};
+    const int nk = sizeof(ks) / sizeof(ks[0]);
+    for (int i = 0; i < nk; ++i) CHECK(hipFuncSetAttribute((const void*)ks[i].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float ms = 0.f;
+    CHECK(hipEventRecord(e0));
+    do {       // settle the clock
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(ks[0].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } while (ms < 400.f);
+    std::vector<std::vector<double>> t(nk);
+    for (int round = 0; round < 9; ++round)
+        for (int i = 0; i < nk; ++i) {
+            for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+            CHECK(hipEventRecord(e0));
+            for (int w = 0; w < 100; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+            CHECK(hipGetLastError());
+            t[i].push_back(ms / 100.0 * 1e3);
+        }
+    const double flops = 64.0 * 2 * 32 * 32 * 16 * 4 * n_cu * iters;
+    printf("{\"_comment\": \"tools/ubench/mfma_shape_probe.py: synthetic forward tile bodies, one wave per SIMD, %d CUs, %d bodies per launch, U[0,1) fp16 operands, interleaved rounds; us per launch (median of 9 x 100 launches), TF at the body's FLOPs\"", n_cu, iters);
+    for (int i = 0; i < nk; ++i) {
+        std::sort(t[i].begin(), t[i].end());
+        const double med = t[i][t[i].size() / 2];
+        printf(", \"%s\": {\"us\": %.1f, \"tflops\": %.0f, \"best_us\": %.1f}", ks[i].name, med, flops / (med * 1e-6) / 1e12, t[i][0]);
+    }
+    printf("}\n");
+    return 0;
+}
+"""
+
+
+def main():
+    variants = [("body_32x32x16", 32, ()), ("body_16x16x32", 16, ()), ("mfma_only_32x32x16", 32, tuple(FILL)), ("mfma_only_16x16x32", 16, tuple(FILL)),
+                ("no_lds_32x32x16", 32, ("kread", "vread")), ("no_lds_16x16x32", 16, ("kread", "vread"))]
+    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf) for n, s, nf in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (n, n) for n, _, _ in variants))
+    path = os.path.join(HERE, "mfma_shape_probe.hip")
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/ubench/mfma_shape_probe.py — do not edit.\n" + src)
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", path, "-o", os.path.join(HERE, "mfma_shape_probe")]
+        print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,8 @@ namespace fa2 {
 // read once when the library is loaded).  They select between kernels that all satisfy the same contract.
 struct Options {
     std::atomic<int> rows{0};      // FA2_ROWS: 0 = heuristic, 128 | 256 = rows per forward workgroup
-    std::atomic<int> asm_mask{3};      // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies
+    std::atomic<int> asm_mask{67};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bit 6 = the head-dim-128 forward
+                                       // bodies built on v_mfma_f32_16x16x32 (round 5; off: the 32x32x16 bodies everywhere)
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
     std::atomic<int> split{1};         // FA2_SPLIT: KV-split of the last, partly filled round of forward workgroups (fa2_fwd_ws)
@@ -102,7 +103,8 @@ FA2_HIDDEN int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t st
 FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream);
 // hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
 // fold: the body that folds scale * log2(e) into Q (FA2_CONTRACT_PRESCALE_Q) instead of scaling the f32 product
-FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream);
+// m16: the body built on v_mfma_f32_16x16x32 (head dim 128, f32 scale, whole items only; csrc/gen/fwd_m16_gen.py) where it applies
+FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16 = false);
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
 // dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).
 // Tile costs (us per 64-row tile of a 256-row workgroup, 8-wave HIP kernels): dQ pass 3 GEMMs, fused dK / dV pass 4 — 1.5x / 2x the forward's 0.9 * HD / 64.

@@ -10,9 +10,9 @@ namespace {
 // Persistent workgroups of the d128 kernel (non-causal launches): at most one workgroup per CU, each working through a
 // strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
 // (fa2_fwd_d128.hip.h).  Option "persist" = 0 launches one workgroup per item instead (A/B measurements, bit-identity tests).
-template <int HD, bool BF16, bool CAUSAL, bool FOLD>
+template <int HD, bool BF16, bool CAUSAL, bool FOLD, bool M16 = false>
 int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL, FOLD>;
+    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL, FOLD, M16>;
     constexpr int lds = fa2::AsmGeo<HD>::LDS_BYTES;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     fa2::FwdParams p = p0;
@@ -49,7 +49,18 @@ static int launch_asm_hd(const FwdParams& p, bool causal, bool fold, hipStream_t
     return causal ? launch_asm_t<HD, BF16, true, false>(p, stream) : launch_asm_t<HD, BF16, false, false>(p, stream);
 }
 
-int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream) {
+int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16) {
+    // The v_mfma_f32_16x16x32 bodies: head dim 128, whole items only.  Measured against the 32x32x16 bodies on one box (tools/kbench.py,
+    // profiles/r16_kbench_m16_*.txt): folded scale fp16 c2 +4.7 %, c4 +4.6 %, B8 +3.8 %; f32 scale fp16 +3.3 % / +3.3 % / +1.1 %; f32 scale bf16
+    // -0.5 .. +0.5 % (c3, c2-shape, B8: the bf16 32x32x16 MFMA is the cheaper one to begin with, profiles/mfma_peak.json) -> those stay where they were.
+    if (m16 && HD == 128 && p.item_cap == 0 && (fold || !bf16)) {
+        if (fold) {
+            if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
+            return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);
+        }
+        if (bf16) return causal ? launch_asm_t<128, true, true, false, true>(p, stream) : launch_asm_t<128, true, false, false, true>(p, stream);
+        return causal ? launch_asm_t<128, false, true, false, true>(p, stream) : launch_asm_t<128, false, false, false, true>(p, stream);
+    }
     if (HD == 128) return bf16 ? launch_asm_hd<128, true>(p, causal, fold, stream) : launch_asm_hd<128, false>(p, causal, fold, stream);
     return bf16 ? launch_asm_hd<64, true>(p, causal, fold, stream) : launch_asm_hd<64, false>(p, causal, fold, stream);
 }

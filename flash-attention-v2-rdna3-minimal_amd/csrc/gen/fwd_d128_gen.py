@@ -796,6 +796,23 @@ class Gen:
     # ------------------------------------------------------------------ scheduler (shared with the backward generator: sched.py)
     place = staticmethod(sched.place)
 
+    def place_pool_kreads(self, load, slots, par):
+        """32-register fragment pool: k-steps 0..3 are read during the PV phase, k-step ks >= 4 goes into the slot of ks - 4
+        as soon as the four MFMAs of that k-step are issued (12 MFMAs ahead of its own first use)"""
+        cfg = self.cfg
+        kr = self.stream_kread(par)
+        self.place(load, slots, kr[:8], cfg["kread_ct"][0], cfg["kread_ct"][1], 3)
+        for ks in range(4, 8):
+            g = 32 + 4 * (ks - 4) + 3
+            for kvb in range(2):
+                it = kr[2 * ks + kvb]
+                load[g] += _weight(it)
+                slots[g].append((g + 0.5 + 0.1 * kvb, 3, it))
+
+    def ct_reader_gaps(self, qb):
+        """(first, last) gap of the MFMAs that read the C tuple(s) of q block qb: the first Q.K^T k-step of the NEXT tile."""
+        return self.npv + 2 * qb, self.npv + 2 * qb + 1
+
     # ------------------------------------------------------------------ one body
     def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True, qpre=False):
         """B(t) with t & 1 == par.  pv: PV(t); s1: softmax of tile t+1 (M0, M1, E0, E1) and the V(t+1) reads; s2: K(t+2)
@@ -862,16 +879,7 @@ class Gen:
                 grp = self.qstage_group(par) + grp
             self.place(load, slots, grp, cfg["dma"][0], cfg["dma"][1], 2)
         if s2 and "kread" not in abl and self.pool:
-            # 32-register fragment pool: k-steps 0..3 are read during the PV phase, k-step ks >= 4 goes into the slot of ks - 4
-            # as soon as the four MFMAs of that k-step are issued (12 MFMAs ahead of its own first use)
-            kr = self.stream_kread(par)
-            self.place(load, slots, kr[:8], cfg["kread_ct"][0], cfg["kread_ct"][1], 3)
-            for ks in range(4, 8):
-                g = 32 + 4 * (ks - 4) + 3
-                for kvb in range(2):
-                    it = kr[2 * ks + kvb]
-                    load[g] += _weight(it)
-                    slots[g].append((g + 0.5 + 0.1 * kvb, 3, it))
+            self.place_pool_kreads(load, slots, par)
         elif s2 and "kread" not in abl:
             self.place(load, slots, self.stream_kread(par), cfg["kread"][0], cfg["kread"][1], 3)
         if s1 and "vread" not in abl and cfg["vsplit"][1] > 0 and fast:
@@ -939,16 +947,17 @@ class Gen:
             assert len(gap) == 1, (lab, gap)
             # PV(t) of this q block (MFMAs 16 qb .. 16 qb + 15) must be issued: the rare block rescales its accumulators
             assert gap[0] >= (self.npv // 2) * (qb + 1) - 1, "sum check of q block %d in gap %d: its PV MFMAs are not all issued" % (qb, gap[0])
+            ct_first, ct_last = self.ct_reader_gaps(qb)
             if self.ct:
-                # `fix` treats the two first-k-step MFMAs of this q block (npv + 2 qb: kv half 0, npv + 2 qb + 1: kv half 1) as one event: a check between
-                # them would rewrite the C tuple for half of the scores only, and rare_fix shifts all 32 — refuse such a schedule
-                assert gap[0] != self.npv + 2 * qb, "sum check of q block %d in gap %d: between the two MFMAs that read its C tuple" % (qb, gap[0])
+                # `fix` treats the first-k-step MFMAs of this q block (gaps ct_first .. ct_last) as one event: a check between them would rewrite the C
+                # tuple for some of the scores only, and rare_fix shifts all of them — refuse such a schedule
+                assert not (ct_first <= gap[0] < ct_last), "sum check of q block %d in gap %d: between the MFMAs that read its C tuple" % (qb, gap[0])
             # the pair packing of this q block (stream_pack) rounds P in place; the rare block reads the unpacked f32 P -> no pack instruction ahead of the check
             packs = [(g, pos) for g in range(ng) for (pos, sid, it) in slots[g] if sid == 5 + qb and not isinstance(it, list) and it.op == self.cvt]
             chk = [(g, pos) for g in range(ng) for (pos, sid, it) in slots[g] if isinstance(it, list) and any(
                 x.op == "s_cbranch_vccnz" and x.ops[0].name == lab for x in it)]
             assert packs and min(packs) > chk[0], "pair packing of q block %d starts at %s, ahead of its sum check at %s" % (qb, min(packs), chk[0])
-            self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= self.npv + 2 * qb))
+            self.rare.append(self.rare_sum(lab, qb, rpar, fix=self.ct and gap[0] >= ct_last))
             self.check_gaps = getattr(self, "check_gaps", {})
             self.check_gaps[(name, qb)] = gap[0]
         # emit: gap g fillers come AFTER mfma g

@@ -1,0 +1,730 @@
+#!/usr/bin/env python3
+"""Forward main block for D = 128 built on v_mfma_f32_16x16x32 (round 5) — the same software pipeline, staging, seams and sum-check bodies as
+fwd_d128_gen.py (reference counterpart: kernel_fp16.cu:381-508), another MFMA tile.
+
+Why.  The chip is power-limited under this kernel: a launch takes what its ENERGY takes.  A loop of nothing but MFMAs sustains
+1 981 TF with the 16x16x32 form against 1 728 with 32x32x16 on the same operands (it moves half the accumulator bytes per FLOP), and a synthetic
+tile body with every filler of the real one runs 8.4 % faster (tools/ubench/mfma_shape_probe.py, profiles/r16_mfma_shape_probe.json).
+
+Shape (one workgroup = 4 waves = 256 Q rows, one wave per SIMD, wave = 64 Q rows = four 16-row groups qg, KV tiles of 64 = four 16-row groups kg):
+    S^T[kv,q] tile (kg, qg) = sum_ks  K[kg rows, 32 d of k-step ks] . Q^T[ks, qg]      4 x 4 x 4 = 64 MFMAs per tile, 4 registers per tile
+    O^T[d,q]  tile (dg, qg) += sum_kvs V^T[16 d of dg, 32 kv of kvs] . P^T[kvs, qg]      8 x 4 x 2 = 64 MFMAs per tile
+  MFMA layouts: A[m][k]: lane l holds m = l % 16, k = 8 (l / 16) .. +7;  B[k][n]: n = l % 16, same k;  D[m][n]: n = l % 16, m = 4 (l / 16) + i.
+  So a lane (n, g = l / 16) holds, of Q row 16 qg + n, the scores kv = 16 kg + 4 g + i — a ROW IS SPREAD OVER FOUR LANES (g = 0..3).  Nothing in the
+  fast bodies cares: they keep per-lane partial row sums (summed across the four lanes once, in the epilogue) and the sum check is per lane; only
+  the max-first head / tail bodies and the rare repair reduce across lanes (v_permlane16_swap + v_permlane32_swap).
+  A "q block" qb of the base generator is a PAIR of q groups (qg = 2 qb + h): the S / P bank of (qb, parity) keeps register e = 16 h + 4 kg + i, and
+  the packed P of k-step kvs (kv groups 2 kvs, 2 kvs + 1) lands in registers 16 h + 8 kvs .. +3 — the very formula of the 32 x 32 layout
+  (8 (e // 8) + (e % 8) // 2), so exp / pack streams carry over; a lane's bank now belongs to TWO rows (h = 0, 1): reference, sums and limits are
+  per row.  The MFMA k-slot (g, j) of P.V stands for kv = 32 kvs + 16 (j >> 2) + 4 g + (j & 3): the V^T fragment is two transposed reads, rows
+  32 kvs + 4 g .. +3 and 16 further down — what ds_read_b64_tr_b16 delivers per 16-lane group anyway.
+
+opt=ct: the folded scale (the base generator's scheme: Q * scale*log2e rounded once to the I/O dtype, the running reference enters the first Q.K^T
+k-step as its C operand — one 4-register tuple per q group here, all four registers of a 16 x 16 tile belong to one row).  It matters MORE with this
+tile: 128 MFMA issues per body instead of 64 make the body issue-bound (the fillers alone take 76 % of a launch, profiles/r16_kbench_m16_sweep.txt),
+and the fold takes 64 of them out.  The C tuples take v[176:191]: the V^T fragments of k-step 1 move to a[224:255], the K fragments to a
+32-register pool (k-steps 2, 3 are read into the slots of 0, 1 once those MFMAs are issued; counted lgkmcnt waits, sched.lds_waits).
+
+Not in this generator (the 32 x 32 kernels keep those launches): head dim 64, KV-split parts.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.realpath(__file__)))
+import fwd_d128_gen as base  # noqa: E402
+from fwd_d128_gen import (A_C, A_EPI, A_FLAGS, A_KD0, A_KR0, A_KRS, A_KROW4, A_KTILE, A_LDSW, A_LIM0, A_LIM1, A_LSE0, A_NKRS, A_NQRS,  # noqa: E402,F401
+                          A_NQW, A_NTW, A_NTWG, A_NVRS, A_QD0, A_QRS, A_QT16, A_QW, A_VD0, A_VR0, A_VROW4, A_VRS, A_VTILE, KD, NEG_INF,
+                          PSUM_MAX, QD, SB, S_D, S_FLAG, S_FIX, S_KOFF, S_NFAST, S_NOVM, S_PF, S_QH, S_QM0, S_QSB, S_QSOFF, S_SUM, S_T, S_TMP,
+                          S_TMP2, S_VOFF, S_WAVE, THR, VBASE, VD)
+from isa import A, V, Ins, Label, M0, Neg, VCC, mk  # noqa: E402
+
+# ---- register map (everything the base generator does not fix)
+KR = [V(208 + i) for i in range(4)]                # K / Q fragment read addresses, k-step ks (32 head-dim columns each)
+VR = [V(212 + i) for i in range(4)]                # V^T fragment read addresses, 64-byte chunk dg >> 1
+LA = [V(228), V(230)]                              # running partial row sums of THIS lane: row h = 0 of q block qb ...
+LB = [V(229), V(231)]                              # ... and row h = 1
+MCA = [V(232), V(234)]                             # reference (m * c, log2 units) of row h = 0 of q block qb ...
+MCB = [V(233), V(235)]                             # ... h = 1
+FSA = [V(236), V(238)]                             # pending O rescale factors (max-first bodies), rows h = 0 / 1
+FSB = [V(237), V(239)]
+TMP = [V(240 + i) for i in range(8)]               # scratch (row-max chains, tile sums, rescale block, epilogue)
+EPX = [V(248 + i) for i in range(4)]               # epilogue: 1 / l of the wave's four rows of this lane; rare_sum scratch
+LIMQ = [[V(216), V(217)], [V(218), V(219)]]        # masked bodies: kv limits of this lane's two rows of q block qb (the two blocks' streams interleave)
+# (v252..255: QD of the base generator — the staging of the next item's Q runs through every body)
+MC = [MCA, MCB]
+FS = [FSA, FSB]
+LS = [LA, LB]
+
+
+def OACC(dg, qg):
+    return A(4 * (8 * qg + dg), 4)
+
+
+def QF(qg, ks):
+    return A(128 + 4 * (4 * qg + ks), 4)
+
+
+def KF(kg, ks):
+    return A(192 + 4 * (4 * kg + ks), 4)
+
+
+def VF(dg, kvs):
+    return V(144 + 4 * (8 * kvs + dg), 4)
+
+
+# "ct" (folded scale): C tuples in v[176:191], so the V^T fragments of k-step 1 live in a[224:255] and the K fragments in a 32-register pool
+def KF_POOL(kg, ks):
+    return A(192 + 16 * (ks % 2) + 4 * kg, 4)
+
+
+def VF_CT(dg, kvs):
+    return V(144 + 4 * dg, 4) if kvs == 0 else A(224 + 4 * dg, 4)
+
+
+CT16 = [V(176 + 4 * qg, 4) for qg in range(4)]     # -(reference) of this lane's row of q group qg, four copies (the C operand of a 16 x 16 tile)
+DSH16 = [[V(192), V(193)], [V(194), V(195)]]       # [h][qb]: pending shift of the NEXT tile's scores of row h of q block qb (see rare_fix)
+
+
+class Gen16(base.Gen):
+    # schedule windows of a 128-gap body: the base generator's, in units of the shorter MFMA
+    # (measured, tools/kbench.py on one box, folded body, c2 / b8 us: dma 20:56, vread 66:80 (the base windows doubled) 205.4 / 839.8; dma 8:40 204.6 / 833.6;
+    #  + vread 66:100 203.0 / 822.4; the exp / pack windows are flat — profiles/r16_kbench_m16_sweep.txt)
+    DEFAULTS16 = {"m": (4.0, 20.0), "e": (20.0, 128.0), "vread": (66.0, 100.0), "kread": (0.0, 48.0), "dma": (8.0, 40.0), "mmask": (4.0, 48.0),
+                  "se0": (0.0, 96.0), "se1": (16.0, 120.0), "sc0": (96.0, 116.0), "sc1": (120.0, 128.0)}
+
+    def __init__(self, bf16=False, **cfg):
+        opt = tuple(cfg.get("opt", ()))
+        assert "lmfma" not in opt, "the 16x16x32 generator has no lmfma bodies"
+        user = dict(cfg)
+        super().__init__(bf16, hd=128, **cfg)
+        self.cfg.update({k: v for k, v in self.DEFAULTS16.items() if k not in user})
+        if "kread_ct" not in user:
+            self.cfg["kread_ct"] = (16.0, 64.0)      # "ct": gap window of the K reads of k-steps 0, 1 (2, 3 follow their pool slots)
+        self.kf16 = KF_POOL if self.ct else KF
+        self.vf16 = VF_CT if self.ct else VF
+        self.mfma = "v_mfma_f32_16x16x32_bf16" if bf16 else "v_mfma_f32_16x16x32_f16"
+        self.npv, self.nqk = 64, 64
+        self.ng = 128
+
+    # ------------------------------------------------------------------ MFMA lists
+    def pv_mfmas(self, par, qb):
+        out = []
+        b = SB(qb, par)
+        for kvs in range(2):
+            for dg in range(8):
+                for h in range(2):
+                    acc = OACC(dg, 2 * qb + h)
+                    out.append(mk(self.mfma, acc, self.vf16(dg, kvs), b.sub(16 * h + 8 * kvs, 4), acc, tag="mfma"))
+        return out
+
+    def qk_mfmas(self, par):
+        out = []
+        for ks in range(4):
+            for qb in range(2):
+                for h in range(2):
+                    for kg in range(4):
+                        dst = SB(qb, par).sub(16 * h + 4 * kg, 4)
+                        c0 = CT16[2 * qb + h] if self.ct else 0
+                        out.append(mk(self.mfma, dst, self.kf16(kg, ks), QF(2 * qb + h, ks), c0 if ks == 0 else dst, tag="mfma"))
+        return out
+
+    # ------------------------------------------------------------------ filler streams
+    @staticmethod
+    def _order():
+        """the 16 register pairs of a bank, rows h = 0 / 1 alternating (two dependent chains never back to back)"""
+        return [(16 * h + 2 * k) for k in range(8) for h in range(2)]
+
+    def stream_exp(self, qb, par):
+        """max-first bodies: P = 2^(S*c - m*c) in place, per-row sum chains, pairs packed in place; skewed by pair."""
+        b = SB(qb, par)
+        prs = self._order()
+        out = []
+        for k in range(16 + 3):
+            F, E, Ad, C = [], [], [], []
+            if k < 16 and not self.fold:
+                e = prs[k]
+                for x in (e, e + 1):
+                    F.append(mk("v_fma_f32", b[x], b[x], A_C, Neg(MC[e // 16][qb]), tag="valu"))
+            if 0 <= k - 1 < 16:
+                e = prs[k - 1]
+                E += [mk("v_exp_f32", b[e], b[e], tag="trans"), mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans")]
+            if 0 <= k - 2 < 16:
+                e = prs[k - 2]
+                Ad.append(mk("v_add_f32", LS[e // 16][qb], LS[e // 16][qb], b[e], tag="valu"))
+            if 0 <= k - 3 < 16:
+                e = prs[k - 3]
+                Ad.append(mk("v_add_f32", LS[e // 16][qb], LS[e // 16][qb], b[e + 1], tag="valu"))
+                C.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
+            out += F + E + Ad + C
+        return out
+
+    def stream_exp_sum(self, qb, par):
+        """fast bodies (no row-max stream; base.Gen.stream_exp_sum has the argument): P against the current references of the lane's two rows, the
+        tile's sums per row (ta: h = 0, tb: h = 1) started afresh, added to the running sums, and ONE check: ta + tb bounds each of this lane's 32 P."""
+        b = SB(qb, par)
+        ta, tb, ts = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2]
+        tsum = [ta, tb]
+        prs = self._order()
+        out = []
+        for k in range(16 + 3):
+            F, E, Ad = [], [], []
+            if k < 16 and not self.fold:
+                e = prs[k]
+                for x in (e, e + 1):
+                    F.append(mk("v_fma_f32", b[x], b[x], A_C, Neg(MC[e // 16][qb]), tag="valu"))
+            if 0 <= k - 1 < 16:
+                e = prs[k - 1]
+                E += [mk("v_exp_f32", b[e], b[e], tag="trans"), mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans")]
+            if 0 <= k - 2 < 16:
+                e = prs[k - 2]
+                t = tsum[e // 16]
+                if e % 16 == 0:                   # the row's first pair starts its chain
+                    Ad.append(mk("v_add_f32", t, b[e], b[e + 1], tag="valu"))
+                else:
+                    Ad.append(mk("v_add_f32", t, t, b[e], tag="valu"))
+            if 0 <= k - 3 < 16:
+                e = prs[k - 3]
+                if e % 16 != 0:
+                    Ad.append(mk("v_add_f32", tsum[e // 16], tsum[e // 16], b[e + 1], tag="valu"))
+            out += F + E + Ad
+        out.append(mk("v_add_f32", LA[qb], LA[qb], ta, tag="valu"))
+        out.append(mk("v_add_f32", LB[qb], LB[qb], tb, tag="valu"))
+        out.append(mk("v_add_f32", ts, ta, tb, tag="valu"))
+        lab = self.p.fresh("rare_s")
+        out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_nge_f32", VCC, PSUM_MAX, ts, tag="valu"),
+                    mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+        self.pending_rare_sum.append((lab, qb, par))
+        return out
+
+    # stream_pack: the base generator's (the packed P of k-step kvs of row h lands in registers 16 h + 8 kvs .. + 3 by the same formula)
+
+    def _row_reduce_max(self, r, x, t):
+        """x = max of x over the four lanes of a row (l % 16 equal): exchange with the lane 16 away, then 32 away (t: scratch)"""
+        for op in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
+            r.append(mk("v_mov_b32", t, x))
+            r.append(mk("s_nop", 1))
+            r.append(mk(op, x, t))
+            r.append(mk("v_max_f32", x, x, t))
+            r.append(mk("s_nop", 0))
+
+    def rare_sum(self, lab, qb, par, fix):
+        """Out of line, sum-check bodies (base.Gen.rare_sum has the scheme): the two rows of this lane get their P maximum — over the row's four lanes —,
+        the references move by d = max(0, ceil(log2 max P)) octaves per row and everything at the old references (this tile's P, the running sums, the O
+        accumulators of the q block: all of PV(t) was issued gaps ago) is multiplied by 2^-d.  Growth of 120 octaves and more: flag, redo in safe mode."""
+        b = SB(qb, par)
+        mx = [TMP[4 * qb], TMP[4 * qb + 1]]            # (the tile's sum chains, already added to the running sums)
+        t, t2 = TMP[4 * qb + 2], TMP[4 * qb + 3]
+        f = [EPX[0], EPX[1]]                           # the rows' factors 2^-d
+        scr = [EPX[2], EPX[3]]
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("v_mov_b32", t2, t))               # the tile sum the check read: it carries an inf / NaN the maxima may drop
+        for h in range(2):
+            r.append(mk("v_max3_f32", mx[h], b[16 * h], b[16 * h + 1], b[16 * h + 2]))
+        for i in range(6):
+            for h in range(2):
+                r.append(mk("v_max3_f32", mx[h], mx[h], b[16 * h + 3 + 2 * i], b[16 * h + 4 + 2 * i]))
+        for h in range(2):
+            r.append(mk("v_max_f32", mx[h], mx[h], b[16 * h + 15]))
+        r.append(mk("s_nop", 0))
+        for h in range(2):
+            self._row_reduce_max(r, mx[h], t)
+        r.append(mk("v_max_f32", t, mx[0], mx[1]))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_f32", t2, t2, t))
+        fail = lab + "_fail"
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_cmp_ngt_f32", VCC, float(2.0 ** 120), t2))
+        r.append(mk("s_cbranch_vccnz", Label(fail)))
+        for h in range(2):
+            r.append(mk("v_log_f32", t, mx[h]))
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_max_f32", t, 0, t))                          # rows that stayed below their reference keep it (d = 0)
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_ceil_f32", t, t))                            # whole octaves: every factor below is an exact power of two
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_exp_f32", f[h], Neg(t)))
+            r.append(mk("v_add_f32", MC[h][qb], MC[h][qb], t))
+            r.append(mk("s_nop", 0))
+            for e in range(16):
+                r.append(mk("v_mul_f32", b[16 * h + e], b[16 * h + e], f[h]))
+            r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], f[h]))
+            if self.ct:
+                # the C tuple of the coming Q.K^T products; `fix`: the first k-step of the NEXT tile was issued with the old tuple already — those scores
+                # get the shift at the start of the next body (S_FIX, rare_fix)
+                r.append(mk("v_sub_f32", scr[0], 0, MC[h][qb]))
+                r.append(mk("s_nop", 0))
+                for i in range(4):
+                    r.append(mk("v_mov_b32", CT16[2 * qb + h][i], scr[0]))
+                if fix:
+                    r.append(mk("v_mov_b32", DSH16[h][qb], t))
+        if self.ct and fix:
+            r.append(mk("s_or_b32", S_FIX, S_FIX, 1 << qb))
+        r.append(mk("s_nop", 15))
+        r.append(mk("s_nop", 15))
+        for h in range(2):
+            for dg in range(8):
+                acc = OACC(dg, 2 * qb + h)
+                for j in range(0, 4, 2):
+                    for x in range(2):
+                        r.append(mk("v_accvgpr_read_b32", scr[x], acc[j + x]))
+                    r.append(mk("s_nop", 1))
+                    for x in range(2):
+                        r.append(mk("v_mul_f32", scr[x], scr[x], f[h]))
+                    r.append(mk("s_nop", 1))
+                    for x in range(2):
+                        r.append(mk("v_accvgpr_write_b32", acc[j + x], scr[x]))
+        r.append(mk("s_nop", 7))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        r.append(Ins("label", (Label(fail),)))
+        r.append(mk("v_mov_b32", t, S_WAVE))
+        r.append(mk("v_mov_b32", t2, 1))
+        r.append(mk("v_lshlrev_b32", t, 2, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_u32", t, self.g.FAIL_OFF, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("ds_write_b32", t, t2))
+        r.append(mk("s_waitcnt", lgkmcnt=0))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
+
+    def stream_max(self, qb, par, masked, first=False):
+        """mask (tail bodies) -> maxima of this lane's 16 scores of each of its two rows -> reduce over the row's four lanes -> rescale decision."""
+        b = SB(qb, par)
+        out = []
+        mx = [TMP[4 * qb], TMP[4 * qb + 1]]
+        t, t2 = TMP[4 * qb + 2], TMP[4 * qb + 3]
+        if masked:
+            # element (kg, i) of row h is kv_local = 16 kg + i (4 g is folded into the limits): kept iff <= the row's limit
+            # lim(row h of q block qb) = min(A_LIM0 + 16 (2 qb + h), A_LIM1)   (A_LIM0: causal diagonal of q group 0, A_LIM1: ragged Nkv; fa2_fwd_m16.hip.h)
+            lim = LIMQ[qb]
+            for h in range(2):
+                out.append(mk("v_add_u32", lim[h], 16 * (2 * qb + h), A_LIM0, tag="valu"))
+            for h in range(2):
+                out.append(mk("v_min_i32", lim[h], lim[h], A_LIM1, tag="valu"))
+            out.append(mk("v_mov_b32", t2, NEG_INF, tag="valu"))
+            for h in range(2):
+                for kg in range(4):
+                    for i in range(4):
+                        out.append([mk("v_cmp_le_i32", VCC, 16 * kg + i, lim[h], tag="valu"),
+                                    mk("v_cndmask_b32", b[16 * h + 4 * kg + i], t2, b[16 * h + 4 * kg + i], VCC, tag="valu")])
+        for h in range(2):
+            out.append(mk("v_max3_f32", mx[h], b[16 * h], b[16 * h + 1], b[16 * h + 2], tag="valu"))
+        for i in range(6):
+            for h in range(2):
+                out.append(mk("v_max3_f32", mx[h], mx[h], b[16 * h + 3 + 2 * i], b[16 * h + 4 + 2 * i], tag="valu"))
+        for h in range(2):
+            out.append(mk("v_max_f32", mx[h], mx[h], b[16 * h + 15], tag="valu"))
+        for op in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
+            out.append(mk("v_mov_b32", t, mx[0], tag="valu"))
+            out.append(mk("v_mov_b32", t2, mx[1], tag="valu"))
+            out.append([mk("s_nop", 1, tag="salu"), mk(op, mx[0], t, tag="valu"), mk(op, mx[1], t2, tag="valu")])
+            out.append(mk("v_max_f32", mx[0], mx[0], t, tag="valu"))
+            out.append(mk("v_max_f32", mx[1], mx[1], t2, tag="valu"))
+        lab = self.p.fresh("rare_m")
+        if self.fold:
+            # S already is (score - reference) in log2 units: a row's maximum IS its growth.  Tile 0 adopts its own maxima whatever their sign (the
+            # reference starts at 0, not at -inf: it travels through the MFMA as a 16-bit-exact f32 term)
+            if first:
+                out.append([mk("s_branch", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+            else:
+                out.append(mk("v_max_f32", t, mx[0], mx[1], tag="valu"))
+                out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_lt_f32", VCC, THR, t, tag="valu"),
+                            mk("s_cbranch_vccnz", Label(lab), tag="branch"), Ins("label", (Label(lab + "_ret"),))])
+            r = [Ins("label", (Label(lab),))]
+            for h in range(2):
+                if not first:
+                    r.append(mk("v_max_f32", mx[h], 0, mx[h]))              # a row that did not grow keeps its reference
+                    r.append(mk("s_nop", 0))
+                r.append(mk("v_add_f32", t, MC[h][qb], mx[h]))               # new reference
+                r.append(mk("s_nop", 0))
+                r.append(mk("v_sub_f32", t2, t, MC[h][qb]))                  # the shift as applied
+                r.append(mk("v_mov_b32", MC[h][qb], t))
+                r.append(mk("v_sub_f32", t, 0, t))                           # -reference for the C tuple
+                r.append(mk("s_nop", 0))
+                for e in range(16):
+                    r.append(mk("v_sub_f32", b[16 * h + e], b[16 * h + e], t2))
+                for i in range(4):
+                    r.append(mk("v_mov_b32", CT16[2 * qb + h][i], t))
+                r.append(mk("v_exp_f32", t2, Neg(t2)))                        # factor for everything accumulated at the old reference
+                r.append(mk("s_nop", 1))
+                r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
+                r.append(mk("v_mov_b32", FS[h][qb], t2))
+            if not first:
+                r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+            r.append(mk("s_nop", 1))
+            r.append(mk("s_branch", Label(lab + "_ret")))
+            self.rare.append(r)
+            return out
+        out.append(mk("v_fma_f32", t, mx[0], A_C, Neg(MCA[qb]), tag="valu"))
+        out.append(mk("v_fma_f32", t2, mx[1], A_C, Neg(MCB[qb]), tag="valu"))
+        out.append(mk("v_max_f32", t, t, t2, tag="valu"))
+        out.append([mk("s_nop", 0, tag="salu"), mk("v_cmp_lt_f32", VCC, THR, t, tag="valu"), mk("s_cbranch_vccnz", Label(lab), tag="branch"),
+                    Ins("label", (Label(lab + "_ret"),))])
+        # out of line: move the references (scaled units m*c), scale the row sums now, leave the O rescale pending
+        r = [Ins("label", (Label(lab),))]
+        for h in range(2):
+            r.append(mk("v_mul_f32", t, A_C, mx[h]))                     # tile max * c
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_max_f32", t, t, MC[h][qb]))                   # new reference
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_sub_f32", t2, MC[h][qb], t))                  # (m_old - m_new) * c  (<= 0; -inf on the first tile)
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_exp_f32", t2, t2))
+            r.append(mk("v_mov_b32", MC[h][qb], t))
+            r.append(mk("s_nop", 0))
+            r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
+            r.append(mk("v_mov_b32", FS[h][qb], t2))                     # (1.0 for a row whose reference stayed; one softmax per body: never two pending)
+        if not first:               # the q block's first tile: O is still all zeros, nothing to rescale later
+            r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        self.rare.append(r)
+        return out
+
+    def rare_fix(self, lab, par):
+        """Out of line, start of a body (folded scale): rows whose reference moved after the first Q.K^T k-step of THIS body's softmax tile had been
+        issued with the old C tuple (rare_sum, `fix`): shift those scores by the pending amount."""
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("s_nop", 15))
+        r.append(mk("s_nop", 15))
+        for qb in range(2):
+            skip = self.p.fresh("fix_skip")
+            r.append(mk("s_bitcmp1_b32", S_FIX, qb))
+            r.append(mk("s_cbranch_scc0", Label(skip)))
+            b = SB(qb, par)
+            for h in range(2):
+                for e in range(16):
+                    r.append(mk("v_sub_f32", b[16 * h + e], b[16 * h + e], DSH16[h][qb]))
+            r.append(Ins("label", (Label(skip),)))
+        r.append(mk("s_mov_b32", S_FIX, 0))
+        r.append(mk("s_nop", 1))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
+
+    def ct_reader_gaps(self, qb):
+        return self.npv + 8 * qb, self.npv + 8 * qb + 7
+
+    def place_pool_kreads(self, load, slots, par):
+        """K fragment pool of two k-step slots: k-steps 0, 1 are read during the PV phase, k-step ks >= 2 goes into the slot of ks - 2 as soon as the
+        sixteen MFMAs of that k-step are issued (a whole k-step ahead of its own first use)"""
+        kr = self.stream_kread(par)                       # order: ks major, kg minor
+        self.place(load, slots, kr[:8], self.cfg["kread_ct"][0], self.cfg["kread_ct"][1], 3)
+        for ks in range(2, 4):
+            g0 = self.npv + 16 * (ks - 2) + 15
+            for kg in range(4):
+                it = kr[4 * ks + kg]
+                load[g0] += base._weight(it)
+                slots[g0].append((g0 + 0.5 + 0.1 * kg, 3, it))
+
+    def rare_rescale(self, lab):
+        r = [Ins("label", (Label(lab),))]
+        r.append(mk("s_nop", 15))
+        r.append(mk("s_nop", 15))
+        for qb in range(2):
+            skip = self.p.fresh("rr_skip")
+            r.append(mk("s_bitcmp1_b32", S_FLAG, qb))
+            r.append(mk("s_cbranch_scc0", Label(skip)))
+            for h in range(2):
+                for dg in range(8):
+                    acc = OACC(dg, 2 * qb + h)
+                    for j in range(4):
+                        r.append(mk("v_accvgpr_read_b32", EPX[j], acc[j]))
+                    r.append(mk("s_nop", 1))
+                    for j in range(4):
+                        r.append(mk("v_mul_f32", EPX[j], EPX[j], FS[h][qb]))
+                    r.append(mk("s_nop", 1))
+                    for j in range(4):
+                        r.append(mk("v_accvgpr_write_b32", acc[j], EPX[j]))
+            r.append(Ins("label", (Label(skip),)))
+        r.append(mk("s_mov_b32", S_FLAG, 0))
+        r.append(mk("s_nop", 7))
+        r.append(mk("s_branch", Label(lab + "_ret")))
+        return r
+
+    def stream_kread(self, par):
+        g = self.g
+        return [mk("ds_read_b128", self.kf16(kg, ks), KR[ks], tag="lds", offset=g.K_SLOT + par * g.SLOT_B + kg * 16 * g.ROWB)
+                for ks in range(4) for kg in range(4)]
+
+    def stream_vread(self, par):
+        out = []
+        g = self.g
+        for kvs in range(2):
+            for dg in range(8):
+                off = g.V_BASE + par * g.SLOT_B + 32 * kvs * g.ROWB + 32 * (dg & 1)
+                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(0, 2), VR[dg >> 1], tag="lds", offset=off))
+                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(2, 2), VR[dg >> 1], tag="lds", offset=off + 16 * g.ROWB))
+        return out
+
+    def seam_q_reads(self):
+        g = self.g
+        r = []
+        two, waited = self.p.fresh("qrd_two"), self.p.fresh("qrd_waited")
+        r.append(mk("s_bitcmp1_b32", A_FLAGS, 2))
+        r.append(mk("s_cbranch_scc1", Label(two)))
+        r.append(mk("s_waitcnt", vmcnt=g.NP))
+        r.append(mk("s_branch", Label(waited)))
+        r.append(Ins("label", (Label(two),)))
+        r.append(mk("s_waitcnt", vmcnt=2 * g.NP))
+        r.append(Ins("label", (Label(waited),)))
+        for i in range(4):
+            r.append(mk("v_add_u32", QD[i], S_QSB, KR[i]))
+        r.append(mk("s_nop", 0))
+        for qg in range(4):
+            for ks in range(4):
+                r.append(mk("ds_read_b128", QF(qg, ks), QD[ks], offset=qg * 16 * g.ROWB))
+        return r
+
+    # ------------------------------------------------------------------ whole block
+    def build(self):
+        p = self.p
+        g = self.g
+        tr = int(self.cfg["trace"][0])
+        assert not tr, "the trace builds belong to the 32x32 generator"
+        # ---- entry: addresses, the wave's Q through its LDS image, the first tiles
+        p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        for ks in range(4):
+            p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
+        for j in range(4):
+            p.emit("v_xor_b32", VR[j], j << 6, A_VR0)
+        p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
+        p.emit("s_mul_i32", S_QSB, S_WAVE, 64 * g.EPI_ROWB)
+        p.emit("s_add_u32", S_QSB, S_QSB, g.EPI_BASE)
+        p.emit("v_mov_b32", QD[0], A_QD0)
+        p.emit("s_lshr_b32", S_TMP2, A_QT16, (16 // g.RPP).bit_length() - 1)
+        p.emit("s_sub_u32", S_TMP2, S_TMP2, 1024)
+        p.emit("s_mov_b32", S_TMP, 0)
+        for i in range(1, g.NP):
+            p.emit("s_add_u32", S_TMP, S_TMP, S_TMP2)
+            p.emit("v_xor_b32", QD[i], i << 6, A_QD0)
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", QD[i], S_TMP, QD[i])
+        p.emit("s_and_b32", S_PF, A_FLAGS, 1)
+        p.emit("s_cmp_eq_u32", S_PF, 1)
+        p.emit("s_cbranch_scc1", Label("have_q"))
+        p.emit("s_mov_b32", S_TMP, A_QW)
+        for j in range(4):
+            p.emit("s_add_u32", M0, S_QSB, j * g.NP * 1024)
+            if j:
+                p.emit("s_add_u32", S_TMP, S_TMP, A_QT16)
+            else:
+                p.emit("s_nop", 0)
+            for ins in self.q_group_loads(A_QRS, S_TMP):
+                p.ins.append(ins)
+        if self.fold:
+            # folded scale: Q passes through the (still unused) S banks, is multiplied by c in f32 and rounded back ONCE — the reference oracle's contract
+            # `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file.  A prefetched item's raw fragments come back from there.
+            p.emit("s_branch", Label("q_issued"))
+            p.label("have_q")
+            for i in range(64):
+                p.emit("v_accvgpr_read_b32", V(VBASE + i), QF(i // 16, (i % 16) // 4)[i % 4])
+            p.label("q_issued")
+        else:
+            p.label("have_q")
+        p.emit("v_mov_b32", KD[0], A_KD0)
+        p.emit("v_mov_b32", VD[0], A_VD0)
+        p.emit("s_mov_b32", S_TMP, 0)
+        p.emit("s_mov_b32", S_TMP2, 0)
+        for i in range(1, g.NP):
+            p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
+            p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
+            p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
+            p.emit("v_add_u32", VD[i], S_TMP2, A_VD0)
+            p.emit("s_nop", 0)
+            p.emit("v_add_u32", KD[i], S_TMP, KD[i])
+        p.emit("s_mov_b32", S_T, -2)
+        p.emit("s_mov_b32", S_FLAG, 0)
+        p.emit("s_mov_b32", S_FIX, 0)
+        for r in S_SUM:
+            p.emit("s_mov_b32", r, 0)
+        p.emit("s_mov_b32", S_KOFF, 0)
+        p.emit("s_mov_b32", S_NOVM, 0)
+        p.emit("s_mov_b32", S_VOFF, 0)
+        p.emit("s_cmp_eq_u32", S_PF, 1)
+        p.emit("s_cbranch_scc1", Label("staged"))
+        p.emit("s_add_u32", M0, A_LDSW, g.K_SLOT)
+        p.emit("s_nop", 0)
+        for i in range(g.NP):
+            p.emit("buffer_load_dwordx4", KD[i], A_KRS, S_KOFF, offen=True, offset=1024 * i, lds=True)
+        p.emit("s_add_u32", M0, A_LDSW, g.V_BASE)
+        p.emit("s_nop", 0)
+        for i in range(g.NP):
+            p.emit("buffer_load_dwordx4", VD[i], A_VRS, S_VOFF, offen=True, offset=1024 * i, lds=True)
+        p.emit("s_cmp_lt_i32", A_NTWG, 2)
+        p.emit("s_cbranch_scc1", Label("no_k1"))
+        p.emit("s_add_u32", M0, A_LDSW, g.K_SLOT + g.SLOT_B)
+        p.emit("s_nop", 0)
+        for i in range(g.NP):
+            p.emit("buffer_load_dwordx4", KD[i], A_KRS, A_KTILE, offen=True, offset=1024 * i, lds=True)
+        p.label("no_k1")
+        # Q (issued first) from the image into the fragment registers; K(0), V(0), K(1) keep flying
+        p.emit("s_cmp_lt_i32", A_NTWG, 2)
+        p.emit("s_cbranch_scc1", Label("qwait8"))
+        p.emit("s_waitcnt", vmcnt=3 * g.NP)
+        p.emit("s_branch", Label("qwaited"))
+        p.label("qwait8")
+        p.emit("s_waitcnt", vmcnt=2 * g.NP)
+        p.label("qwaited")
+        for ks in range(4):
+            p.emit("v_add_u32", TMP[ks], S_QSB, KR[ks])
+        p.emit("s_nop", 0)
+        for qg in range(4):
+            for ks in range(4):
+                p.emit("ds_read_b128", V(VBASE + 16 * qg + 4 * ks, 4) if self.fold else QF(qg, ks), TMP[ks], offset=qg * 16 * g.ROWB)
+        p.label("staged")
+        p.emit("s_bitcmp1_b32", A_FLAGS, 1)
+        p.emit("s_cselect_b32", S_QH, 0, 8)
+        p.emit("s_mov_b32", S_QM0, S_QSB)
+        p.emit("s_mov_b32", S_QSOFF, A_NQW)
+        p.emit("s_mov_b32", S_KOFF, A_KTILE)
+        for qb in range(2):
+            for h in range(2):
+                p.emit("v_mov_b32", MC[h][qb], 0.0 if self.fold else NEG_INF)
+                p.emit("v_mov_b32", LS[h][qb], 0)
+                p.emit("v_mov_b32", FS[h][qb], 1.0)
+        for i in range(128):
+            p.emit("v_accvgpr_write_b32", A(i), 0)
+        p.emit("s_waitcnt", lgkmcnt=0)
+        if self.fold:
+            for qg in range(4):
+                for i in range(4):
+                    p.emit("v_mov_b32", CT16[qg][i], 0)                 # C tuples: the references start at 0
+            for i in range(64):
+                for ins in self.q_prescale_reg(V(VBASE + i), QF(i // 16, (i % 16) // 4)[i % 4], TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]):
+                    p.ins.append(ins)
+        p.emit("s_cmp_lt_i32", A_NTWG, 2)
+        p.emit("s_cbranch_scc1", Label("wait4"))
+        p.emit("s_waitcnt", vmcnt=2 * g.NP)
+        p.emit("s_branch", Label("waited"))
+        p.label("wait4")
+        p.emit("s_waitcnt", vmcnt=g.NP)
+        p.label("waited")
+        p.emit("s_barrier")
+
+        # ---- head bodies, fast loop, tail dispatch: the base generator's structure
+        self.body(0, pv=False, s1=False, s2=True, name="H1", dma=False)
+        p.emit("s_cmp_eq_u32", A_NTW, 1)
+        p.emit("s_cbranch_scc1", Label("h2b"))
+        self.body(1, pv=False, s1=True, s2=True, name="H2", first=True)
+        p.emit("s_branch", Label("main"))
+        p.label("h2b")
+        self.body(1, pv=False, s1=True, s2=False, masked=True, name="H2b", first=True)
+        p.label("main")
+        p.emit("s_bitcmp1_b32", A_FLAGS, 4)
+        p.emit("s_cbranch_scc1", Label("dispatch"))
+        p.emit("s_sub_u32", S_NFAST, A_NTW, 3)
+        p.emit("s_cmp_gt_i32", S_NFAST, 0)
+        p.emit("s_cbranch_scc0", Label("dispatch"))
+        p.emit("s_nop", 0)
+        p.label("fast0")
+        self.body(0, guarded=False, name="F0")
+        p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
+        p.emit("s_cmp_gt_i32", S_NFAST, 0)
+        p.emit("s_cbranch_scc0", Label("dispatch"))
+        self.body(1, guarded=False, name="F1")
+        p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
+        p.emit("s_cmp_gt_i32", S_NFAST, 0)
+        p.emit("s_cbranch_scc1", Label("fast0"))
+        p.label("dispatch")
+        p.emit("s_cmp_ge_i32", S_T, A_NTWG)
+        p.emit("s_cbranch_scc1", Label("epilogue"))
+        p.emit("s_sub_u32", S_D, A_NTW, S_T)
+        p.emit("s_and_b32", S_TMP, S_T, 1)
+        p.emit("s_cmp_eq_u32", S_TMP, 1)
+        p.emit("s_cbranch_scc1", Label("disp_odd"))
+        for par, suffix in ((0, "e"), (1, "o")):
+            if par == 1:
+                p.label("disp_odd")
+            p.emit("s_cmp_ge_i32", S_D, 3)
+            p.emit("s_cbranch_scc1", Label("ta_" + suffix))
+            p.emit("s_cmp_eq_u32", S_D, 2)
+            p.emit("s_cbranch_scc1", Label("tb_" + suffix))
+            p.emit("s_cmp_eq_u32", S_D, 1)
+            p.emit("s_cbranch_scc1", Label("tc_" + suffix))
+            self.body(par, pv=False, s1=False, s2=False, name="ST%d" % par)
+            p.emit("s_branch", Label("dispatch"))
+            p.label("ta_" + suffix)
+            self.body(par, name="TA%d" % par)
+            p.emit("s_branch", Label("dispatch"))
+            p.label("tb_" + suffix)
+            self.body(par, s2=False, masked=True, name="TB%d" % par)
+            p.emit("s_branch", Label("dispatch"))
+            p.label("tc_" + suffix)
+            self.body(par, s1=False, s2=False, name="TC%d" % par)
+            p.emit("s_branch", Label("dispatch"))
+
+        # ---- epilogue: row sums over the row's four lanes, O / l -> 16 bit -> the wave's LDS image (rows of 272 B), LSE out
+        p.label("epilogue")
+        p.emit("s_nop", 15)
+        lse = [TMP[4], TMP[5], TMP[6], TMP[7]]          # LSE of this lane's row of q group qg
+        for qb in range(2):
+            for h in range(2):
+                qg = 2 * qb + h
+                lt, t = TMP[0], TMP[1]
+                p.emit("v_mov_b32", lt, LS[h][qb])
+                for op in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
+                    p.emit("v_mov_b32", t, lt)
+                    p.emit("s_nop", 1)
+                    p.emit(op, lt, t)
+                    p.emit("v_add_f32", lt, lt, t)
+                    p.emit("s_nop", 0)
+                p.emit("v_rcp_f32", EPX[qg], lt)
+                p.emit("v_log_f32", t, lt)
+                p.emit("s_nop", 0)
+                p.emit("v_add_f32", lse[qg], MC[h][qb], t)
+        p.emit("s_nop", 0)
+        for qg in range(4):
+            for dg in range(8):
+                acc = OACC(dg, qg)
+                for j in range(4):
+                    p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
+                p.emit("s_nop", 0)
+                for j in range(4):
+                    p.emit("v_mul_f32", TMP[j], TMP[j], EPX[qg])
+                p.emit("s_nop", 0)
+                p.emit(self.cvt, TMP[0], TMP[0], TMP[1])
+                p.emit(self.cvt, TMP[1], TMP[2], TMP[3])
+                p.emit("s_nop", 0)
+                # 8 bytes: d = 16 dg + 4 g .. + 3 of row 16 qg + n
+                p.emit("ds_write_b64", A_EPI, V(TMP[0].idx, 2), offset=16 * qg * g.EPI_ROWB + 32 * dg)
+        # the LSE leaves in ONE register: lane l = 16 g + n hands over row l of the wave, i.e. q group g
+        p.emit("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
+        p.emit("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
+        p.emit("s_nop", 0)
+        p.emit("v_lshrrev_b32", TMP[0], 4, TMP[0])
+        p.emit("s_nop", 0)
+        p.emit("v_mov_b32", TMP[1], lse[0])
+        for qg in range(1, 4):
+            p.emit("v_cmp_eq_u32", VCC, qg, TMP[0])
+            p.emit("v_cndmask_b32", TMP[1], TMP[1], lse[qg], VCC)
+        p.emit("s_waitcnt", lgkmcnt=0)
+        p.emit("v_mov_b32", A_LSE0, TMP[1])
+        p.emit("s_branch", Label("end"))
+        for r in self.rare:
+            p.extend(r)
+        p.label("end")
+        return p
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
+    ap.add_argument("--opt", default="", help="schedule tunables / options (fwd_d128_gen.parse_opts)")
+    ap.add_argument("--probe", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    cfg = base.parse_opts(a.opt)
+    if base.is_probe(cfg) and not a.probe:
+        sys.exit("fwd_m16_gen.py: %r contains timing-probe options; they need --probe" % a.opt)
+    for bf16 in (False, True):
+        for fold in (False, True):
+            c = dict(cfg)
+            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o != "ct") + (("ct",) if fold else ())
+            prog = Gen16(bf16, **c).build()
+            path = os.path.join(a.out, "fa2_fwd_m16_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))
+            base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
+            print(path, len(prog.ins), "instructions")
+
+
+if __name__ == "__main__":
+    main()

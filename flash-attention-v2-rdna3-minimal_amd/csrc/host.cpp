@@ -162,7 +162,9 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
 
 int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     const RangePlan r = plan_range(HD, bf16, p, causal);
-    if (r.kernel == FA2_KERNEL_ASM) return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream);
+    // option "asm" bit 6 (default): head dim 128 launches of whole items take the bodies built on v_mfma_f32_16x16x32 (round 5; fwd_asm.cpp)
+    if (r.kernel == FA2_KERNEL_ASM)
+        return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, r.rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, r.rows, false, stream);
 }
 

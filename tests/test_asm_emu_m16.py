@@ -1,0 +1,115 @@
+"""The forward body built on v_mfma_f32_16x16x32 (csrc/gen/fwd_m16_gen.py, round 5) on the instruction-level emulator (tools/asm_emu.py): the same
+checks the 32x32x16 bodies get in tests/test_asm_emu.py — every body variant against float64 attention with the hazard model on, persistent item seams
+(non-causal and causal pairs), the sum-check repair / redo paths — plus the text through the gfx950 assembler.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-v2-rdna3-minimal_amd", "csrc", "gen"))
+import asm_emu_harness as harness  # noqa: E402
+
+
+@pytest.fixture(autouse=True, params=[(), ("ct",)], ids=["f32-scale", "folded-scale"])
+def m16(request):
+    saved = harness.HD, harness.OPT, harness.M16
+    harness.HD, harness.OPT, harness.M16 = 128, request.param, True
+    harness._PROGS.clear()
+    yield request.param
+    harness.HD, harness.OPT, harness.M16 = saved
+    harness._PROGS.clear()
+
+
+CASES = [
+    # Nq, Nkv, q block, causal, bf16, spike
+    (256, 64, 0, False, False, False),         # one tile: head bodies + TC only
+    (256, 128, 0, False, False, False),
+    (256, 192, 0, False, True, False),
+    (256, 256, 0, False, False, False),        # first fast body
+    (256, 640, 0, False, True, False),
+    (200, 333, 0, False, False, False),        # ragged Nq and Nkv
+    (256, 77, 0, True, False, False),          # causal + ragged: the limits of both kinds
+    (512, 512, 1, True, False, False),         # causal diagonal: waves finish at different tiles
+    (1024, 1024, 3, True, True, False),
+    (256, 704, 0, False, False, True),         # hard spikes: P = inf in a sum-check body -> flag -> safe-mode redo
+    (256, 704, 0, False, False, 2),            # moderate spikes: repaired in place, rows of both q groups of a lane
+    (512, 768, 1, True, False, 2),
+    (256, 704, 0, False, True, 3),             # growth of 121 .. 126.6 octaves: redo
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_m16_block_matches_dense_attention(case, m16):
+    Nq, Nkv, qblk, causal, bf16, spike = case
+    err, lerr, m = harness.check(Nq, Nkv, qblk, causal, bf16=bf16, seed=Nq + Nkv, spike=spike, verbose=False)
+    assert not m.errors, m.errors[:5]
+    tol = (8e-3 if bf16 else 1e-3) * (3 if spike else 1)
+    assert err <= tol and lerr <= 1e-4, (err, lerr)
+    if spike == 2:
+        assert m.redos == 0            # repaired in place
+    if spike in (True, 3):
+        assert m.redos == 1
+
+
+def test_m16_fast_bodies_carry_no_cross_lane_instruction():
+    """What makes the other MFMA tile affordable: a Q row is spread over four lanes, and the fast bodies never look across them — per-lane partial
+    sums and a per-lane sum check; every permlane swap of the block is in a head / tail body, an out-of-line block or the epilogue."""
+    import fwd_m16_gen
+    g = fwd_m16_gen.Gen16(False, opt=harness.OPT)
+    prog = g.build()
+    names = [i.ops[0].name if i.op == "label" else None for i in prog.ins]
+    lo, hi = names.index("fast0"), names.index("dispatch")
+    ops = [i.op for i in prog.ins[lo:hi]]
+    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 2 * 128
+    assert not any(o.startswith("v_permlane") or o.startswith("v_max") for o in ops)
+
+
+SEAMS = [
+    (512, [256, 256], [0, 1], False, False),
+    (512, [64, 64, 64], [0, 1, 0], False, False),        # one tile per item: the seam is a head body
+    (768, [640, 640, 600], [0, 2, 1], False, False),     # the next item's Q fully staged by the fast bodies
+    (256, [192, 192], [0, 0], False, True),
+    (1024, [1024, 1024], [3, 0], True, False),           # causal pair: a long block, then its short partner
+    (768, [768, 768, 768], [2, 0, 1], True, True),
+]
+
+
+@pytest.mark.parametrize("seam", SEAMS)
+def test_m16_persistent_workgroup_seams(seam):
+    nq, nkvs, qblks, causal, bf16 = seam
+    rng = np.random.default_rng(nq + sum(nkvs))
+    if causal:
+        q, k, v = (rng.standard_normal((nq, 128)) for _ in range(3))
+        items = [(q, k, v, qb) for qb in qblks]
+    else:
+        items = [(rng.standard_normal((nq, 128)), rng.standard_normal((nkv, 128)), rng.standard_normal((nkv, 128)), qb) for nkv, qb in zip(nkvs, qblks)]
+    outs, m = harness.run_items(items, causal, bf16=bf16)
+    assert not m.errors, m.errors[:5]
+    for (q, k, v, qb), (o, lse) in zip(items, outs):
+        r0 = qb * 256
+        o_ref, lse_ref = harness.dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre=bool(harness.OPT))
+        assert np.abs(o - o_ref).max() <= (8e-3 if bf16 else 1.1e-3)
+        assert np.abs(lse - lse_ref).max() <= 1e-4
+
+
+def test_m16_text_assembles_for_gfx950(tmp_path):
+    import re
+    import shutil
+    import subprocess
+    import fwd_m16_gen
+    mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    subst = {0: "v0", 1: "v1", 2: "v2", 3: "s2", 4: "s[36:39]", 5: "s[4:7]", 6: "s[8:11]", 7: "v6", 8: "v7", 9: "v8", 10: "v9", 11: "v10",
+             12: "v11", 13: "s12", 14: "s13", 15: "s14", 16: "s15", 17: "s16", 18: "s17", 19: "s18", 20: "s19", 21: "v12", 22: "s20",
+             23: "s21", 24: "s3", 25: "s[40:43]", 26: "s[24:27]", 27: "s[28:31]", 28: "s[32:33]"}
+    for bf16 in (False, True):
+        text = "\n".join(fwd_m16_gen.Gen16(bf16, opt=harness.OPT).build().text_lines())
+        text = re.sub(r"%(\d+)", lambda m_: subst[int(m_.group(1))], text.replace("%=", "0"))
+        src = tmp_path / ("m16_%d.s" % bf16)
+        src.write_text(text + "\n")
+        res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[:2000]

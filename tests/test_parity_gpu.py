@@ -1065,3 +1065,31 @@ def test_compiled_autograd_node_matches_python_class():
     k.requires_grad_(True)
     o = FlashAttentionFunction.apply(q2, k, v, None, False)
     assert type(o.grad_fn).__name__ == "FlashAttentionFunctionBackward"
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_both_mfma_tiles_of_the_head_dim_128_forward_hold_the_planned_contract(dt, causal):
+    """Round 5: head dim 128 launches of whole items run bodies built on v_mfma_f32_16x16x32 by default (option "asm" bit 6; csrc/gen/fwd_m16_gen.py:
+    a Q row is spread over four lanes there) and the 32x32x16 bodies otherwise (bit 6 clear; KV-split launches).  Same contract either way — both
+    against the oracle under the contract fa2_fwd_plan names, under every `fold` setting, on a ragged shape with more items than workgroups (first
+    items, prefetched items, a ragged last tile, rows past Nq) — and the two differ only in f32 summation order."""
+    B, H, N, Nkv = (2, 40, 2000, 2000) if causal else (3, 30, 1000, 1111)          # 640 / 360 items of 256 rows; ragged Nq and Nkv
+    g = torch.Generator(device="cpu").manual_seed(900 + dt + 2 * causal)
+    q = torch.randn((B, H, N, 128), generator=g).to(TORCH_DT[dt]).to(_dev())
+    k, v = (torch.randn((B, H, Nkv, 128), generator=g).to(TORCH_DT[dt]).to(_dev()) for _ in range(2))
+    for fold in (0, 1, 2):
+        outs = {}
+        for asm in (67, 3):
+            with _fa2_lib.options(asm=asm, fold=fold, rows=256):
+                plan = _plan(q, k, causal)
+                assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.heads_main == B * H
+                assert bool(plan.contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q) == (fold >= (2 if dt else 1))
+                o, lse = _cabi_forward(q, k, v, causal)
+                for head in (0, B * H // 2, B * H - 1):
+                    b, h = divmod(head, H)
+                    sl = (slice(b, b + 1), slice(h, h + 1))
+                    _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, causal, plan=plan, head=head)
+            outs[asm] = (o, lse)
+        assert float((outs[67][0].float() - outs[3][0].float()).abs().max()) <= (3.2e-2 if dt else 4e-3)
+        assert float((outs[67][1] - outs[3][1]).abs().max()) <= 1e-4

@@ -295,6 +295,42 @@ class Machine:
         w.n_issued += 1
         ops = ins.ops
         R = lambda i: self.resolve(w, ops[i])   # noqa: E731
+        if op.startswith("v_mfma_f32_16x16x32"):
+            # A[m][k]: lane l holds m = l % 16, k = 8 (l / 16) .. + 7;  B[k][n]: n = l % 16, the same k;  D[m][n]: n = l % 16, m = 4 (l / 16) + i (4 registers)
+            start = max(w.cycle, w.mfma_free)
+            w.cycle = start
+            dst = R(0)
+            a = self.frag_to_f32(w, ops[1], "mfma_ab")
+            b = self.frag_to_f32(w, ops[2], "mfma_ab")
+            Am = np.zeros((16, 32), dtype=np.float32)
+            Bm = np.zeros((32, 16), dtype=np.float32)
+            for l in range(NLANE):
+                Am[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = a[l]
+                Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = b[l]
+            with np.errstate(invalid="ignore", over="ignore"):
+                D = Am.astype(np.float64) @ Bm.astype(np.float64)
+            c = ops[3]
+            rf = self.regfile(w, dst.kind)
+            out = np.empty((4, NLANE), dtype=np.float32)
+            for r in range(4):
+                out[r] = D[4 * (LANES >> 4) + r, LANES & 15].astype(np.float32)
+            if not (isinstance(c, int) and c == 0):
+                cr = self.resolve(w, c)
+                self.check_read(w, cr.kind, cr.idx, 4, "mfma_c")
+                with np.errstate(invalid="ignore", over="ignore"):
+                    out = (out.astype(np.float64) + self.regfile(w, cr.kind)[cr.idx:cr.idx + 4].view(np.float32).astype(np.float64)).astype(np.float32)
+            for r in range(4):
+                key = (dst.kind, dst.idx + r)
+                if self.check and w.inflight.get(key, 0) > 0:
+                    self.err(w, "MFMA writes %s%d while a load into it is in flight" % key)
+                rf[dst.idx + r] = out[r].view(np.uint32)
+                w.mfma_ready[key] = start + 40.0          # 4 passes: a dependent MFMA / a VALU read this long after the issue
+                w.last_valu_write.pop(key, None)
+            w.mfma_free = start + 16.0
+            w.cycle = start + 4.0
+            w.issue_idx += 1
+            w.pc = nxt
+            return
         if op.startswith("v_mfma"):
             start = max(w.cycle, w.mfma_free)
             w.cycle = start
@@ -529,6 +565,25 @@ class Machine:
             ny[:32] = x[32:]
             self.wr32(w, d, nx)
             self.wr32(w, s, ny)
+        elif op == "v_permlane16_swap_b32":
+            # within each half of the wave (32 lanes): lanes 16..31 of the first operand <-> lanes 0..15 of the second
+            d, s_ = R(0), R(1)
+            x, y = self.rd32(w, d, "permlane"), self.rd32(w, s_, "permlane")
+            nx, ny = x.copy(), y.copy()
+            for h0 in (0, 32):
+                nx[h0 + 16:h0 + 32] = y[h0:h0 + 16]
+                ny[h0:h0 + 16] = x[h0 + 16:h0 + 32]
+            self.wr32(w, d, nx)
+            self.wr32(w, s_, ny)
+        elif op == "v_min_i32":
+            self.wr32(w, ops[0], np.minimum(self.rd32(w, ops[1]).view(np.int32), self.rd32(w, ops[2]).view(np.int32)).view(np.uint32))
+        elif op == "ds_write_b64":
+            addr = self.rd32(w, ops[0]).astype(np.int64) + ins.mods.get("offset", 0)
+            src = R(1)
+            self.check_read(w, src.kind, src.idx, 2, "valu")
+            data = np.ascontiguousarray(self.regfile(w, src.kind)[src.idx:src.idx + 2].T).view(np.uint8)   # [64, 8]
+            self.lds_write(w, addr, data)
+            w.lgkm.append(lambda: None)
         elif op == "v_accvgpr_read_b32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]))
         elif op == "v_accvgpr_write_b32":

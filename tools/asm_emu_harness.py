@@ -16,12 +16,17 @@ LOG2E = 1.4426950408889634
 _PROGS = {}
 OPT = ()                # generator options of the programs under test (default: the f32-scale body the library ships)
 HD = 128                # head dim of the programs under test (128 or 64)
+M16 = False             # the v_mfma_f32_16x16x32 generator (csrc/gen/fwd_m16_gen.py, head dim 128) instead of the 32x32x16 one
 
 
 def program(bf16):
-    key = (bf16, HD) if HD != 128 else bf16
+    key = (bf16, HD, M16)
     if key not in _PROGS:
-        _PROGS[key] = gen.Gen(bf16, hd=HD, opt=OPT).build()
+        if M16:
+            import fwd_m16_gen
+            _PROGS[key] = fwd_m16_gen.Gen16(bf16, opt=OPT).build()
+        else:
+            _PROGS[key] = gen.Gen(bf16, hd=HD, opt=OPT).build()
     return _PROGS[key]
 
 
@@ -83,6 +88,21 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     trow = 4 * hi + (pp >> 2)
     v[10] = (trow * g.ROWB + (((trow // rpb) & vmask) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
     v[13] = (g.EPI_BASE + w * 64 * g.EPI_ROWB + l31 * g.EPI_ROWB + hi * 16).astype(np.uint32)
+    if M16:
+        # lane = (n = lane % 16, g4 = lane / 16).  K / Q fragment of k-step ks: row n, granule 4 ks + g4 of the swizzled row image (the asm xors ks << 6)
+        n16, g4 = lane & 15, lane >> 4
+        v[9] = (n16 * g.ROWB + ((g4 ^ (n16 & kmask)) << 4)).astype(np.uint32)
+        # V^T fragment: the 16-lane group g4 addresses rows 4 g4 + (n >> 2), 8 bytes at column 4 (n & 3) of the 16-column group (chunk 0 swizzled; the asm
+        # xors (dg >> 1) << 6 and adds 32 (dg & 1))
+        trow = 4 * g4 + (n16 >> 2)
+        v[10] = (trow * g.ROWB + ((trow & vmask) << 6) + 8 * (n16 & 3)).astype(np.uint32)
+        # masks of the wave's last tile: row 16 qg + n keeps kv_local = 16 kg + 4 g4 + i  iff  16 kg + i <= min(L0 + 16 qg, cap)
+        qrow0 = qw0 + n16
+        l0 = (qrow0 if causal else np.full(64, 0x3fff0000)) - 64 * (ntw - 1) - 4 * g4
+        cap = np.full(64, Nkv - 1) - 64 * (ntw - 1) - 4 * g4
+        v[11] = l0.astype(np.int32).view(np.uint32)
+        v[12] = cap.astype(np.int32).view(np.uint32)
+        v[13] = (g.EPI_BASE + w * 64 * g.EPI_ROWB + n16 * g.EPI_ROWB + g4 * 8).astype(np.uint32)
 
     def srd(base, nkv):
         return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + g.ROWB, 0x00020000], dtype=np.uint32)
@@ -195,6 +215,9 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             o = from_bits(img, bf16)[:rows]
         lse = np.empty(256, dtype=np.float32)
         for w in range(4):
+            if M16:         # one output register: lane l hands over row l of the wave
+                lse[64 * w:64 * w + 64] = m.waves[w].v[0].view(np.float32)
+                continue
             for qb in range(2):
                 lse[64 * w + 32 * qb:64 * w + 32 * qb + 32] = m.waves[w].v[qb][:32].view(np.float32)
         outs.append((o, lse[:rows].copy()))

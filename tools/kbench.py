@@ -26,6 +26,9 @@ CFGS = {
     "c3": (2, 16, 4096, 128, "bf16", True),
     "c4": (1, 32, 8192, 128, "f16", True),
     "b8": (8, 16, 4096, 128, "f16", False),
+    "c2b": (2, 16, 4096, 128, "bf16", False),
+    "b8b": (8, 16, 4096, 128, "bf16", False),
+    "c4b": (1, 32, 8192, 128, "bf16", True),
     "d64": (2, 16, 4096, 64, "f16", False),
     "d64c": (2, 16, 4096, 64, "bf16", True),
     "d64b": (2, 16, 4096, 64, "bf16", False),
@@ -60,7 +63,7 @@ def build(specs):
     for s in specs:
         name, _, flags = s.partition(":")
         fl = [f for f in flags.split(",") if f]
-        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "only="))]
+        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "m16gen=", "only=", "opts="))]
         only = None if extra else ["fwd_asm", "bwd_asm"]          # generator-only variants: recompile just the units that include the bodies
         for f in fl:
             if f.startswith("only="):                            # only=fwd_asm+host: -D flags that matter to these units alone
@@ -71,10 +74,16 @@ def build(specs):
                 opts["fwd_d128_gen.py"] = f[4:].replace(";", ",")
             if f.startswith("bgen="):
                 opts["bwd_d128_gen.py"] = f[5:].replace(";", ",")
+            if f.startswith("m16gen="):      # options of csrc/gen/fwd_m16_gen.py (the 16x16x32 body)
+                opts["fwd_m16_gen.py"] = f[7:].replace(";", ",")
         gdir = os.path.join(VAR_DIR, name + "_gen")
         os.makedirs(gdir, exist_ok=True)
         b.generate(gdir, opts, probe=True)
         out = os.path.join(VAR_DIR, name + ".so")
+        for f in fl:
+            if f.startswith("opts="):        # opts=fold=0;asm=67 -> <name>.opts: fa2_set_option on this copy of the library at load (Variant)
+                with open(os.path.join(VAR_DIR, name + ".opts"), "w") as fo:
+                    fo.write(f[5:].replace(";", " ") + "\n")
         try:
             log = b.compile_library(out, extra_flags=extra, inc_dir=gdir, verbose=True, only=only)
         except RuntimeError as e:
@@ -98,6 +107,12 @@ class Variant:
         import torch  # noqa: F401  (torch's HIP runtime first)
         self.name = os.path.basename(path)[:-3]
         self.lib = ctypes.CDLL(path)
+        # <name>.opts next to the library: "asm=67 fold=0" -> fa2_set_option on THIS copy of the library (options are per loaded library)
+        if os.path.exists(path[:-3] + ".opts"):
+            self.lib.fa2_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+            for kv in open(path[:-3] + ".opts").read().split():
+                k, _, v = kv.partition("=")
+                assert self.lib.fa2_set_option(k.encode(), int(v)) == 0, kv
         i64p = ctypes.POINTER(ctypes.c_int64)
         self.lib.fa2_fwd.restype = ctypes.c_int
         self.lib.fa2_fwd.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [i64p] * 5 + \

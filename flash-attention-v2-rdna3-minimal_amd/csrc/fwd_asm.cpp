@@ -50,10 +50,10 @@ static int launch_asm_hd(const FwdParams& p, bool causal, bool fold, hipStream_t
 }
 
 int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16) {
-    // The v_mfma_f32_16x16x32 bodies: head dim 128, whole items only.  Measured against the 32x32x16 bodies on one box (tools/kbench.py,
+    // The v_mfma_f32_16x16x32 bodies: head dim 128.  Measured against the 32x32x16 bodies on one box (tools/kbench.py,
     // profiles/r16_kbench_m16_*.txt): folded scale fp16 c2 +4.7 %, c4 +4.6 %, B8 +3.8 %; f32 scale fp16 +3.3 % / +3.3 % / +1.1 %; f32 scale bf16
     // -0.5 .. +0.5 % (c3, c2-shape, B8: the bf16 32x32x16 MFMA is the cheaper one to begin with, profiles/mfma_peak.json) -> those stay where they were.
-    if (m16 && HD == 128 && p.item_cap == 0 && (fold || !bf16)) {
+    if (m16 && HD == 128 && (fold || !bf16)) {
         if (fold) {
             if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
             return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);

@@ -25,14 +25,14 @@ tile: 128 MFMA issues per body instead of 64 make the body issue-bound (the fill
 and the fold takes 64 of them out.  The C tuples take v[176:191]: the V^T fragments of k-step 1 move to a[224:255], the K fragments to a
 32-register pool (k-steps 2, 3 are read into the slots of 0, 1 once those MFMAs are issued; counted lgkmcnt waits, sched.lds_waits).
 
-Not in this generator (the 32 x 32 kernels keep those launches): head dim 64, KV-split parts.
+Not in this generator (the 32 x 32 kernels keep those launches): head dim 64.
 """
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.realpath(__file__)))
 import fwd_d128_gen as base  # noqa: E402
-from fwd_d128_gen import (A_C, A_EPI, A_FLAGS, A_KD0, A_KR0, A_KRS, A_KROW4, A_KTILE, A_LDSW, A_LIM0, A_LIM1, A_LSE0, A_NKRS, A_NQRS,  # noqa: E402,F401
+from fwd_d128_gen import (A_C, A_EPI, A_FLAGS, A_WSB, A_KD0, A_KR0, A_KRS, A_KROW4, A_KTILE, A_LDSW, A_LIM0, A_LIM1, A_LSE0, A_NKRS, A_NQRS,  # noqa: E402,F401
                           A_NQW, A_NTW, A_NTWG, A_NVRS, A_QD0, A_QRS, A_QT16, A_QW, A_VD0, A_VR0, A_VROW4, A_VRS, A_VTILE, KD, NEG_INF,
                           PSUM_MAX, QD, SB, S_D, S_FLAG, S_FIX, S_KOFF, S_NFAST, S_NOVM, S_PF, S_QH, S_QM0, S_QSB, S_QSOFF, S_SUM, S_T, S_TMP,
                           S_TMP2, S_VOFF, S_WAVE, THR, VBASE, VD)
@@ -689,6 +689,8 @@ class Gen16(base.Gen):
                 p.emit("s_nop", 0)
                 p.emit("v_add_f32", lse[qg], MC[h][qb], t)
         p.emit("s_nop", 0)
+        p.emit("s_bitcmp1_b32", A_FLAGS, 3)
+        p.emit("s_cbranch_scc1", Label("part_store"))
         for qg in range(4):
             for dg in range(8):
                 acc = OACC(dg, qg)
@@ -703,6 +705,7 @@ class Gen16(base.Gen):
                 p.emit("s_nop", 0)
                 # 8 bytes: d = 16 dg + 4 g .. + 3 of row 16 qg + n
                 p.emit("ds_write_b64", A_EPI, V(TMP[0].idx, 2), offset=16 * qg * g.EPI_ROWB + 32 * dg)
+        p.label("lse_out")
         # the LSE leaves in ONE register: lane l = 16 g + n hands over row l of the wave, i.e. q group g
         p.emit("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
         p.emit("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
@@ -716,6 +719,39 @@ class Gen16(base.Gen):
         p.emit("s_waitcnt", lgkmcnt=0)
         p.emit("v_mov_b32", A_LSE0, TMP[1])
         p.emit("s_branch", Label("end"))
+        # ---- a KV-split part (flag bit 3; fa2_fwd_ws): the normalised f32 tile goes straight to the part's workspace tile — float
+        # (((dt*4 + g) * 256 + row) * 8 + 4*hi + e) for d = 32 dt + 8 g + 4 hi + e, the layout of every part in this library (fa2_fwd_kernel.hip.h).
+        # This lane holds d = 16 dg + 4 g4 + i of row 64 wave + 16 qg + n: dt = dg >> 1, g = 2 (dg & 1) + (g4 >> 1), hi = g4 & 1, e = i.
+        p.label("part_store")
+        wso, adr = KD[2], KD[3]
+        p.emit("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
+        p.emit("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
+        p.emit("s_lshl_b32", S_TMP, S_WAVE, 6)
+        p.emit("v_and_b32", TMP[1], 15, TMP[0])                 # n
+        p.emit("v_lshrrev_b32", TMP[2], 4, TMP[0])              # g4
+        p.emit("v_add_u32", TMP[1], S_TMP, TMP[1])              # 64 wave + n
+        p.emit("v_and_b32", TMP[3], 1, TMP[2])                  # hi
+        p.emit("v_lshrrev_b32", TMP[2], 1, TMP[2])              # g4 >> 1
+        p.emit("v_lshlrev_b32", TMP[1], 5, TMP[1])              # row * 32 bytes
+        p.emit("v_lshlrev_b32", TMP[3], 4, TMP[3])
+        p.emit("v_lshlrev_b32", TMP[2], 13, TMP[2])             # (g4 >> 1) * 8192
+        p.emit("s_nop", 0)
+        p.emit("v_add_u32", wso, TMP[1], TMP[3])
+        p.emit("s_nop", 0)
+        p.emit("v_add_u32", wso, wso, TMP[2])
+        for qg in range(4):
+            for dg in range(8):
+                acc = OACC(dg, qg)
+                for j in range(4):
+                    p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
+                p.emit("v_add_u32", adr, 512 * qg + 8192 * (4 * (dg >> 1) + 2 * (dg & 1)), wso)
+                for j in range(4):
+                    p.emit("v_mul_f32", TMP[j], TMP[j], EPX[qg])
+                p.emit("s_nop", 0)
+                p.emit("global_store_dwordx4", adr, V(TMP[0].idx, 4), A_WSB)
+                p.emit("s_nop", 3)             # (a store of more than 64 bits: its data registers must not be rewritten right behind it)
+        p.emit("s_waitcnt", vmcnt=0)           # the stores, and whatever the item seam prefetched: the next statement counts loads only
+        p.emit("s_branch", Label("lse_out"))
         for r in self.rare:
             p.extend(r)
         p.label("end")

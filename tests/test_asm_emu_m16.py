@@ -113,3 +113,25 @@ def test_m16_text_assembles_for_gfx950(tmp_path):
         src.write_text(text + "\n")
         res = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(src)], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[:2000]
+
+
+def test_m16_kv_split_part_epilogue():
+    """KV-split parts (fa2_fwd_ws; flag bit 3): a whole item, then two parts of another item through the item seam — each part leaves its NORMALISED f32
+    tile in its workspace tile, in the layout of every part in this library (float (((dt*4 + g) * 256 + row) * 8 + 4*hi + e)), and its partial LSE;
+    merged like fwd_combine_kernel they are the whole item.  The workspace starts NaN-filled: every element must be written."""
+    rng = np.random.default_rng(128)
+    q, k, v = rng.standard_normal((512, 128)), rng.standard_normal((448, 128)), rng.standard_normal((448, 128))
+    items = [(q, k, v, 1), (q, k[:256], v[:256], 0, True), (q, k[256:], v[256:], 0, True)]      # parts: tiles [0, 4) and [4, 7) of q block 0
+    outs, m = harness.run_items(items, False)
+    assert not m.errors, m.errors[:5]
+    pre = bool(harness.OPT)
+    for (item, (o, lse)) in zip(items, outs):
+        qq, kk, vv, qb = item[:4]
+        o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre=pre)
+        assert np.isfinite(o).all()
+        assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-4
+    (o1, l1), (o2, l2) = outs[1], outs[2]
+    lse = np.logaddexp2(l1, l2)
+    o = o1 * np.exp2(l1 - lse)[:, None] + o2 * np.exp2(l2 - lse)[:, None]
+    o_ref, lse_ref = harness.dense(q[:256], k, v, False, pre=pre)
+    assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-3

@@ -81,6 +81,7 @@ def VF_CT(dg, kvs):
     return V(144 + 4 * dg, 4) if kvs == 0 else A(224 + 4 * dg, 4)
 
 
+VRO = [V(196 + i) for i in range(4)]               # "ct": read addresses of the ODD d groups (see stream_vread)
 CT16 = [V(176 + 4 * qg, 4) for qg in range(4)]     # -(reference) of this lane's row of q group qg, four copies (the C operand of a 16 x 16 tile)
 DSH16 = [[V(192), V(193)], [V(194), V(195)]]       # [h][qb]: pending shift of the NEXT tile's scores of row h of q block qb (see rare_fix)
 
@@ -463,13 +464,21 @@ class Gen16(base.Gen):
                 for ks in range(4) for kg in range(4)]
 
     def stream_vread(self, par):
+        """V^T fragments: two transposed reads per (d group, k-step).  A read's lanes 0..31 are the 16-lane groups g = 0, 1: rows 4 g + (n >> 2) — rows r and
+        r + 4 of the tile, which the V image (64-byte chunk ^ (row & 3)) keeps in the same banks: a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT
+        8.8e6 per c2 launch, profiles/r17_c2_summary.txt).  "ct" kernels (they have the registers) keep a V image of their own in which the 32-byte half
+        of a chunk is flipped for rows with (row >> 2) & 1 (fa2_fwd_d128.hip.h: vd0; VD below) and read the odd d groups through a second address set."""
         out = []
         g = self.g
         for kvs in range(2):
             for dg in range(8):
-                off = g.V_BASE + par * g.SLOT_B + 32 * kvs * g.ROWB + 32 * (dg & 1)
-                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(0, 2), VR[dg >> 1], tag="lds", offset=off))
-                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(2, 2), VR[dg >> 1], tag="lds", offset=off + 16 * g.ROWB))
+                off = g.V_BASE + par * g.SLOT_B + 32 * kvs * g.ROWB
+                if self.ct:
+                    adr = (VRO if dg & 1 else VR)[dg >> 1]
+                else:
+                    adr, off = VR[dg >> 1], off + 32 * (dg & 1)
+                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(0, 2), adr, tag="lds", offset=off))
+                out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(2, 2), adr, tag="lds", offset=off + 16 * g.ROWB))
         return out
 
     def seam_q_reads(self):
@@ -503,6 +512,9 @@ class Gen16(base.Gen):
             p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
         for j in range(4):
             p.emit("v_xor_b32", VR[j], j << 6, A_VR0)
+        if self.ct:
+            for j in range(4):
+                p.emit("v_xor_b32", VRO[j], (j << 6) | 32, A_VR0)      # the other 32-byte half
         p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mul_i32", S_QSB, S_WAVE, 64 * g.EPI_ROWB)
         p.emit("s_add_u32", S_QSB, S_QSB, g.EPI_BASE)
@@ -545,7 +557,12 @@ class Gen16(base.Gen):
             p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
             p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
             p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
-            p.emit("v_add_u32", VD[i], S_TMP2, A_VD0)
+            if self.ct and (i & 1):       # the rows of an odd piece have (row >> 2) & 1 set: their 32-byte halves are flipped in the "ct" V image
+                p.emit("v_xor_b32", VD[i], 32, A_VD0)
+                p.emit("s_nop", 0)
+                p.emit("v_add_u32", VD[i], S_TMP2, VD[i])
+            else:
+                p.emit("v_add_u32", VD[i], S_TMP2, A_VD0)
             p.emit("s_nop", 0)
             p.emit("v_add_u32", KD[i], S_TMP, KD[i])
         p.emit("s_mov_b32", S_T, -2)

@@ -96,6 +96,12 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         # xors (dg >> 1) << 6 and adds 32 (dg & 1))
         trow = 4 * g4 + (n16 >> 2)
         v[10] = (trow * g.ROWB + ((trow & vmask) << 6) + 8 * (n16 & 3)).astype(np.uint32)
+        if "ct" in OPT:
+            # the folded bodies' own V image: the 32-byte half of a chunk is flipped for rows with (row >> 2) & 1 (conflict-free transposed reads)
+            v[10] = v[10] + (32 * (g4 & 1)).astype(np.uint32)
+            drow = (64 // 4) * w + lane // gran
+            gv2 = (((slot >> 2) ^ ((drow // rpb) & vmask)) << 2) | ((slot & 3) ^ (((drow >> 2) & 1) << 1))
+            v[8] = (drow * row_bytes + gv2 * 16).astype(np.uint32)
         # masks of the wave's last tile: row 16 qg + n keeps kv_local = 16 kg + 4 g4 + i  iff  16 kg + i <= min(L0 + 16 qg, cap)
         qrow0 = qw0 + n16
         l0 = (qrow0 if causal else np.full(64, 0x3fff0000)) - 64 * (ntw - 1) - 4 * g4

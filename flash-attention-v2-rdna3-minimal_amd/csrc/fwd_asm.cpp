@@ -26,7 +26,9 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
         // B2 H16 N4096 bf16 112.7 -> 112.1 us, B4 H16 N2048 70.0 -> 69.4 (profiles/r16_kbench_pairs_ab.txt); fewer units than CUs keep single items
         // (twice the workgroups: more of the chip busy).
         const int64_t units = (int64_t)p.nbh * ((p.nqblk + 1) / 2);
-#ifndef FA2_PAIRS_ALWAYS      // (developer A/B: tools/kbench.py build pairs:-DFA2_PAIRS_ALWAYS=1)
+#if defined(FA2_PAIRS_ROUND4)   // (developer A/B, tools/kbench.py build nopairs:-DFA2_PAIRS_ROUND4=1,only=fwd_asm: round 4's rule)
+        if (!(units > pg || p.nqblk >= 32)) p.persist = 0;
+#elif !defined(FA2_PAIRS_ALWAYS)
         if (!(units >= pg || p.nqblk >= 32)) p.persist = 0;
 #endif
     }

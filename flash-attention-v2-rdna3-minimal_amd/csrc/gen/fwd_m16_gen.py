@@ -88,9 +88,10 @@ DSH16 = [[V(192), V(193)], [V(194), V(195)]]       # [h][qb]: pending shift of t
 
 class Gen16(base.Gen):
     # schedule windows of a 128-gap body: the base generator's, in units of the shorter MFMA
-    # (measured, tools/kbench.py on one box, folded body, c2 / b8 us: dma 20:56, vread 66:80 (the base windows doubled) 205.4 / 839.8; dma 8:40 204.6 / 833.6;
-    #  + vread 66:100 203.0 / 822.4; the exp / pack windows are flat — profiles/r16_kbench_m16_sweep.txt)
-    DEFAULTS16 = {"m": (4.0, 20.0), "e": (20.0, 128.0), "vread": (66.0, 100.0), "kread": (0.0, 48.0), "dma": (8.0, 40.0), "mmask": (4.0, 48.0),
+    # (measured, tools/kbench.py, folded body, c2 / b8 / c4 us on one box: dma 8:40 + vread 66:100 203.6 / 837.3 / 422.4; dma 4:36 + vread 66:80 200.6 / 823.2 /
+    #  413.6 — the LDS-DMA pieces want to be early, the V^T reads compact since their image is conflict-free; K-read and exp / pack windows are flat:
+    #  profiles/r16_kbench_m16_sweep.txt, r16_kbench_m16_windows2.txt)
+    DEFAULTS16 = {"m": (4.0, 20.0), "e": (20.0, 128.0), "vread": (66.0, 80.0), "kread": (0.0, 48.0), "dma": (4.0, 36.0), "mmask": (4.0, 48.0),
                   "se0": (0.0, 96.0), "se1": (16.0, 120.0), "sc0": (96.0, 116.0), "sc1": (120.0, 128.0)}
 
     def __init__(self, bf16=False, **cfg):

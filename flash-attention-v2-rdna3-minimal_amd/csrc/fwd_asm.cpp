@@ -55,7 +55,11 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
     // The v_mfma_f32_16x16x32 bodies: head dim 128.  Measured against the 32x32x16 bodies on one box (tools/kbench.py,
     // profiles/r16_kbench_m16_*.txt): folded scale fp16 c2 +4.7 %, c4 +4.6 %, B8 +3.8 %; f32 scale fp16 +3.3 % / +3.3 % / +1.1 %; f32 scale bf16
     // -0.5 .. +0.5 % (c3, c2-shape, B8: the bf16 32x32x16 MFMA is the cheaper one to begin with, profiles/mfma_peak.json) -> those stay where they were.
-    if (m16 && HD == 128 && (fold || !bf16)) {
+    // The folded 16 x 16 bodies derive the LDS-DMA source offsets of the odd V pieces by flipping bit 5 of the byte offset (their V image keeps the
+    // 32-byte halves of those rows flipped): the same as re-deriving the granule only when a row's byte offset has that bit clear — V's row pitch must
+    // be a multiple of 64 bytes (contiguous BHND / BNHD tensors are; a row-padded V is not and keeps the 32 x 32 body: found by tools/fuzz_parity.py,
+    // profiles/fuzz_runs.md row r17_fuzz_rows256_seed503).
+    if (m16 && HD == 128 && (fold ? p.vs[2] % 32 == 0 : !bf16)) {
         if (fold) {
             if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
             return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);

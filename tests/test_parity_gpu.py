@@ -1093,3 +1093,26 @@ def test_both_mfma_tiles_of_the_head_dim_128_forward_hold_the_planned_contract(d
             outs[asm] = (o, lse)
         assert float((outs[67][0].float() - outs[3][0].float()).abs().max()) <= (3.2e-2 if dt else 4e-3)
         assert float((outs[67][1] - outs[3][1]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("pitch", [136, 160, 192])
+def test_row_padded_v_on_the_hand_scheduled_head_dim_128_kernels(pitch):
+    """A V whose rows are a column slice of a wider matrix (row pitch 136 / 160 / 192 elements: multiples of 8, 32 and 64) on a grid that reaches the
+    hand-scheduled kernels.  The folded 16x16x32 bodies derive the source offsets of every other V piece by flipping a bit of the byte offset, which
+    needs a pitch that is a multiple of 32 elements (fwd_asm.cpp keeps other pitches on the 32x32x16 body) — found by tools/fuzz_parity.py in round 5
+    (profiles/fuzz_runs.md, row r17_fuzz_rows256_seed503: O wrong by 0.2 .. 4, LSE right)."""
+    B, H, N = 2, 40, 1500
+    g = torch.Generator(device="cpu").manual_seed(pitch)
+    q, k = (torch.randn((B, H, N, 128), generator=g).half().to(_dev()) for _ in range(2))
+    vw = torch.randn((B, H, N, pitch), generator=g).half().to(_dev())
+    v = vw[..., :128]
+    assert v.stride(2) == pitch
+    for causal in (False, True):
+        with _fa2_lib.options(rows=256):
+            plan = _plan(q, k, causal)
+            assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM
+            o, lse = _cabi_forward(q, k, v, causal)
+        for head in (0, B * H - 1):
+            b, h = divmod(head, H)
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl].contiguous(), 0, causal, plan=plan, head=head)

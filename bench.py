@@ -460,7 +460,8 @@ def main():
         value = flops_global * args.steps / elapsed / 1e12
         achieved = flops_local / (kernel_ms * 1e-3) / 1e12
         peak_rec = read_json("mfma_peak.json")
-        sustained = peak_rec.get("sustained_tflops_f16" if dtype == torch.float16 else "sustained_tflops_bf16")
+        # (fp16 head-dim-128 launches run the 16x16x32 MFMA since round 5: the MFMA-only rate of that instruction where it was measured)
+        sustained = (peak_rec.get("sustained_tflops_f16_16x16x32") or peak_rec.get("sustained_tflops_f16")) if dtype == torch.float16 else peak_rec.get("sustained_tflops_bf16")
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": read_json("hbm_traffic.json").get(args.workload, {}).get("hbm_bytes_per_launch"),

@@ -52,16 +52,26 @@ size_t cached_ws_bytes(int which, int dtype, int dev, int64_t b, int64_t h, int6
 // plus at most 64 MiB per stream in use, not a fresh block per call in flight (the reference records peak memory on every run, bench_with_sdpa.py:34).
 // While the stream is being captured into a graph the block comes from the caching allocator (the capture's private pool keeps it alive for the
 // replays).  FA2_WS_POOL=0: per-call allocation.  Forward (caller's thread) and backward (the autograd engine's device thread) share the pool: a mutex.
+struct WsSlot { int dev; hipStream_t stream; at::Tensor ws; };
+std::mutex g_ws_mu;
+std::vector<WsSlot> g_ws_pool;
+
+int64_t workspace_pool_bytes() {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    int64_t n = 0;
+    for (const WsSlot& s : g_ws_pool) n += s.ws.numel();
+    return n;
+}
+
 at::Tensor workspace(size_t bytes, const at::Tensor& like, hipStream_t stream) {
     static const bool pool_on = [] { const char* e = std::getenv("FA2_WS_POOL"); return !(e && e[0] == '0'); }();
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (!pool_on || (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone))
         return at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
-    struct Slot { int dev; hipStream_t stream; at::Tensor ws; };
-    static std::mutex mu;
-    static std::vector<Slot> pool;
+    using Slot = WsSlot;
+    std::vector<Slot>& pool = g_ws_pool;
     const int dev = like.device().index();
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_ws_mu);
     for (size_t i = 0; i < pool.size(); ++i)
         if (pool[i].dev == dev && pool[i].stream == stream) {
             if ((size_t)pool[i].ws.numel() < bytes) pool[i].ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
@@ -227,5 +237,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled front end of the gfx950 FlashAttention-2 operator (forward of the reference's flash_attn_wmma module)";
     m.def("forward", &forward, "forward(q, k, v, Br, Bc, causal (bool, or the C-ABI's call flags), scale, permute_NH) -> [O_fwd, q_pad, k_pad, v_pad, O, L]");
     m.def("attention", &attention, "attention(q, k, v, causal, scale, permute_NH) -> O, differentiable (the C++ autograd node of FlashAttentionFunction)");
+    m.def("workspace_pool_bytes", &workspace_pool_bytes, "bytes the per-stream scratch blocks of the split hold right now");
     m.def("backward", &backward, "backward(Q, K, V, O, dO, L, act_n, act_nkv, act_d, Br, Bc, causal, scale, permute_NH) -> [dQ, dK, dV]");
 }

@@ -231,7 +231,11 @@ def _workspace(need, device, dev, stream):
 
 def workspace_pool_bytes():
     """Bytes the per-stream scratch blocks of this process hold right now (tools/scan_bench.py reports it beside the peak)."""
-    return sum(t.numel() for t in _WS_POOL.values())
+    n = sum(t.numel() for t in _WS_POOL.values())
+    fe = _frontend()
+    if fe is not None and hasattr(fe, "workspace_pool_bytes"):      # the compiled front end keeps its own blocks
+        n += int(fe.workspace_pool_bytes())
+    return n
 
 
 _POOL_ON = os.environ.get("FA2_WS_POOL", "1") != "0"

@@ -229,20 +229,21 @@ def test_emulator_flags_a_missing_wait():
     prog = gen.Gen(False, opt=harness.OPT).build()
     idx = [i for i, ins in enumerate(prog.ins) if ins.op == "s_waitcnt" and ins.mods == {"lgkmcnt": 0}]
     assert idx
-    saved = harness._PROGS.get(False)
+    key = (False, harness.HD, harness.M16)            # (the harness's program cache: dtype, head dim, MFMA tile)
+    saved = harness._PROGS.get(key)
     try:
         for i in idx[:-1]:
             prog.ins[i].mods = {"lgkmcnt": 15}
-        harness._PROGS[False] = prog
+        harness._PROGS[key] = prog
         _, _, m = harness.check(256, 256, 0, False, verbose=False)
         assert any("in flight" in e for e in m.errors)
     except Exception as e:      # the emulator may also abort on the error flood
         assert "in flight" in str(e)
     finally:
         if saved is not None:
-            harness._PROGS[False] = saved
+            harness._PROGS[key] = saved
         else:
-            harness._PROGS.pop(False, None)
+            harness._PROGS.pop(key, None)
 
 
 @pytest.mark.parametrize("opt", [(), ("ct",)])

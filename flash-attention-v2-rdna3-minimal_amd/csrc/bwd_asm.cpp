@@ -17,11 +17,19 @@ int launch_dkv(const fa2::BwdParams& p, hipStream_t stream) {
 }
 
 template <bool BF16, bool CAUSAL>
-int launch_t(fa2::BwdParams p, int parts, bool neg_delta, bool kfold, hipStream_t stream) {
+int launch_t(fa2::BwdParams p, int parts, bool neg_delta, bool kfold, bool dq16, hipStream_t stream) {
     if (parts & 1) {        // dQ (+ delta): one workgroup per 256 Q rows
         p.nblk = (p.Nq + 255) / 256;
         const dim3 grid((unsigned)((int64_t)p.B * p.H * p.nblk));
-        if (neg_delta) {
+        if (dq16 && neg_delta) {        // the body built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dq_m16_gen.py)
+            constexpr auto kern = fa2::bwd_dq_d128_kernel<BF16, CAUSAL, true, true>;
+            if (int rc = fa2::set_lds<kern>(fa2::kBwdDqLdsBytes)) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(256), fa2::kBwdDqLdsBytes, stream, p);
+        } else if (dq16) {
+            constexpr auto kern = fa2::bwd_dq_d128_kernel<BF16, CAUSAL, false, true>;
+            if (int rc = fa2::set_lds<kern>(fa2::kBwdDqLdsBytes)) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(256), fa2::kBwdDqLdsBytes, stream, p);
+        } else if (neg_delta) {
             constexpr auto kern = fa2::bwd_dq_d128_kernel<BF16, CAUSAL, true>;
             if (int rc = fa2::set_lds<kern>(fa2::kBwdDqLdsBytes)) return rc;
             hipLaunchKernelGGL(kern, grid, dim3(256), fa2::kBwdDqLdsBytes, stream, p);
@@ -44,9 +52,9 @@ int launch_t(fa2::BwdParams p, int parts, bool neg_delta, bool kfold, hipStream_
 
 namespace fa2 {
 
-int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream) {
-    if (bf16) return causal ? launch_t<true, true>(p, parts, neg_delta, kfold, stream) : launch_t<true, false>(p, parts, neg_delta, kfold, stream);
-    return causal ? launch_t<false, true>(p, parts, neg_delta, kfold, stream) : launch_t<false, false>(p, parts, neg_delta, kfold, stream);
+int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream, bool dq16) {
+    if (bf16) return causal ? launch_t<true, true>(p, parts, neg_delta, kfold, dq16, stream) : launch_t<true, false>(p, parts, neg_delta, kfold, dq16, stream);
+    return causal ? launch_t<false, true>(p, parts, neg_delta, kfold, dq16, stream) : launch_t<false, false>(p, parts, neg_delta, kfold, dq16, stream);
 }
 
 }  // namespace fa2

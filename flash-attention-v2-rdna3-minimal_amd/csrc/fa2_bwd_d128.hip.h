@@ -35,7 +35,10 @@ __device__ __forceinline__ uint32_t bwd_swz(uint32_t r) { return ((r & 3u) << 2)
 // dQ pass: workgroup = 256 Q rows (4 waves x 64), sweep over KV tiles of 32.  Also writes delta = rowsum(dO * O).
 // Requires D == 128 (host.cpp dispatch); any Nq, Nkv (clamped rows, masked tail tiles), causal or not.
 // NEG_DELTA: the delta workspace receives -delta (what the hand-scheduled dK/dV pass takes as the C operand of its dP product).
-template <bool BF16, bool CAUSAL, bool NEG_DELTA>
+// M16 (round 5): the body built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dq_m16_gen.py): same pipeline, images and operand list; a lane is (n = lane % 16,
+// g = lane / 16) there and a Q row is spread over four lanes, so operands 2..9 carry the lane's row of q group 0, 16 g, Nq - 1 and the three row pitches
+// instead of eight clamped row offsets, the fragment / epilogue addresses and the mask limits differ, and delta leaves in one register (lane l = row l).
+template <bool BF16, bool CAUSAL, bool NEG_DELTA, bool M16 = false>
 __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -81,6 +84,16 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
         const int lim_c = CAUSAL ? qrow : 0x3fffffff;
         lim[qb] = (lim_c < p.Nkv - 1 ? lim_c : p.Nkv - 1) - kBwdTile * (ntw - 1) - 4 * hi;
     }
+    const int n16 = lane & 15, g4 = lane >> 4;
+    if constexpr (M16) {
+        qo[0] = (uint32_t)(qw0 + n16);  qo[1] = 16u * g4;              // ROW0, 16 g
+        go[0] = (uint32_t)(p.Nq - 1);   go[1] = q_rowb;                // Nq - 1, Q pitch
+        oo[0] = g_rowb;                 oo[1] = o_rowb;                // dO pitch, O pitch
+        lo[0] = lo[1] = 0;
+        // row 16 qg + n keeps kv_local = 16 kg + 4 g + i of the wave's LAST tile (the one before: + 32) iff 16 kg + i <= min(lim[0] + 16 qg, lim[1])
+        lim[0] = (CAUSAL ? qw0 + n16 : 0x3fff0000) - kBwdTile * (ntw - 1) - 4 * g4;
+        lim[1] = p.Nkv - 1 - kBwdTile * (ntw - 1) - 4 * g4;
+    }
     // LDS-DMA: piece i of this wave fills image bytes [wave*2048 + i*1024, +1024): lane l supplies the source of image slot
     // (row = 8*wave + 4*i + l/16, slot = l%16); the asm block derives piece 1 from piece 0
     const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
@@ -93,11 +106,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
     const uint32_t kd0 = drow * k_rowb + ((dslot ^ (drow & 15u)) << 4);                                   // row images: granule ^ (row & 15)
     const uint32_t vd0 = drow * v_rowb + ((dslot ^ (drow & 15u)) << 4);
     const uint32_t td0 = drow * k_rowb + (((((dslot >> 2) ^ (drow & 3u)) << 2) | (dslot & 3u)) << 4);     // "tr" image: 64-B chunk ^ (row & 3)
-    const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ ((uint32_t)l31 & 15u)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1;
-    const uint32_t vr0 = (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
+    const uint32_t trow16 = 4u * g4 + (n16 >> 2);
+    const uint32_t kr0 = M16 ? (uint32_t)n16 * 256u + (((uint32_t)g4 ^ (uint32_t)n16) << 4) : (uint32_t)l31 * 256u + (((uint32_t)hi ^ ((uint32_t)l31 & 15u)) << 4);
+    const uint32_t vr0 = M16 ? trow16 * 256u + ((trow16 & 3u) << 6) + 8u * (n16 & 3) : (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
 #endif
-    const uint32_t epi = kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
+    const uint32_t epi = M16 ? kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + n16 * kBwdEpiRowB + g4 * 8
+                             : kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
 
     const uint64_t qbase = (uint64_t)((const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1]);
     const uint64_t gbase = (uint64_t)((const uint16_t*)p.dout + b * p.dos[0] + h * p.dos[1]);
@@ -118,7 +133,19 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
       "v"(td0), "v"(kr0), "v"(vr0), "v"(lim[0]), "v"(lim[1]), "v"(epi), "s"(qbase), "s"(gbase), "s"(obase), "s"(lbase), "s"(krs), "s"(vrs), \
       "s"(c), "s"(scale), "s"(ntw), "s"(ntwg), "s"(k_tile), "s"(v_tile), "s"(k_row4), "s"(v_row4), "s"(ldsw), "s"(dsign)         \
     :
-    if constexpr (BF16) {
+    if constexpr (M16 && BF16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dq_m16_bf16.inc)
+            FA2_BWD_DQ_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dq_d128_clobbers.inc)
+        );
+    } else if constexpr (M16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dq_m16_f16.inc)
+            FA2_BWD_DQ_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dq_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16) {
         asm volatile(
 #include FA2_BWD_INC(fa2_bwd_dq_d128_bf16.inc)
             FA2_BWD_DQ_OPERANDS
@@ -134,7 +161,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
 #undef FA2_BWD_DQ_OPERANDS
 
     // ---- delta out; the wave's 64 x 128 dQ tile is in its LDS image: whole-row stores (4 rows of 256 B per instruction)
-    if (hi == 0) {
+    if constexpr (M16) {
+        float* dp = p.delta + b * p.ls[0] + h * p.ls[1];
+        if (qw0 + lane < p.Nq) dp[qw0 + lane] = d0;                    // one register: lane l hands over row l of the wave
+    } else if (hi == 0) {
         float* dp = p.delta + b * p.ls[0] + h * p.ls[1];
         if (qw0 + l31 < p.Nq) dp[qw0 + l31] = d0;
         if (qw0 + 32 + l31 < p.Nq) dp[qw0 + 32 + l31] = d1;

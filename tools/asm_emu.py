@@ -575,6 +575,10 @@ class Machine:
                 ny[h0:h0 + 16] = x[h0 + 16:h0 + 32]
             self.wr32(w, d, nx)
             self.wr32(w, s_, ny)
+        elif op == "v_min_u32":
+            self.wr32(w, ops[0], np.minimum(self.rd32(w, ops[1]), self.rd32(w, ops[2])))
+        elif op == "v_mul_lo_u32":
+            self.wr32(w, ops[0], (self.rd32(w, ops[1]).astype(np.uint64) * self.rd32(w, ops[2]).astype(np.uint64) & np.uint64(0xffffffff)).astype(np.uint32))
         elif op == "v_min_i32":
             self.wr32(w, ops[0], np.minimum(self.rd32(w, ops[1]).view(np.int32), self.rd32(w, ops[2]).view(np.int32)).view(np.uint32))
         elif op == "ds_write_b64":

@@ -17,11 +17,18 @@ LOG2E = 1.4426950408889634
 DQ = gen.DQ
 _PROGS = {}
 QSPLIT = False          # mirror of the shell's -DFA2_BWD_QSPLIT (programs built with opt "qsplit")
+DQ_M16 = False          # the dQ pass built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dq_m16_gen.py) instead of GenDQ
 
 
 def program(kind, bf16):
+    if kind == "dq" and DQ_M16:
+        kind = "dq16"
     if (kind, bf16) not in _PROGS:
-        _PROGS[(kind, bf16)] = (gen.GenDQ if kind == "dq" else gen.GenDKV)(bf16).build()
+        if kind == "dq16":
+            import bwd_dq_m16_gen
+            _PROGS[(kind, bf16)] = bwd_dq_m16_gen.GenDQ16(bf16).build()
+        else:
+            _PROGS[(kind, bf16)] = (gen.GenDQ if kind == "dq" else gen.GenDKV)(bf16).build()
     return _PROGS[(kind, bf16)]
 
 
@@ -100,6 +107,22 @@ def dq_wave_args(w, qblk, Nq, Nkv, causal, scale, bases):
     v[13] = (l31 * 256 + ((hi ^ (l31 & 15)) << 4)).astype(np.uint32)
     v[14] = ((4 * hi + (pp >> 2)) * 256 + ((pp >> 2) << 6) + 32 * g1 + 8 * (pp & 3)).astype(np.uint32)
     v[17] = (DQ.EPI_BASE + w * 64 * DQ.EPI_ROWB + l31 * DQ.EPI_ROWB + hi * 16).astype(np.uint32)
+    if DQ_M16:
+        # lane = (n = lane % 16, g4 = lane / 16): operands 2..9 carry ROW0, 16 g4, Nq - 1 and the row pitches of Q / dO / O (bwd_dq_m16_gen.py)
+        n16, g4 = lane & 15, lane >> 4
+        v[2] = (qw0 + n16).astype(np.uint32)
+        v[3] = (16 * g4).astype(np.uint32)
+        v[4] = np.full(64, Nq - 1, dtype=np.uint32)
+        v[5] = v[6] = v[7] = np.full(64, rb, dtype=np.uint32)
+        v[8] = v[9] = 0
+        v[13] = (n16 * 256 + ((g4 ^ n16) << 4)).astype(np.uint32)
+        trow = 4 * g4 + (n16 >> 2)
+        v[14] = (trow * 256 + ((trow & 3) << 6) + 8 * (n16 & 3)).astype(np.uint32)
+        l0 = ((qw0 + n16) if causal else np.full(64, 0x3fff0000)) - 32 * (ntw - 1) - 4 * g4
+        cap = np.full(64, Nkv - 1) - 32 * (ntw - 1) - 4 * g4
+        v[15] = l0.astype(np.int32).view(np.uint32)
+        v[16] = cap.astype(np.int32).view(np.uint32)
+        v[17] = (DQ.EPI_BASE + w * 64 * DQ.EPI_ROWB + n16 * DQ.EPI_ROWB + g4 * 8).astype(np.uint32)
     args = {n: Reg("v", n) for n in range(DQ.N_VARGS)}
     args[18], args[19], args[20], args[21] = _pair(bases["q"]), _pair(bases["do"]), _pair(bases["o"]), _pair(bases["lse"])
     args[22], args[23] = _srd(bases["k"], Nkv), _srd(bases["v"], Nkv)
@@ -131,6 +154,9 @@ def run_dq(q, k, v, do, qblk, causal, scale=None, bf16=False, check_hazards=True
     dq = from_bits(img, bf16)[:rows]
     delta = np.empty(256, dtype=np.float32)
     for w in range(4):
+        if DQ_M16:          # one output register: lane l hands over row l of the wave
+            delta[64 * w:64 * w + 64] = m.waves[w].v[0].view(np.float32)
+            continue
         for qb in range(2):
             delta[64 * w + 32 * qb:64 * w + 32 * qb + 32] = m.waves[w].v[qb][:32].view(np.float32)
     r0 = qblk * 256

@@ -20,13 +20,16 @@ import sys
 HERE = os.path.dirname(os.path.realpath(__file__))
 
 FILL = {"exp": 64, "add": 64, "cvt": 32, "kread": 16, "vread": 32}
+# the dQ pass of the hand-scheduled backward (csrc/gen/bwd_d128_gen.py): per body 48 MFMAs of 32x32x16 (dQ 16, then S and dP 32) and, per wave, 144 plain
+# VALU instructions (fma, sub, mul, pack), 32 exp, 16 row-fragment + 16 transposed reads: would the other MFMA tile pay there too?
+FILL_BWD = {"exp": 32, "add": 144, "cvt": 0, "kread": 16, "vread": 16}
 
 
-def fillers(nofill=()):
+def fillers(nofill=(), fill=None):
     """The body's single-issue work as a list of instruction strings, interleaved the way the generator's water-filling leaves them: evenly."""
     out = []
     streams = []
-    for kind, n in FILL.items():
+    for kind, n in (fill or FILL).items():
         if kind in nofill:
             continue
         lst = []
@@ -51,13 +54,13 @@ def fillers(nofill=()):
     return [ins for _, ins in pos], total
 
 
-def body(shape, nofill=()):
-    """One tile body: MFMAs with the fillers spread evenly over the gaps."""
-    fl, _ = fillers(nofill)
+def body(shape, nofill=(), fill=None, pv_steps=None):
+    """One tile body: MFMAs with the fillers spread evenly over the gaps.  pv_steps: k-steps of the P.V-like product (default: the forward's)."""
+    fl, _ = fillers(nofill, fill)
     mf = []
     if shape == 32:
         # P.V-like: 8 accumulators x 4 k-steps (a[64:191]); Q.K^T-like: 4 accumulators x 8 k-steps, the first from C = 0 (a[0:63])
-        for ks in range(4):
+        for ks in range(4 if pv_steps is None else pv_steps):
             for acc in range(8):
                 a0 = 64 + 16 * acc
                 mf.append("v_mfma_f32_32x32x16_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 15, 16 + 4 * ((acc + ks) % 8), 19 + 4 * ((acc + ks) % 8),
@@ -70,7 +73,7 @@ def body(shape, nofill=()):
                                                                                   48 + 4 * ((ks + 2 * acc) % 8), 51 + 4 * ((ks + 2 * acc) % 8), c))
     else:
         # the same products as 16x16x32 tiles: P.V-like: 32 accumulators (4 registers) x 2 k-steps; Q.K^T-like: 16 accumulators x 4 k-steps
-        for ks in range(2):
+        for ks in range(2 if pv_steps is None else max(1, pv_steps // 2)):
             for acc in range(32):
                 a0 = 64 + 4 * acc
                 mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
@@ -94,7 +97,7 @@ def body(shape, nofill=()):
     return lines
 
 
-def kernel(name, shape, nofill=()):
+def kernel(name, shape, nofill=(), fill=None, pv_steps=None):
     # operands: %0 = result (out), %1 = iters (s), %2 = operand pointer (s, 64 bit), %3 / %4 = LDS read addresses (v), %5 = this thread's byte offset (v)
     lines = ["s_mov_b32 s60, %1", "v_mov_b32 v250, %5"]
     for i in range(16):          # 8 A + 8 B operand quads: U[0,1) fp16 data
@@ -108,7 +111,7 @@ def kernel(name, shape, nofill=()):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
     lines.append("s_waitcnt vmcnt(0)")
     lines.append(".Lprobe_%s_%%=:" % name)
-    lines += body(shape, nofill)
+    lines += body(shape, nofill, fill, pv_steps)
     lines += ["s_sub_u32 s60, s60, 1", "s_cmp_gt_i32 s60, 0", "s_cbranch_scc1 .Lprobe_%s_%%=" % name]
     lines.append("s_nop 7")
     lines.append("v_accvgpr_read_b32 %0, a64")     # keep something observable
@@ -189,9 +192,12 @@ int main() {
 
 
 def main():
-    variants = [("body_32x32x16", 32, ()), ("body_16x16x32", 16, ()), ("mfma_only_32x32x16", 32, tuple(FILL)), ("mfma_only_16x16x32", 16, tuple(FILL)),
-                ("no_lds_32x32x16", 32, ("kread", "vread")), ("no_lds_16x16x32", 16, ("kread", "vread"))]
-    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf) for n, s, nf in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (n, n) for n, _, _ in variants))
+    variants = [("body_32x32x16", 32, (), None, None), ("body_16x16x32", 16, (), None, None), ("mfma_only_32x32x16", 32, tuple(FILL), None, None),
+                ("mfma_only_16x16x32", 16, tuple(FILL), None, None), ("no_lds_32x32x16", 32, ("kread", "vread"), None, None),
+                ("no_lds_16x16x32", 16, ("kread", "vread"), None, None),
+                # a dQ-pass-like body: 48 (96) MFMAs, the backward's filler mix (its FLOPs are 0.75 of the forward body's: the TF printed for it are 4/3 too high)
+                ("bwd_dq_like_32x32x16", 32, (), FILL_BWD, 2), ("bwd_dq_like_16x16x32", 16, (), FILL_BWD, 2)]
+    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv) for n, s, nf, fl, pv in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
     path = os.path.join(HERE, "mfma_shape_probe.hip")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/ubench/mfma_shape_probe.py — do not edit.\n" + src)

@@ -105,6 +105,16 @@ FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t s
 // fold: the body that folds scale * log2(e) into Q (FA2_CONTRACT_PRESCALE_Q) instead of scaling the f32 product
 // m16: the body built on v_mfma_f32_16x16x32 (head dim 128, f32 scale, whole items only; csrc/gen/fwd_m16_gen.py) where it applies
 FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16 = false);
+// Does launch_fwd_asm(..., m16) run a body built on v_mfma_f32_16x16x32 (csrc/gen/fwd_m16_gen.py)?  ONE predicate: the launcher executes it, the plan
+// reports its contract (the folded 16 x 16 bodies add the ROUNDED P into the row sums: FA2_CONTRACT_LSUM_P16).  fwd_asm.cpp has the measurements.
+inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
+#ifdef FA2_M16_BF16        // (developer A/B: the f32-scale 16 x 16 body for bf16 launches too)
+    const bool nf16 = true;
+#else
+    const bool nf16 = !bf16;
+#endif
+    return m16 && HD == 128 && (fold ? p.vs[2] % 32 == 0 : nf16);
+}
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
 // dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).
 // Tile costs (us per 64-row tile of a 256-row workgroup, 8-wave HIP kernels): dQ pass 3 GEMMs, fused dK / dV pass 4 — 1.5x / 2x the forward's 0.9 * HD / 64.

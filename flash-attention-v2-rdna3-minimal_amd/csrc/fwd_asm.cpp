@@ -59,12 +59,9 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
     // 32-byte halves of those rows flipped): the same as re-deriving the granule only when a row's byte offset has that bit clear — V's row pitch must
     // be a multiple of 64 bytes (contiguous BHND / BNHD tensors are; a row-padded V is not and keeps the 32 x 32 body: found by tools/fuzz_parity.py,
     // profiles/fuzz_runs.md row r17_fuzz_rows256_seed503).
-#ifdef FA2_M16_BF16        // (developer A/B: the f32-scale 16 x 16 body for bf16 launches too)
-    const bool nf16 = true;
-#else
-    const bool nf16 = !bf16;
-#endif
-    if (m16 && HD == 128 && (fold ? p.vs[2] % 32 == 0 : nf16)) {
+    // Round 5, later: the folded 16 x 16 bodies keep their row sums on the matrix pipe (gen opt=lm: 8 MFMAs for 64 v_add_f32 per tile, and fast bodies
+    // that are exp + pack only): another -4.0 .. 4.7 % (profiles/r18_kbench_lm_windows.txt); contract FA2_CONTRACT_LSUM_P16 (plan_range, host.cpp).
+    if (fwd_asm_is_m16(HD, bf16, p, fold, m16)) {
         if (fold) {
             if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
             return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);

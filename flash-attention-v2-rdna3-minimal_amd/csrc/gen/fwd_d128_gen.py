@@ -276,6 +276,7 @@ class Gen:
         self.lmfma = "lmfma" in self.opt
         # "sum check" fast bodies (default at head dim 128; opt=maxfirst keeps the row-max stream everywhere): see stream_exp_sum
         self.sumchk = not self.lmfma and "maxfirst" not in self.opt
+        self.lm = False                   # (fwd_m16_gen.py, opt=lm: row sums on the matrix pipe AND fast bodies without a row-max stream)
         self.lacc = lambda qb: A(g.LA0 + 16 * qb, 16)
         self.npv = 8 * g.NDT + (8 if self.lmfma else 0)   # MFMAs of the PV phase (both q blocks) ...
         self.nqk = 4 * g.NKS              # ... and of the QK phase
@@ -856,7 +857,7 @@ class Gen:
         # whole sweep of an item that is redone in safe mode
         sumchk = self.sumchk and fast and s1 and not masked and not first and not abl
         self.pending_rare_sum = []
-        if s1 and self.sumchk and self.ct and not first:
+        if s1 and self.sumchk and self.ct and not first and not self.lm:
             # scores formed against a reference that moved after their first k-step was issued (rare_sum, `fix`) get their shift before anything reads them
             lab = p.fresh("rare_f")
             p.emit("s_cmp_lg_u32", S_FIX, 0)

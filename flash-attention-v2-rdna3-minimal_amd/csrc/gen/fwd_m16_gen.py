@@ -82,6 +82,13 @@ def VF_CT(dg, kvs):
 
 
 VRO = [V(196 + i) for i in range(4)]               # "ct": read addresses of the ODD d groups (see stream_vread)
+# "lm" (with "ct"): the row sums ride the matrix pipe.  One more MFMA per (q group, P.V k-step): A = a constant tuple that holds 0.25 in the rows m with
+# m % 4 == qg and 0 elsewhere, B = the packed P the P.V product consumes, C = D = LSV — so register qg of LSV gains a quarter of the row sum of row
+# 16 qg + n on each of the row's four lanes: the very registers, and the very meaning (a lane's share; the epilogue adds the four lanes up), of the
+# partial sums the v_add chains keep.  The constants take the registers the repair blocks of the sum check no longer need.
+ONES16 = [V(192, 4), V(200, 4), V(204, 4), V(248, 4)]
+LSV = V(228, 4)                                    # = LS[h][qb] at index 2 qb + h
+LM_MAX = float(2.0 ** 40)                          # a lane's share of a row sum at or above this (or NaN): redo the item in safe mode (see Gen16.__init__)
 CT16 = [V(176 + 4 * qg, 4) for qg in range(4)]     # -(reference) of this lane's row of q group qg, four copies (the C operand of a 16 x 16 tile)
 DSH16 = [[V(192), V(193)], [V(194), V(195)]]       # [h][qb]: pending shift of the NEXT tile's scores of row h of q block qb (see rare_fix)
 
@@ -105,8 +112,46 @@ class Gen16(base.Gen):
         self.kf16 = KF_POOL if self.ct else KF
         self.vf16 = VF_CT if self.ct else VF
         self.mfma = "v_mfma_f32_16x16x32_bf16" if bf16 else "v_mfma_f32_16x16x32_f16"
-        self.npv, self.nqk = 64, 64
-        self.ng = 128
+        # opt=lm: row sums on the matrix pipe (ONES16 above), in EVERY body, and fast bodies that are exp + pack and nothing else: no adds, no check, no
+        # repair blocks.  What the sum check guarded against — a P beyond the 16-bit type's range, an accumulator beyond f32's — is caught later and
+        # coarser: an fp16 P above 65504 packs to inf and the row sum it enters stays inf; a lane's share is compared with 2^40 wherever it is about to be
+        # scaled down (rare_rescale) and in the epilogue, and a share that fails sends the ITEM through the safe-mode redo (max-first bodies only) the sum
+        # check uses for growth beyond 120 octaves.  Below the threshold every P is below 2^42 and every accumulator finite (2^42 * |V| * Nkv).  The
+        # price is the in-place repair: a row whose scores outgrow the reference of its first tiles by 16 octaves (fp16) costs its item a second sweep.
+        # Contract: FA2_CONTRACT_LSUM_P16 — l adds the ROUNDED P (what P.V consumes; the weights O applies then sum to exactly one).
+        # Measured: tools/ubench/mfma_shape_probe.py (profiles/r18_mfma_sum_probe.json): 64 v_add_f32 out, 8 MFMAs in: -3.9 % on the synthetic body;
+        # the kernel (tools/kbench.py, one box, profiles/r18_kbench_lm_*.txt): c2 196.6 -> 188.6 us, B8 788.8 -> 751.5, c4 387.9 -> 372.4 (-4.0 .. 4.7 %).
+        # Windows (same files): the exp + pack streams anywhere (no check to stay ahead of, no packs to hold back), the V^T reads spread over 74 .. 110;
+        # every variant within 0.5 % of the best — the optimum is flat.
+        self.lm = "lm" in self.opt
+        assert self.ct or not self.lm, "opt=lm needs the folded scale (opt=ct): its constants live in the registers of the ct repair blocks"
+        self.npv, self.nqk = (72 if self.lm else 64), 64
+        self.ng = self.npv + self.nqk
+        if self.lm:
+            for k, w in {"e": (20.0, 136.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 136.0), "kread_ct": (16.0, 72.0)}.items():
+                if k not in user:
+                    self.cfg[k] = w
+            for k, w in user.items():         # "lm_<key>": a schedule tunable of the lm bodies only (window sweeps, tools/kbench.py)
+                if k.startswith("lm_"):
+                    self.cfg[k[3:]] = w
+
+    def body(self, par, *args, **kw):
+        start = len(self.p.ins)
+        super().body(par, *args, **kw)
+        # legality of the V^T read window (an input: tools/kbench.py sweeps it): the fragments read in this body are P.V(t+1)'s — a read ahead of the last
+        # P.V(t) MFMA that takes its registers would hand that MFMA the next tile's data
+        ins = [x for x in self.p.ins[start:] if x.op != "label"]
+        last = {}
+        for i, x in enumerate(ins):
+            if x.op.startswith("v_mfma"):
+                for (kind, lo, hi) in base.Gen._regs(x)[0]:
+                    for r in range(lo, hi):
+                        last[(kind, r)] = i
+        for i, x in enumerate(ins):
+            if x.op == "ds_read_b64_tr_b16":
+                for (kind, lo, hi) in base.Gen._regs(x)[1]:
+                    if any(last.get((kind, r), -1) > i for r in range(lo, hi)):
+                        raise ValueError("illegal schedule: a V^T fragment read (%s) ahead of a P.V MFMA of this body that reads its registers" % x)
 
     # ------------------------------------------------------------------ MFMA lists
     def pv_mfmas(self, par, qb):
@@ -117,6 +162,9 @@ class Gen16(base.Gen):
                 for h in range(2):
                     acc = OACC(dg, 2 * qb + h)
                     out.append(mk(self.mfma, acc, self.vf16(dg, kvs), b.sub(16 * h + 8 * kvs, 4), acc, tag="mfma"))
+                if self.lm and dg in (3, 7):      # the row sums of q group 2 qb + h, this k-step (eight P.V MFMAs between two links of the LSV chain)
+                    h = dg >> 2
+                    out.append(mk(self.mfma, LSV, ONES16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), LSV, tag="mfma"))
         return out
 
     def qk_mfmas(self, par):
@@ -150,12 +198,13 @@ class Gen16(base.Gen):
             if 0 <= k - 1 < 16:
                 e = prs[k - 1]
                 E += [mk("v_exp_f32", b[e], b[e], tag="trans"), mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans")]
-            if 0 <= k - 2 < 16:
+            if 0 <= k - 2 < 16 and not self.lm:
                 e = prs[k - 2]
                 Ad.append(mk("v_add_f32", LS[e // 16][qb], LS[e // 16][qb], b[e], tag="valu"))
             if 0 <= k - 3 < 16:
                 e = prs[k - 3]
-                Ad.append(mk("v_add_f32", LS[e // 16][qb], LS[e // 16][qb], b[e + 1], tag="valu"))
+                if not self.lm:
+                    Ad.append(mk("v_add_f32", LS[e // 16][qb], LS[e // 16][qb], b[e + 1], tag="valu"))
                 C.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
             out += F + E + Ad + C
         return out
@@ -164,6 +213,18 @@ class Gen16(base.Gen):
         """fast bodies (no row-max stream; base.Gen.stream_exp_sum has the argument): P against the current references of the lane's two rows, the
         tile's sums per row (ta: h = 0, tb: h = 1) started afresh, added to the running sums, and ONE check: ta + tb bounds each of this lane's 32 P."""
         b = SB(qb, par)
+        if self.lm:
+            # exp and pack, nothing else (the row sums: pv_mfmas of the NEXT body; what replaces the check: __init__)
+            prs = self._order()
+            out = []
+            for k in range(16 + 2):
+                if k < 16:
+                    e = prs[k]
+                    out += [mk("v_exp_f32", b[e], b[e], tag="trans"), mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans")]
+                if 0 <= k - 2 < 16:
+                    e = prs[k - 2]
+                    out.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
+            return out
         ta, tb, ts = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2]
         tsum = [ta, tb]
         prs = self._order()
@@ -216,6 +277,23 @@ class Gen16(base.Gen):
         return out
 
     # stream_pack: the base generator's (the packed P of k-step kvs of row h lands in registers 16 h + 8 kvs .. + 3 by the same formula)
+    def stream_pack(self, qb, par):
+        return [] if self.lm else super().stream_pack(qb, par)          # (lm: packed by stream_exp_sum, a pair behind its exps)
+
+    def lm_fail_check(self, r, x, t, t2):
+        """appends to r: a lane's share x of a row sum at or above LM_MAX, or NaN -> the wave raises its flag word (the shell redoes the item in safe mode)"""
+        ok = self.p.fresh("lm_ok")
+        r.append(mk("v_cmp_ngt_f32", VCC, LM_MAX, x))
+        r.append(mk("s_cbranch_vccz", Label(ok)))
+        r.append(mk("v_mov_b32", t, S_WAVE))
+        r.append(mk("v_mov_b32", t2, 1))
+        r.append(mk("v_lshlrev_b32", t, 2, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("v_add_u32", t, self.g.FAIL_OFF, t))
+        r.append(mk("s_nop", 0))
+        r.append(mk("ds_write_b32", t, t2))
+        r.append(mk("s_waitcnt", lgkmcnt=0))
+        r.append(Ins("label", (Label(ok),)))
 
     def _row_reduce_max(self, r, x, t):
         """x = max of x over the four lanes of a row (l % 16 equal): exchange with the lane 16 away, then 32 away (t: scratch)"""
@@ -366,7 +444,8 @@ class Gen16(base.Gen):
                     r.append(mk("v_mov_b32", CT16[2 * qb + h][i], t))
                 r.append(mk("v_exp_f32", t2, Neg(t2)))                        # factor for everything accumulated at the old reference
                 r.append(mk("s_nop", 1))
-                r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
+                if not self.lm:     # (lm: the sum MFMAs of the tile before — old reference — are not all issued yet: LS is rescaled with O, rare_rescale)
+                    r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
                 r.append(mk("v_mov_b32", FS[h][qb], t2))
             if not first:
                 r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
@@ -442,17 +521,22 @@ class Gen16(base.Gen):
             skip = self.p.fresh("rr_skip")
             r.append(mk("s_bitcmp1_b32", S_FLAG, qb))
             r.append(mk("s_cbranch_scc0", Label(skip)))
+            scr = TMP[:4] if self.lm else EPX      # (lm: v[248:251] hold a constant tuple; the row-max chains in TMP end ahead of the phase boundary)
             for h in range(2):
+                if self.lm:
+                    # the row sums, with the sum MFMAs of every tile at the old reference landed (s_nop above): checked at full size, then scaled
+                    self.lm_fail_check(r, LS[h][qb], TMP[4], TMP[5])
+                    r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], FS[h][qb]))
                 for dg in range(8):
                     acc = OACC(dg, 2 * qb + h)
                     for j in range(4):
-                        r.append(mk("v_accvgpr_read_b32", EPX[j], acc[j]))
+                        r.append(mk("v_accvgpr_read_b32", scr[j], acc[j]))
                     r.append(mk("s_nop", 1))
                     for j in range(4):
-                        r.append(mk("v_mul_f32", EPX[j], EPX[j], FS[h][qb]))
+                        r.append(mk("v_mul_f32", scr[j], scr[j], FS[h][qb]))
                     r.append(mk("s_nop", 1))
                     for j in range(4):
-                        r.append(mk("v_accvgpr_write_b32", acc[j], EPX[j]))
+                        r.append(mk("v_accvgpr_write_b32", acc[j], scr[j]))
             r.append(Ins("label", (Label(skip),)))
         r.append(mk("s_mov_b32", S_FLAG, 0))
         r.append(mk("s_nop", 7))
@@ -505,6 +589,7 @@ class Gen16(base.Gen):
     def build(self):
         p = self.p
         g = self.g
+        bf16_ = self.bf16
         tr = int(self.cfg["trace"][0])
         assert not tr, "the trace builds belong to the 32x32 generator"
         # ---- entry: addresses, the wave's Q through its LDS image, the first tiles
@@ -516,6 +601,16 @@ class Gen16(base.Gen):
         if self.ct:
             for j in range(4):
                 p.emit("v_xor_b32", VRO[j], (j << 6) | 32, A_VR0)      # the other 32-byte half
+        if self.lm:
+            # the constant A tuples of the row-sum MFMAs: 0.25 (two packed 16-bit values) on the lanes of rows m = lane % 16 with m % 4 == qg
+            p.emit("v_lshrrev_b32", TMP[0], 8, A_KR0)               # A_KR0 = n * 256 + ((g ^ n) << 4), n = lane % 16
+            p.emit("v_mov_b32", TMP[1], 0x3e803e80 if bf16_ else 0x34003400)
+            p.emit("v_and_b32", TMP[0], 3, TMP[0])
+            for qg in range(4):
+                p.emit("v_cmp_eq_u32", VCC, qg, TMP[0])
+                p.emit("v_cndmask_b32", ONES16[qg][0], 0, TMP[1], VCC)
+                for i in range(1, 4):
+                    p.emit("v_mov_b32", ONES16[qg][i], ONES16[qg][0])
         p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mul_i32", S_QSB, S_WAVE, 64 * g.EPI_ROWB)
         p.emit("s_add_u32", S_QSB, S_QSB, g.EPI_BASE)
@@ -691,10 +786,15 @@ class Gen16(base.Gen):
         p.label("epilogue")
         p.emit("s_nop", 15)
         lse = [TMP[4], TMP[5], TMP[6], TMP[7]]          # LSE of this lane's row of q group qg
+        epx = [FS[qg & 1][qg >> 1] for qg in range(4)] if self.lm else EPX      # (lm: v[248:251] hold a constant tuple; no O rescale is pending here)
         for qb in range(2):
             for h in range(2):
                 qg = 2 * qb + h
                 lt, t = TMP[0], TMP[1]
+                if self.lm:
+                    blk = []
+                    self.lm_fail_check(blk, LS[h][qb], TMP[2], TMP[3])
+                    p.ins.extend(blk)
                 p.emit("v_mov_b32", lt, LS[h][qb])
                 for op in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
                     p.emit("v_mov_b32", t, lt)
@@ -702,7 +802,7 @@ class Gen16(base.Gen):
                     p.emit(op, lt, t)
                     p.emit("v_add_f32", lt, lt, t)
                     p.emit("s_nop", 0)
-                p.emit("v_rcp_f32", EPX[qg], lt)
+                p.emit("v_rcp_f32", epx[qg], lt)
                 p.emit("v_log_f32", t, lt)
                 p.emit("s_nop", 0)
                 p.emit("v_add_f32", lse[qg], MC[h][qb], t)
@@ -716,7 +816,7 @@ class Gen16(base.Gen):
                     p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
                 p.emit("s_nop", 0)
                 for j in range(4):
-                    p.emit("v_mul_f32", TMP[j], TMP[j], EPX[qg])
+                    p.emit("v_mul_f32", TMP[j], TMP[j], epx[qg])
                 p.emit("s_nop", 0)
                 p.emit(self.cvt, TMP[0], TMP[0], TMP[1])
                 p.emit(self.cvt, TMP[1], TMP[2], TMP[3])
@@ -764,7 +864,7 @@ class Gen16(base.Gen):
                     p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
                 p.emit("v_add_u32", adr, 512 * qg + 8192 * (4 * (dg >> 1) + 2 * (dg & 1)), wso)
                 for j in range(4):
-                    p.emit("v_mul_f32", TMP[j], TMP[j], EPX[qg])
+                    p.emit("v_mul_f32", TMP[j], TMP[j], epx[qg])
                 p.emit("s_nop", 0)
                 p.emit("global_store_dwordx4", adr, V(TMP[0].idx, 4), A_WSB)
                 p.emit("s_nop", 3)             # (a store of more than 64 bits: its data registers must not be rewritten right behind it)
@@ -790,7 +890,10 @@ def main():
     for bf16 in (False, True):
         for fold in (False, True):
             c = dict(cfg)
-            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o != "ct") + (("ct",) if fold else ())
+            # the folded bodies ship with the row sums on the matrix pipe (opt=lm; opt=nolm builds them with the sum check of the f32-scale bodies)
+            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if fold else ())
+            if fold and "nolm" not in cfg.get("opt", ()):
+                c["opt"] += ("lm",)
             prog = Gen16(bf16, **c).build()
             path = os.path.join(a.out, "fa2_fwd_m16_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))
             base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))

@@ -271,9 +271,11 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
  *                                 reference maximum enters the first Q.K^T k-step as its C operand.  Removes the 64 v_fma per tile of bodies that run
  *                                 at their instruction-issue bound (+9 % at head dim 64, +1.4 ... +2.9 % at 128).  fp16: ~2e-4 of log2 LSE on
  *                                 U[0,1) / N(0,1) inputs, growing with the logits (~1e-2 in O at logits of several hundred); bf16: ~6e-3.
- *   FA2_CONTRACT_LSUM_P16         the row sums add the P values ROUNDED to the I/O dtype — the ones the P.V product consumes.  Version 0.8's head-dim-64
- *                                 body formed them on the matrix pipe; no kernel of version 0.9 does (its head-dim-64 body adds the f32 P like every
- *                                 other kernel: the bit stays defined for callers built against 0.8).
+ *   FA2_CONTRACT_LSUM_P16         the row sums add the P values ROUNDED to the I/O dtype — the ones the P.V product consumes, so the weights O applies
+ *                                 sum to exactly one; the LSE carries the rounding (fp16: <= 7e-4 of log2 LSE for a one-hot row, ~1e-4 on N(0,1)
+ *                                 inputs).  Version 0.8's head-dim-64 body formed them on the matrix pipe; since round 5 the head-dim-128 bodies that
+ *                                 fold the scale (option "fold", never a call flagged FA2_FLAG_EXACT_SCALE) built on v_mfma_f32_16x16x32 do: one MFMA
+ *                                 with a constant operand per (16 rows, 32 kv) instead of 64 v_add_f32 per tile, -4 % of a launch.
  * Kernels.
  *   FA2_KERNEL_HIP_256 / _128     compiler-scheduled HIP kernel, 8-wave 256-row / 4-wave 128-row workgroups (csrc/fa2_fwd_kernel.hip.h)
  *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py), head dims exactly 64 and 128

@@ -13,7 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "flash-attention-v2-rdna3-minimal_amd", "c
 import asm_emu_harness as harness  # noqa: E402
 
 
-@pytest.fixture(autouse=True, params=[(), ("ct",)], ids=["f32-scale", "folded-scale"])
+# ("ct", "lm"): the folded bodies as shipped — row sums on the matrix pipe, fast bodies without adds or a check (FA2_CONTRACT_LSUM_P16: the LSE carries
+# the rounding of P; what the check guarded against sends the item through the safe-mode redo); ("ct",): the folded bodies with the sum check (gen opt=nolm)
+@pytest.fixture(autouse=True, params=[(), ("ct",), ("ct", "lm")], ids=["f32-scale", "folded-scale", "folded-lm"])
 def m16(request):
     saved = harness.HD, harness.OPT, harness.M16
     harness.HD, harness.OPT, harness.M16 = 128, request.param, True
@@ -47,9 +49,10 @@ def test_m16_block_matches_dense_attention(case, m16):
     err, lerr, m = harness.check(Nq, Nkv, qblk, causal, bf16=bf16, seed=Nq + Nkv, spike=spike, verbose=False)
     assert not m.errors, m.errors[:5]
     tol = (8e-3 if bf16 else 1e-3) * (3 if spike else 1)
-    assert err <= tol and lerr <= 1e-4, (err, lerr)
-    if spike == 2:
-        assert m.redos == 0            # repaired in place
+    lm = "lm" in m16
+    assert err <= tol and lerr <= ((4e-3 if bf16 else 1e-3) if lm else 1e-4), (err, lerr)
+    if spike == 2 and not lm:
+        assert m.redos == 0            # repaired in place (lm: no repair — a P beyond the 16-bit range costs the item a second sweep)
     if spike in (True, 3):
         assert m.redos == 1
 
@@ -63,8 +66,12 @@ def test_m16_fast_bodies_carry_no_cross_lane_instruction():
     names = [i.ops[0].name if i.op == "label" else None for i in prog.ins]
     lo, hi = names.index("fast0"), names.index("dispatch")
     ops = [i.op for i in prog.ins[lo:hi]]
-    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 2 * 128
+    lm = "lm" in harness.OPT
+    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 2 * (136 if lm else 128)
     assert not any(o.startswith("v_permlane") or o.startswith("v_max") for o in ops)
+    if lm:      # exp + pack and nothing else: no add, no compare, no branch into a repair block
+        assert not any(o in ("v_add_f32", "v_cmp_nge_f32", "s_cbranch_vccnz") for o in ops)
+        assert sum(o == "v_exp_f32" for o in ops) == 2 * 64 and sum(o.startswith("v_cvt_pk") for o in ops) == 2 * 32
 
 
 SEAMS = [
@@ -92,7 +99,7 @@ def test_m16_persistent_workgroup_seams(seam):
         r0 = qb * 256
         o_ref, lse_ref = harness.dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre=bool(harness.OPT))
         assert np.abs(o - o_ref).max() <= (8e-3 if bf16 else 1.1e-3)
-        assert np.abs(lse - lse_ref).max() <= 1e-4
+        assert np.abs(lse - lse_ref).max() <= ((4e-3 if bf16 else 1e-3) if "lm" in harness.OPT else 1e-4)
 
 
 def test_m16_text_assembles_for_gfx950(tmp_path):
@@ -129,9 +136,18 @@ def test_m16_kv_split_part_epilogue():
         qq, kk, vv, qb = item[:4]
         o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre=pre)
         assert np.isfinite(o).all()
-        assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-4
+        assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in harness.OPT else 1e-4)
     (o1, l1), (o2, l2) = outs[1], outs[2]
     lse = np.logaddexp2(l1, l2)
     o = o1 * np.exp2(l1 - lse)[:, None] + o2 * np.exp2(l2 - lse)[:, None]
     o_ref, lse_ref = harness.dense(q[:256], k, v, False, pre=pre)
     assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-3
+
+
+def test_m16_generator_rejects_a_v_read_window_that_reaches_into_the_pv_phase():
+    """The V^T read window is an input (tools/kbench.py sweeps it): a read placed ahead of the last P.V MFMA of the body that takes its registers would hand
+    that MFMA the next tile's fragment.  The generator refuses such a schedule (Gen16.body) instead of leaving it to a wrong result on the GPU."""
+    import fwd_m16_gen
+    fwd_m16_gen.Gen16(False, opt=("ct", "lm"), lm_vread=(56.0, 110.0)).build()         # k-step 0's registers are free from gap 54 on
+    with pytest.raises(ValueError, match="illegal schedule"):
+        fwd_m16_gen.Gen16(False, opt=("ct", "lm"), lm_vread=(30.0, 60.0)).build()

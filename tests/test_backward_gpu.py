@@ -356,7 +356,7 @@ def test_differentiated_calls_scale_the_f32_product_on_large_logits(causal):
         plain = _fa2_lib.fwd_plan(q, k, causal)
         flagged = _fa2_lib.fwd_plan(q, k, (_fa2_lib.FA2_FLAG_CAUSAL if causal else 0) | _fa2_lib.FA2_FLAG_EXACT_SCALE)
         assert plain.kernel == flagged.kernel == _fa2_lib.FA2_KERNEL_ASM
-        assert plain.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q and flagged.contract == 0
+        assert plain.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16 and flagged.contract == 0
         qa, ka, va = (t.detach().requires_grad_(True) for t in (q, k, v))
         o = FlashAttentionFunction.apply(qa, ka, va, None, causal)
         o.backward(do)

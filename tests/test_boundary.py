@@ -214,11 +214,13 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     kernel (or the reverse) changes these answers.  The GPU parity tests compare against the oracle under exactly the contract named here."""
     import torch
     K, C = _fa2_lib, _fa2_lib
-    # BASELINE.json configs 2, 3, 4 and config 5's per-rank shard: the hand-scheduled body, one launch; fp16 folds the scale, bf16 does not
-    for shape, dt, causal, contract in (((2, 16, 4096, 4096, 128), torch.float16, False, C.FA2_CONTRACT_PRESCALE_Q),
+    # BASELINE.json configs 2, 3, 4 and config 5's per-rank shard: the hand-scheduled body, one launch; fp16 folds the scale (and, on the bodies built on
+    # v_mfma_f32_16x16x32, adds the rounded P into the row sums — on the matrix pipe), bf16 does not
+    FOLD128 = C.FA2_CONTRACT_PRESCALE_Q | C.FA2_CONTRACT_LSUM_P16
+    for shape, dt, causal, contract in (((2, 16, 4096, 4096, 128), torch.float16, False, FOLD128),
                                         ((2, 16, 4096, 4096, 128), torch.bfloat16, True, 0),
-                                        ((1, 32, 8192, 8192, 128), torch.float16, True, C.FA2_CONTRACT_PRESCALE_Q),
-                                        ((8, 16, 4096, 4096, 128), torch.float16, False, C.FA2_CONTRACT_PRESCALE_Q)):
+                                        ((1, 32, 8192, 8192, 128), torch.float16, True, FOLD128),
+                                        ((8, 16, 4096, 4096, 128), torch.float16, False, FOLD128)):
         p = _meta_plan(*shape, dt=dt, causal=causal)
         assert (p.kernel, p.contract, p.rows, p.heads_main, p.kernel_tail, p.nsplit) == (K.FA2_KERNEL_ASM, contract, 256, shape[0] * shape[1], 0, 0), p.as_dict()
     # config 1 (B1 H2 N128 D64): a grid this small runs 128-row workgroups of the HIP kernel, f32 scale
@@ -275,12 +277,16 @@ def test_option_fold_switches_the_contract_and_nothing_else():
         p = _meta_plan(2, 16, 4096, 4096, 64)                  # head dim 64 fp16 without the fold: back on the 8-wave kernel (non-causal)
         assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_HIP_256, 0)
         assert lib.fa2_fwd_prescales_q(128, 0.1) == 0
+    fold128 = _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16
     with _fa2_lib.options(fold=2):
         p = _meta_plan(2, 16, 4096, 4096, 128, dt=torch.bfloat16, causal=True)
-        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, _fa2_lib.FA2_CONTRACT_PRESCALE_Q)
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, fold128)
     assert lib.fa2_get_option(b"fold") == 1 and lib.fa2_set_option(b"fold", 3) < 0
     p = _meta_plan(2, 16, 4096, 4096, 128)
-    assert p.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+    assert p.contract == fold128
+    # the rounded-P row sums belong to the folded bodies built on v_mfma_f32_16x16x32 (option "asm" bit 6); the 32x32x16 bodies add the f32 P
+    with _fa2_lib.options(asm=3):
+        assert _meta_plan(2, 16, 4096, 4096, 128).contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
 
 
 def test_plan_struct_in_the_header_matches_the_ctypes_structure():

@@ -54,9 +54,34 @@ def fillers(nofill=(), fill=None):
     return [ins for _, ins in pos], total
 
 
-def body(shape, nofill=(), fill=None, pv_steps=None):
+# row sums on the matrix pipe instead of 64 v_add_f32 per tile (round 5 probe): "sum16" = one more 16x16x32 MFMA per (q group, k-step) with a constant
+# A operand (ones in the rows m % 4 == q group: one 4-register accumulator collects all four q groups); "sum4" = v_mfma_f32_4x4x4_16b_f16 with a ones
+# row as A: every lane's four packed P values land, summed, in one accumulator register (per-lane partial sums, as the v_add chain leaves them)
+def sum_mfmas(kind):
+    if kind == "sum16":
+        return ["v_mfma_f32_16x16x32_f16 a[192:195], v[%d:%d], v[%d:%d], a[192:195]" % (184 + 4 * (j % 4), 187 + 4 * (j % 4), 48 + 4 * (j % 8), 51 + 4 * (j % 8))
+                for j in range(8)]
+    if kind == "sum4":
+        return ["v_mfma_f32_4x4x4_16b_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (192 + 4 * (j % 2), 195 + 4 * (j % 2), 184 + 2 * (j % 4), 185 + 2 * (j % 4),
+                                                                                    48 + 2 * (j % 16), 49 + 2 * (j % 16), 192 + 4 * (j % 2), 195 + 4 * (j % 2)) for j in range(16)]
+    return []
+
+
+def body(shape, nofill=(), fill=None, pv_steps=None, extra=None):
     """One tile body: MFMAs with the fillers spread evenly over the gaps.  pv_steps: k-steps of the P.V-like product (default: the forward's)."""
     fl, _ = fillers(nofill, fill)
+    if extra in ("dot2", "dot2c"):          # the row sums from the PACKED 16-bit P: one v_dot2 with a ones operand per pair
+        if extra == "dot2":
+            add = ["v_dot2_f32_f16 v%d, v%d, v184, v%d" % (216 + j % 2, 220 + j % 4, 216 + j % 2) for j in range(32)]
+        else:
+            add = ["v_dot2c_f32_f16 v%d, v%d, v184" % (216 + j % 2, 220 + j % 4) for j in range(32)]
+        fl = fl + add
+        pos = sorted(range(len(fl)), key=lambda i: ((i + 0.5) / (len(fl) - 32) if i < len(fl) - 32 else (i - (len(fl) - 32) + 0.5) / 32))
+        fl = [fl[i] for i in pos]
+    if extra == "pkadd":
+        fl = fl + ["v_pk_add_f32 v[216:217], v[216:217], v[%d:%d]" % (200 + 2 * (j % 4), 201 + 2 * (j % 4)) for j in range(32)]
+        pos = sorted(range(len(fl)), key=lambda i: ((i + 0.5) / (len(fl) - 32) if i < len(fl) - 32 else (i - (len(fl) - 32) + 0.5) / 32))
+        fl = [fl[i] for i in pos]
     mf = []
     if shape == 32:
         # P.V-like: 8 accumulators x 4 k-steps (a[64:191]); Q.K^T-like: 4 accumulators x 8 k-steps, the first from C = 0 (a[0:63])
@@ -84,6 +109,12 @@ def body(shape, nofill=(), fill=None, pv_steps=None):
                 c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 3)
                 mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], %s" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
                                                                                   48 + 4 * ((acc + ks) % 8), 51 + 4 * ((acc + ks) % 8), c))
+    ex = sum_mfmas(extra)
+    if ex:          # spread over the P.V-like phase (the first len(mf) / 2 MFMAs)
+        half = len(mf) // 2
+        step = half // len(ex)
+        for j, ins in enumerate(reversed(ex)):
+            mf.insert(half - j * step, ins)
     n = len(mf)
     lines = []
     fi = 0
@@ -97,7 +128,7 @@ def body(shape, nofill=(), fill=None, pv_steps=None):
     return lines
 
 
-def kernel(name, shape, nofill=(), fill=None, pv_steps=None):
+def kernel(name, shape, nofill=(), fill=None, pv_steps=None, extra=None):
     # operands: %0 = result (out), %1 = iters (s), %2 = operand pointer (s, 64 bit), %3 / %4 = LDS read addresses (v), %5 = this thread's byte offset (v)
     lines = ["s_mov_b32 s60, %1", "v_mov_b32 v250, %5"]
     for i in range(16):          # 8 A + 8 B operand quads: U[0,1) fp16 data
@@ -107,11 +138,13 @@ def kernel(name, shape, nofill=(), fill=None, pv_steps=None):
         lines.append("v_mov_b32 v%d, 0xbf000000" % (208 + i))        # exp sources: -0.5
         lines.append("v_mov_b32 v%d, 0" % (200 + i))
     lines += ["v_mov_b32 v216, 0", "v_mov_b32 v217, 0"]
-    for i in range(192):
+    for i in range(16):
+        lines.append("v_mov_b32 v%d, 0x3c003c00" % (184 + i))       # the ones operand of the row-sum MFMAs
+    for i in range(200):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
     lines.append("s_waitcnt vmcnt(0)")
     lines.append(".Lprobe_%s_%%=:" % name)
-    lines += body(shape, nofill, fill, pv_steps)
+    lines += body(shape, nofill, fill, pv_steps, extra)
     lines += ["s_sub_u32 s60, s60, 1", "s_cmp_gt_i32 s60, 0", "s_cbranch_scc1 .Lprobe_%s_%%=" % name]
     lines.append("s_nop 7")
     lines.append("v_accvgpr_read_b32 %0, a64")     # keep something observable
@@ -197,7 +230,14 @@ def main():
                 ("no_lds_16x16x32", 16, ("kread", "vread"), None, None),
                 # a dQ-pass-like body: 48 (96) MFMAs, the backward's filler mix (its FLOPs are 0.75 of the forward body's: the TF printed for it are 4/3 too high)
                 ("bwd_dq_like_32x32x16", 32, (), FILL_BWD, 2), ("bwd_dq_like_16x16x32", 16, (), FILL_BWD, 2)]
-    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv) for n, s, nf, fl, pv in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
+    variants = [v + (None,) for v in variants]
+    # row sums on the matrix pipe / packed adds instead of the 64 v_add_f32; "noadd": the adds simply gone (the bound of what removing them can return)
+    variants += [("body16_noadd", 16, ("add",), None, None, None), ("body16_sum16", 16, ("add",), None, None, "sum16"), ("body16_sum4", 16, ("add",), None, None, "sum4"),
+                 ("body16_pkadd", 16, ("add",), None, None, "pkadd"), ("body16_dot2", 16, ("add",), None, None, "dot2"), ("body16_dot2c", 16, ("add",), None, None, "dot2c"),
+                 ("body32_dot2", 32, ("add",), None, None, "dot2"), ("body16_nocvt", 16, ("cvt",), None, None, None), ("body16_noexp", 16, ("exp",), None, None, None), ("body32_noadd", 32, ("add",), None, None, None)]
+    if len(sys.argv) > 2:
+        variants = [v for v in variants if v[0] in sys.argv[2].split(",")]
+    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv, ex) for n, s, nf, fl, pv, ex in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
     path = os.path.join(HERE, "mfma_shape_probe.hip")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/ubench/mfma_shape_probe.py — do not edit.\n" + src)

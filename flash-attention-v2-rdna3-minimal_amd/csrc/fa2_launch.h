@@ -113,6 +113,7 @@ inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, boo
 #else
     const bool nf16 = !bf16;
 #endif
+    if (HD == 64) return m16 && fold;      // head dim 64: the launches that fold the scale (fwd_asm.cpp has the measurements)
     return m16 && HD == 128 && (fold ? p.vs[2] % 32 == 0 : nf16);
 }
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused

@@ -61,6 +61,14 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
     // profiles/fuzz_runs.md row r17_fuzz_rows256_seed503).
     // Round 5, later: the folded 16 x 16 bodies keep their row sums on the matrix pipe (gen opt=lm: 8 MFMAs for 64 v_add_f32 per tile, and fast bodies
     // that are exp + pack only): another -4.0 .. 4.7 % (profiles/r18_kbench_lm_windows.txt); contract FA2_CONTRACT_LSUM_P16 (plan_range, host.cpp).
+    // Head dim 64 (same generator, hd = 64: 2 k-steps, 4 d groups, a 72-gap body): the folded body with the row sums on the matrix pipe against the
+    // 32x32x16 folded body, one box (profiles/r18_kbench_d64_m16.txt): fp16 B2 H16 N4096 136.0 -> 123.7 us, B1 H24 N5120 151.1 -> 137.1 (+10 %);
+    // the f32-scale 16 x 16 body (bf16 causal) LOSES 7 % there (75.4 -> 80.9 us: 64 more v_fma_f32 and the adds of the sum check on a body that is
+    // VALU-bound to begin with) — those launches stay on the 32x32x16 body.
+    if (HD == 64 && fwd_asm_is_m16(HD, bf16, p, fold, m16)) {
+        if (bf16) return causal ? launch_asm_t<64, true, true, true, true>(p, stream) : launch_asm_t<64, true, false, true, true>(p, stream);
+        return causal ? launch_asm_t<64, false, true, true, true>(p, stream) : launch_asm_t<64, false, false, true, true>(p, stream);
+    }
     if (fwd_asm_is_m16(HD, bf16, p, fold, m16)) {
         if (fold) {
             if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);

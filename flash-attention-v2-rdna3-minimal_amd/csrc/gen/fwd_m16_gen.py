@@ -56,20 +56,20 @@ FS = [FSA, FSB]
 LS = [LA, LB]
 
 
-def OACC(dg, qg):
-    return A(4 * (8 * qg + dg), 4)
+def OACC(dg, qg, ndg=8):                           # (ndg: 16-column d groups of O = head dim / 16; nks: 32-column k-steps of Q.K^T = head dim / 32)
+    return A(4 * (ndg * qg + dg), 4)
 
 
-def QF(qg, ks):
-    return A(128 + 4 * (4 * qg + ks), 4)
+def QF(qg, ks, nks=4):
+    return A(128 + 4 * (nks * qg + ks), 4)
 
 
-def KF(kg, ks):
-    return A(192 + 4 * (4 * kg + ks), 4)
+def KF(kg, ks, nks=4):
+    return A(192 + 4 * (nks * kg + ks), 4)
 
 
-def VF(dg, kvs):
-    return V(144 + 4 * (8 * kvs + dg), 4)
+def VF(dg, kvs, ndg=8):
+    return V(144 + 4 * (ndg * kvs + dg), 4)
 
 
 # "ct" (folded scale): C tuples in v[176:191], so the V^T fragments of k-step 1 live in a[224:255] and the K fragments in a 32-register pool
@@ -101,16 +101,25 @@ class Gen16(base.Gen):
     DEFAULTS16 = {"m": (4.0, 20.0), "e": (20.0, 128.0), "vread": (66.0, 80.0), "kread": (0.0, 48.0), "dma": (4.0, 36.0), "mmask": (4.0, 48.0),
                   "se0": (0.0, 96.0), "se1": (16.0, 120.0), "sc0": (96.0, 116.0), "sc1": (120.0, 128.0)}
 
-    def __init__(self, bf16=False, **cfg):
+    # head dim 64 (a 64-gap body, 72 with opt=lm): the same windows at half the length
+    DEFAULTS16_64 = {"m": (2.0, 12.0), "e": (12.0, 64.0), "vread": (34.0, 44.0), "kread": (0.0, 24.0), "dma": (2.0, 20.0), "mmask": (2.0, 24.0),
+                     "se0": (0.0, 48.0), "se1": (8.0, 60.0), "sc0": (48.0, 58.0), "sc1": (60.0, 64.0)}
+
+    def __init__(self, bf16=False, hd=128, **cfg):
         opt = tuple(cfg.get("opt", ()))
         assert "lmfma" not in opt, "the 16x16x32 generator has no lmfma bodies"
-        user = dict(cfg)
-        super().__init__(bf16, hd=128, **cfg)
-        self.cfg.update({k: v for k, v in self.DEFAULTS16.items() if k not in user})
+        user = {(k[4:] if k.startswith("d64_") else k): v for k, v in cfg.items() if hd == 64 or not k.startswith("d64_")}
+        super().__init__(bf16, hd=hd, **cfg)
+        self.NKS16, self.NDG = hd // 32, hd // 16         # k-steps of Q.K^T (32 head-dim columns each), 16-column d groups of O
+        nks, ndg = self.NKS16, self.NDG
+        self.cfg.update({k: v for k, v in (self.DEFAULTS16 if hd == 128 else self.DEFAULTS16_64).items() if k not in user})
         if "kread_ct" not in user:
-            self.cfg["kread_ct"] = (16.0, 64.0)      # "ct": gap window of the K reads of k-steps 0, 1 (2, 3 follow their pool slots)
-        self.kf16 = KF_POOL if self.ct else KF
-        self.vf16 = VF_CT if self.ct else VF
+            # "ct": gap window of the K reads of k-steps 0, 1 (2, 3 follow their pool slots; head dim 64 has no others)
+            self.cfg["kread_ct"] = (16.0, 64.0) if hd == 128 else (8.0, 32.0)
+        self.kf16 = KF_POOL if self.ct else (lambda kg, ks: KF(kg, ks, nks))
+        self.vf16 = VF_CT if self.ct else (lambda dg, kvs: VF(dg, kvs, ndg))
+        self.oacc16 = lambda dg, qg: OACC(dg, qg, ndg)
+        self.qf16 = lambda qg, ks: QF(qg, ks, nks)
         self.mfma = "v_mfma_f32_16x16x32_bf16" if bf16 else "v_mfma_f32_16x16x32_f16"
         # opt=lm: row sums on the matrix pipe (ONES16 above), in EVERY body, and fast bodies that are exp + pack and nothing else: no adds, no check, no
         # repair blocks.  What the sum check guarded against — a P beyond the 16-bit type's range, an accumulator beyond f32's — is caught later and
@@ -125,10 +134,12 @@ class Gen16(base.Gen):
         # every variant within 0.5 % of the best — the optimum is flat.
         self.lm = "lm" in self.opt
         assert self.ct or not self.lm, "opt=lm needs the folded scale (opt=ct): its constants live in the registers of the ct repair blocks"
-        self.npv, self.nqk = (72 if self.lm else 64), 64
+        self.npv, self.nqk = 8 * ndg + (8 if self.lm else 0), 16 * nks
         self.ng = self.npv + self.nqk
         if self.lm:
-            for k, w in {"e": (20.0, 136.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 136.0), "kread_ct": (16.0, 72.0)}.items():
+            lmw = ({"e": (20.0, 136.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 136.0), "kread_ct": (16.0, 72.0)} if hd == 128 else
+                   {"e": (12.0, 72.0), "vread": (40.0, 60.0), "se0": (0.0, 56.0), "se1": (8.0, 72.0), "kread_ct": (8.0, 40.0)})
+            for k, w in lmw.items():
                 if k not in user:
                     self.cfg[k] = w
             for k, w in user.items():         # "lm_<key>": a schedule tunable of the lm bodies only (window sweeps, tools/kbench.py)
@@ -158,24 +169,25 @@ class Gen16(base.Gen):
         out = []
         b = SB(qb, par)
         for kvs in range(2):
-            for dg in range(8):
+            for dg in range(self.NDG):
                 for h in range(2):
-                    acc = OACC(dg, 2 * qb + h)
+                    acc = self.oacc16(dg, 2 * qb + h)
                     out.append(mk(self.mfma, acc, self.vf16(dg, kvs), b.sub(16 * h + 8 * kvs, 4), acc, tag="mfma"))
-                if self.lm and dg in (3, 7):      # the row sums of q group 2 qb + h, this k-step (eight P.V MFMAs between two links of the LSV chain)
-                    h = dg >> 2
+                if self.lm and dg in (self.NDG // 2 - 1, self.NDG - 1):
+                    # the row sums of q group 2 qb + h, this k-step (NDG P.V MFMAs between two links of the LSV chain)
+                    h = int(dg == self.NDG - 1)
                     out.append(mk(self.mfma, LSV, ONES16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), LSV, tag="mfma"))
         return out
 
     def qk_mfmas(self, par):
         out = []
-        for ks in range(4):
+        for ks in range(self.NKS16):
             for qb in range(2):
                 for h in range(2):
                     for kg in range(4):
                         dst = SB(qb, par).sub(16 * h + 4 * kg, 4)
                         c0 = CT16[2 * qb + h] if self.ct else 0
-                        out.append(mk(self.mfma, dst, self.kf16(kg, ks), QF(2 * qb + h, ks), c0 if ks == 0 else dst, tag="mfma"))
+                        out.append(mk(self.mfma, dst, self.kf16(kg, ks), self.qf16(2 * qb + h, ks), c0 if ks == 0 else dst, tag="mfma"))
         return out
 
     # ------------------------------------------------------------------ filler streams
@@ -359,8 +371,8 @@ class Gen16(base.Gen):
         r.append(mk("s_nop", 15))
         r.append(mk("s_nop", 15))
         for h in range(2):
-            for dg in range(8):
-                acc = OACC(dg, 2 * qb + h)
+            for dg in range(self.NDG):
+                acc = self.oacc16(dg, 2 * qb + h)
                 for j in range(0, 4, 2):
                     for x in range(2):
                         r.append(mk("v_accvgpr_read_b32", scr[x], acc[j + x]))
@@ -506,7 +518,7 @@ class Gen16(base.Gen):
         sixteen MFMAs of that k-step are issued (a whole k-step ahead of its own first use)"""
         kr = self.stream_kread(par)                       # order: ks major, kg minor
         self.place(load, slots, kr[:8], self.cfg["kread_ct"][0], self.cfg["kread_ct"][1], 3)
-        for ks in range(2, 4):
+        for ks in range(2, self.NKS16):
             g0 = self.npv + 16 * (ks - 2) + 15
             for kg in range(4):
                 it = kr[4 * ks + kg]
@@ -527,8 +539,8 @@ class Gen16(base.Gen):
                     # the row sums, with the sum MFMAs of every tile at the old reference landed (s_nop above): checked at full size, then scaled
                     self.lm_fail_check(r, LS[h][qb], TMP[4], TMP[5])
                     r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], FS[h][qb]))
-                for dg in range(8):
-                    acc = OACC(dg, 2 * qb + h)
+                for dg in range(self.NDG):
+                    acc = self.oacc16(dg, 2 * qb + h)
                     for j in range(4):
                         r.append(mk("v_accvgpr_read_b32", scr[j], acc[j]))
                     r.append(mk("s_nop", 1))
@@ -546,7 +558,7 @@ class Gen16(base.Gen):
     def stream_kread(self, par):
         g = self.g
         return [mk("ds_read_b128", self.kf16(kg, ks), KR[ks], tag="lds", offset=g.K_SLOT + par * g.SLOT_B + kg * 16 * g.ROWB)
-                for ks in range(4) for kg in range(4)]
+                for ks in range(self.NKS16) for kg in range(4)]
 
     def stream_vread(self, par):
         """V^T fragments: two transposed reads per (d group, k-step).  A read's lanes 0..31 are the 16-lane groups g = 0, 1: rows 4 g + (n >> 2) — rows r and
@@ -556,7 +568,7 @@ class Gen16(base.Gen):
         out = []
         g = self.g
         for kvs in range(2):
-            for dg in range(8):
+            for dg in range(self.NDG):
                 off = g.V_BASE + par * g.SLOT_B + 32 * kvs * g.ROWB
                 if self.ct:
                     adr = (VRO if dg & 1 else VR)[dg >> 1]
@@ -577,12 +589,12 @@ class Gen16(base.Gen):
         r.append(Ins("label", (Label(two),)))
         r.append(mk("s_waitcnt", vmcnt=2 * g.NP))
         r.append(Ins("label", (Label(waited),)))
-        for i in range(4):
+        for i in range(self.NKS16):
             r.append(mk("v_add_u32", QD[i], S_QSB, KR[i]))
         r.append(mk("s_nop", 0))
         for qg in range(4):
-            for ks in range(4):
-                r.append(mk("ds_read_b128", QF(qg, ks), QD[ks], offset=qg * 16 * g.ROWB))
+            for ks in range(self.NKS16):
+                r.append(mk("ds_read_b128", self.qf16(qg, ks), QD[ks], offset=qg * 16 * g.ROWB))
         return r
 
     # ------------------------------------------------------------------ whole block
@@ -594,16 +606,18 @@ class Gen16(base.Gen):
         assert not tr, "the trace builds belong to the 32x32 generator"
         # ---- entry: addresses, the wave's Q through its LDS image, the first tiles
         p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
-        for ks in range(4):
+        nks, ndg = self.NKS16, self.NDG
+        nqr = 16 * nks                                                 # registers of the wave's Q fragments
+        for ks in range(nks):
             p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
-        for j in range(4):
+        for j in range(ndg // 2):
             p.emit("v_xor_b32", VR[j], j << 6, A_VR0)
         if self.ct:
-            for j in range(4):
+            for j in range(ndg // 2):
                 p.emit("v_xor_b32", VRO[j], (j << 6) | 32, A_VR0)      # the other 32-byte half
         if self.lm:
             # the constant A tuples of the row-sum MFMAs: 0.25 (two packed 16-bit values) on the lanes of rows m = lane % 16 with m % 4 == qg
-            p.emit("v_lshrrev_b32", TMP[0], 8, A_KR0)               # A_KR0 = n * 256 + ((g ^ n) << 4), n = lane % 16
+            p.emit("v_lshrrev_b32", TMP[0], g.ROWB.bit_length() - 1, A_KR0)      # A_KR0 = n * ROWB + (swizzled granule << 4), n = lane % 16
             p.emit("v_mov_b32", TMP[1], 0x3e803e80 if bf16_ else 0x34003400)
             p.emit("v_and_b32", TMP[0], 3, TMP[0])
             for qg in range(4):
@@ -640,8 +654,8 @@ class Gen16(base.Gen):
             # `scale * q_frags` (pure_torch_ver.py:61) — then parked in the accumulator file.  A prefetched item's raw fragments come back from there.
             p.emit("s_branch", Label("q_issued"))
             p.label("have_q")
-            for i in range(64):
-                p.emit("v_accvgpr_read_b32", V(VBASE + i), QF(i // 16, (i % 16) // 4)[i % 4])
+            for i in range(nqr):
+                p.emit("v_accvgpr_read_b32", V(VBASE + i), self.qf16(i // (4 * nks), (i % (4 * nks)) // 4)[i % 4])
             p.label("q_issued")
         else:
             p.label("have_q")
@@ -653,7 +667,8 @@ class Gen16(base.Gen):
             p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
             p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
             p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
-            if self.ct and (i & 1):       # the rows of an odd piece have (row >> 2) & 1 set: their 32-byte halves are flipped in the "ct" V image
+            if self.ct and ((g.RPP * i) & 4):       # the rows of such a piece have (row >> 2) & 1 set where piece 0's have it clear: their 32-byte halves are
+                                                     # flipped in the "ct" V image (head dim 128: the odd pieces; 64: a piece is eight rows, none)
                 p.emit("v_xor_b32", VD[i], 32, A_VD0)
                 p.emit("s_nop", 0)
                 p.emit("v_add_u32", VD[i], S_TMP2, VD[i])
@@ -694,12 +709,12 @@ class Gen16(base.Gen):
         p.label("qwait8")
         p.emit("s_waitcnt", vmcnt=2 * g.NP)
         p.label("qwaited")
-        for ks in range(4):
+        for ks in range(nks):
             p.emit("v_add_u32", TMP[ks], S_QSB, KR[ks])
         p.emit("s_nop", 0)
         for qg in range(4):
-            for ks in range(4):
-                p.emit("ds_read_b128", V(VBASE + 16 * qg + 4 * ks, 4) if self.fold else QF(qg, ks), TMP[ks], offset=qg * 16 * g.ROWB)
+            for ks in range(nks):
+                p.emit("ds_read_b128", V(VBASE + 4 * nks * qg + 4 * ks, 4) if self.fold else self.qf16(qg, ks), TMP[ks], offset=qg * 16 * g.ROWB)
         p.label("staged")
         p.emit("s_bitcmp1_b32", A_FLAGS, 1)
         p.emit("s_cselect_b32", S_QH, 0, 8)
@@ -711,15 +726,15 @@ class Gen16(base.Gen):
                 p.emit("v_mov_b32", MC[h][qb], 0.0 if self.fold else NEG_INF)
                 p.emit("v_mov_b32", LS[h][qb], 0)
                 p.emit("v_mov_b32", FS[h][qb], 1.0)
-        for i in range(128):
+        for i in range(16 * ndg):
             p.emit("v_accvgpr_write_b32", A(i), 0)
         p.emit("s_waitcnt", lgkmcnt=0)
         if self.fold:
             for qg in range(4):
                 for i in range(4):
                     p.emit("v_mov_b32", CT16[qg][i], 0)                 # C tuples: the references start at 0
-            for i in range(64):
-                for ins in self.q_prescale_reg(V(VBASE + i), QF(i // 16, (i % 16) // 4)[i % 4], TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]):
+            for i in range(nqr):
+                for ins in self.q_prescale_reg(V(VBASE + i), self.qf16(i // (4 * nks), (i % (4 * nks)) // 4)[i % 4], TMP[2 * (i & 1)], TMP[2 * (i & 1) + 1]):
                     p.ins.append(ins)
         p.emit("s_cmp_lt_i32", A_NTWG, 2)
         p.emit("s_cbranch_scc1", Label("wait4"))
@@ -810,8 +825,8 @@ class Gen16(base.Gen):
         p.emit("s_bitcmp1_b32", A_FLAGS, 3)
         p.emit("s_cbranch_scc1", Label("part_store"))
         for qg in range(4):
-            for dg in range(8):
-                acc = OACC(dg, qg)
+            for dg in range(self.NDG):
+                acc = self.oacc16(dg, qg)
                 for j in range(4):
                     p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
                 p.emit("s_nop", 0)
@@ -858,8 +873,8 @@ class Gen16(base.Gen):
         p.emit("s_nop", 0)
         p.emit("v_add_u32", wso, wso, TMP[2])
         for qg in range(4):
-            for dg in range(8):
-                acc = OACC(dg, qg)
+            for dg in range(self.NDG):
+                acc = self.oacc16(dg, qg)
                 for j in range(4):
                     p.emit("v_accvgpr_read_b32", TMP[j], acc[j])
                 p.emit("v_add_u32", adr, 512 * qg + 8192 * (4 * (dg >> 1) + 2 * (dg & 1)), wso)
@@ -887,15 +902,15 @@ def main():
     cfg = base.parse_opts(a.opt)
     if base.is_probe(cfg) and not a.probe:
         sys.exit("fwd_m16_gen.py: %r contains timing-probe options; they need --probe" % a.opt)
-    for bf16 in (False, True):
-        for fold in (False, True):
+    for hd, bf16, fold in ((hd, bf16, fold) for hd in (128, 64) for bf16 in (False, True) for fold in (False, True)):
+        if True:
             c = dict(cfg)
             # the folded bodies ship with the row sums on the matrix pipe (opt=lm; opt=nolm builds them with the sum check of the f32-scale bodies)
             c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if fold else ())
             if fold and "nolm" not in cfg.get("opt", ()):
                 c["opt"] += ("lm",)
-            prog = Gen16(bf16, **c).build()
-            path = os.path.join(a.out, "fa2_fwd_m16_%s%s.inc" % ("bf16" if bf16 else "f16", "_fold" if fold else ""))
+            prog = Gen16(bf16, hd=hd, **c).build()
+            path = os.path.join(a.out, "fa2_fwd_m16_%s%s%s.inc" % ("d64_" if hd == 64 else "", "bf16" if bf16 else "f16", "_fold" if fold else ""))
             base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
             print(path, len(prog.ins), "instructions")
 

@@ -226,9 +226,10 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     # config 1 (B1 H2 N128 D64): a grid this small runs 128-row workgroups of the HIP kernel, f32 scale
     p = _meta_plan(1, 2, 128, 128, 64)
     assert (p.kernel, p.contract, p.rows) == (K.FA2_KERNEL_HIP_128, 0, 128)
-    # head dim 64: fp16 -> the hand-scheduled body (folded scale; f32 row sums since 0.9); bf16 non-causal -> 8-wave HIP kernel; bf16 causal -> the body, f32 scale
+    # head dim 64: fp16 -> the hand-scheduled body (folded scale, row sums of the rounded P on the matrix pipe: the 16x16x32 body); bf16 non-causal ->
+    # 8-wave HIP kernel; bf16 causal -> the 32x32x16 body, f32 scale
     p = _meta_plan(2, 16, 4096, 4096, 64)
-    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_PRESCALE_Q)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, FOLD128)
     p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16)
     assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
     p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16, causal=True)

@@ -795,7 +795,7 @@ def test_tail_split_launches_cover_every_head(shape):
     plan = _plan(q, k, False)
     if shape == (2, 17, 4096, 64):          # 544 workgroups: two full rounds of the hand-scheduled body + the last 2 heads as 128-row workgroups
         assert plan.heads_main == 32 and plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.kernel_tail == _fa2_lib.FA2_KERNEL_HIP_128
-        assert plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q and plan.contract_tail == 0
+        assert plan.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16 and plan.contract_tail == 0
     for (b, h) in {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2)}:
         sl = (slice(b, b + 1), slice(h, h + 1))
         _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], 0, False, plan=plan, head=b * H + h)
@@ -951,7 +951,7 @@ def test_head_dim_64_fp16_folded_scale_contract_on_large_logits():
     assert lib.fa2_fwd_prescales_q(64, 0.125) == 1
     B, H, N, D = 2, 16, 2048, 64                         # 256 workgroups of 256 rows: the hand-scheduled body
     pl = _fa2_lib.fwd_plan(torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), torch.empty((B, H, N, D), dtype=torch.float16, device="meta"), False)
-    assert pl.kernel == _fa2_lib.FA2_KERNEL_ASM and pl.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+    assert pl.kernel == _fa2_lib.FA2_KERNEL_ASM and pl.contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16
     for amp, o_tol, lse_tol in ((1.0, 1e-3, 1e-3), (3.0, 3e-2, 0.3)):
         g = torch.Generator(device="cpu").manual_seed(int(amp * 10))
         q = (torch.randn((B, H, N, D), generator=g) * amp).half().to(_dev())

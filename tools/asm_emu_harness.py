@@ -16,7 +16,7 @@ LOG2E = 1.4426950408889634
 _PROGS = {}
 OPT = ()                # generator options of the programs under test (default: the f32-scale body the library ships)
 HD = 128                # head dim of the programs under test (128 or 64)
-M16 = False             # the v_mfma_f32_16x16x32 generator (csrc/gen/fwd_m16_gen.py, head dim 128) instead of the 32x32x16 one
+M16 = False             # the v_mfma_f32_16x16x32 generator (csrc/gen/fwd_m16_gen.py) instead of the 32x32x16 one
 
 
 def program(bf16):
@@ -24,7 +24,7 @@ def program(bf16):
     if key not in _PROGS:
         if M16:
             import fwd_m16_gen
-            _PROGS[key] = fwd_m16_gen.Gen16(bf16, opt=OPT).build()
+            _PROGS[key] = fwd_m16_gen.Gen16(bf16, hd=HD, opt=OPT).build()
         else:
             _PROGS[key] = gen.Gen(bf16, hd=HD, opt=OPT).build()
     return _PROGS[key]
@@ -91,11 +91,11 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     if M16:
         # lane = (n = lane % 16, g4 = lane / 16).  K / Q fragment of k-step ks: row n, granule 4 ks + g4 of the swizzled row image (the asm xors ks << 6)
         n16, g4 = lane & 15, lane >> 4
-        v[9] = (n16 * g.ROWB + ((g4 ^ (n16 & kmask)) << 4)).astype(np.uint32)
+        v[9] = (n16 * g.ROWB + ((g4 ^ ((n16 // rpb) & kmask)) << 4)).astype(np.uint32)
         # V^T fragment: the 16-lane group g4 addresses rows 4 g4 + (n >> 2), 8 bytes at column 4 (n & 3) of the 16-column group (chunk 0 swizzled; the asm
         # xors (dg >> 1) << 6 and adds 32 (dg & 1))
         trow = 4 * g4 + (n16 >> 2)
-        v[10] = (trow * g.ROWB + ((trow & vmask) << 6) + 8 * (n16 & 3)).astype(np.uint32)
+        v[10] = (trow * g.ROWB + (((trow // rpb) & vmask) << 6) + 8 * (n16 & 3)).astype(np.uint32)
         if "ct" in OPT:
             # the folded bodies' own V image: the 32-byte half of a chunk is flipped for rows with (row >> 2) & 1 (conflict-free transposed reads)
             v[10] = v[10] + (32 * (g4 & 1)).astype(np.uint32)

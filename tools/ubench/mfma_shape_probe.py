@@ -67,7 +67,7 @@ def sum_mfmas(kind):
     return []
 
 
-def body(shape, nofill=(), fill=None, pv_steps=None, extra=None):
+def body(shape, nofill=(), fill=None, pv_steps=None, extra=None, hd=128):
     """One tile body: MFMAs with the fillers spread evenly over the gaps.  pv_steps: k-steps of the P.V-like product (default: the forward's)."""
     fl, _ = fillers(nofill, fill)
     if extra in ("dot2", "dot2c"):          # the row sums from the PACKED 16-bit P: one v_dot2 with a ones operand per pair
@@ -86,11 +86,11 @@ def body(shape, nofill=(), fill=None, pv_steps=None, extra=None):
     if shape == 32:
         # P.V-like: 8 accumulators x 4 k-steps (a[64:191]); Q.K^T-like: 4 accumulators x 8 k-steps, the first from C = 0 (a[0:63])
         for ks in range(4 if pv_steps is None else pv_steps):
-            for acc in range(8):
+            for acc in range(8 if hd == 128 else 4):
                 a0 = 64 + 16 * acc
                 mf.append("v_mfma_f32_32x32x16_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 15, 16 + 4 * ((acc + ks) % 8), 19 + 4 * ((acc + ks) % 8),
                                                                                         48 + 4 * ((2 * ks + acc // 4) % 8), 51 + 4 * ((2 * ks + acc // 4) % 8), a0, a0 + 15))
-        for ks in range(8):
+        for ks in range(8 if hd == 128 else 4):
             for acc in range(4):
                 a0 = 16 * acc
                 c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 15)
@@ -99,11 +99,11 @@ def body(shape, nofill=(), fill=None, pv_steps=None, extra=None):
     else:
         # the same products as 16x16x32 tiles: P.V-like: 32 accumulators (4 registers) x 2 k-steps; Q.K^T-like: 16 accumulators x 4 k-steps
         for ks in range(2 if pv_steps is None else max(1, pv_steps // 2)):
-            for acc in range(32):
+            for acc in range(32 if hd == 128 else 16):
                 a0 = 64 + 4 * acc
                 mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
                                                                                         48 + 4 * ((acc + 4 * ks) % 8), 51 + 4 * ((acc + 4 * ks) % 8), a0, a0 + 3))
-        for ks in range(4):
+        for ks in range(4 if hd == 128 else 2):
             for acc in range(16):
                 a0 = 4 * acc
                 c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 3)
@@ -128,7 +128,7 @@ def body(shape, nofill=(), fill=None, pv_steps=None, extra=None):
     return lines
 
 
-def kernel(name, shape, nofill=(), fill=None, pv_steps=None, extra=None):
+def kernel(name, shape, nofill=(), fill=None, pv_steps=None, extra=None, hd=128):
     # operands: %0 = result (out), %1 = iters (s), %2 = operand pointer (s, 64 bit), %3 / %4 = LDS read addresses (v), %5 = this thread's byte offset (v)
     lines = ["s_mov_b32 s60, %1", "v_mov_b32 v250, %5"]
     for i in range(16):          # 8 A + 8 B operand quads: U[0,1) fp16 data
@@ -144,7 +144,7 @@ def kernel(name, shape, nofill=(), fill=None, pv_steps=None, extra=None):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
     lines.append("s_waitcnt vmcnt(0)")
     lines.append(".Lprobe_%s_%%=:" % name)
-    lines += body(shape, nofill, fill, pv_steps, extra)
+    lines += body(shape, nofill, fill, pv_steps, extra, hd)
     lines += ["s_sub_u32 s60, s60, 1", "s_cmp_gt_i32 s60, 0", "s_cbranch_scc1 .Lprobe_%s_%%=" % name]
     lines.append("s_nop 7")
     lines.append("v_accvgpr_read_b32 %0, a64")     # keep something observable
@@ -235,9 +235,14 @@ def main():
     variants += [("body16_noadd", 16, ("add",), None, None, None), ("body16_sum16", 16, ("add",), None, None, "sum16"), ("body16_sum4", 16, ("add",), None, None, "sum4"),
                  ("body16_pkadd", 16, ("add",), None, None, "pkadd"), ("body16_dot2", 16, ("add",), None, None, "dot2"), ("body16_dot2c", 16, ("add",), None, None, "dot2c"),
                  ("body32_dot2", 32, ("add",), None, None, "dot2"), ("body16_nocvt", 16, ("cvt",), None, None, None), ("body16_noexp", 16, ("exp",), None, None, None), ("body32_noadd", 32, ("add",), None, None, None)]
+    variants = [v + (128,) for v in variants]
+    # head dim 64 (half the MFMAs and half the LDS reads for the same softmax work; its TF are printed at the 128 body's FLOPs: halve them)
+    FILL64 = {"exp": 64, "add": 64, "cvt": 32, "kread": 8, "vread": 16}
+    variants += [("d64_body32", 32, (), FILL64, None, None, 64), ("d64_body16", 16, (), FILL64, None, None, 64),
+                 ("d64_body16_sum16", 16, ("add",), FILL64, None, "sum16", 64), ("d64_body32_noadd", 32, ("add",), FILL64, None, None, 64)]
     if len(sys.argv) > 2:
         variants = [v for v in variants if v[0] in sys.argv[2].split(",")]
-    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv, ex) for n, s, nf, fl, pv, ex in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
+    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv, ex, hd) for n, s, nf, fl, pv, ex, hd in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
     path = os.path.join(HERE, "mfma_shape_probe.hip")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/ubench/mfma_shape_probe.py — do not edit.\n" + src)

@@ -216,7 +216,8 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             f.split = pl;
             f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
             const bool fold = f.split_asm && asm_folds(bf16, p);
-            f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0), 256, fold}
+            const bool lsum16 = fold && fa2::fwd_asm_is_m16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+            f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}
                                  : RangePlan{FA2_KERNEL_HIP_256, 0, 256, false};
             return f;
         }
@@ -252,7 +253,7 @@ int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStre
             // the hand-scheduled persistent kernel: every workgroup works through its whole items, then its parts (the item seam hides a
             // part's load phase like any other item's; the block stores a part's f32 tile itself)
             p.item_cap = f.split.full_items + f.split.split_items * f.split.nsplit;
-            rc = fa2::launch_fwd_asm(HD, bf16, p, false, f.main.fold, stream);
+            rc = fa2::launch_fwd_asm(HD, bf16, p, false, f.main.fold, stream, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
         } else {
             rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
         }

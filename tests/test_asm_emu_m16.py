@@ -204,3 +204,24 @@ def test_m16_head_dim_64_persistent_seams_and_text(m16_d64, tmp_path):
         o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + 256], k, v, True, row0=qb * 256, pre=bool(harness.OPT))
         assert np.abs(o - o_ref).max() <= 1.1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in m16_d64 else 1e-4)
     _assemble(64, tmp_path)
+
+
+def test_m16_head_dim_64_kv_split_part_epilogue(m16_d64):
+    """KV-split parts at head dim 64 (SDXL's 64 x 64 self-attention is 320 workgroups: fa2_fwd_ws splits its last round): a whole item, then two parts of
+    another through the item seam; merged like fwd_combine_kernel the parts are the whole item."""
+    rng = np.random.default_rng(65)
+    q, k, v = rng.standard_normal((512, 64)), rng.standard_normal((448, 64)), rng.standard_normal((448, 64))
+    items = [(q, k, v, 1), (q, k[:256], v[:256], 0, True), (q, k[256:], v[256:], 0, True)]
+    outs, m = harness.run_items(items, False)
+    assert not m.errors, m.errors[:5]
+    pre = bool(harness.OPT)
+    ltol = 1e-3 if "lm" in m16_d64 else 1e-4
+    for (item, (o, lse)) in zip(items, outs):
+        qq, kk, vv, qb = item[:4]
+        o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre=pre)
+        assert np.isfinite(o).all() and np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= ltol
+    (o1, l1), (o2, l2) = outs[1], outs[2]
+    lse = np.logaddexp2(l1, l2)
+    o = o1 * np.exp2(l1 - lse)[:, None] + o2 * np.exp2(l2 - lse)[:, None]
+    o_ref, lse_ref = harness.dense(q[:256], k, v, False, pre=pre)
+    assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-3

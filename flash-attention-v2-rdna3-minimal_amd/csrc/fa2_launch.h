@@ -107,14 +107,25 @@ FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t s
 FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16 = false);
 // Does launch_fwd_asm(..., m16) run a body built on v_mfma_f32_16x16x32 (csrc/gen/fwd_m16_gen.py)?  ONE predicate: the launcher executes it, the plan
 // reports its contract (the folded 16 x 16 bodies add the ROUNDED P into the row sums: FA2_CONTRACT_LSUM_P16).  fwd_asm.cpp has the measurements.
-inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
-#ifdef FA2_M16_BF16        // (developer A/B: the f32-scale 16 x 16 body for bf16 launches too)
-    const bool nf16 = true;
+enum { kM16None = 0, kM16F32 = 1, kM16Fold = 2, kM16F32Lm = 3 };
+inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
+    if (!m16) return kM16None;
+    if (fold) return (HD == 64 || p.vs[2] % 32 == 0) ? kM16Fold : kM16None;           // folded scale, row sums on the matrix pipe
+    // f32 scale.  A call flagged FA2_FLAG_EXACT_SCALE (a forward that will be differentiated) keeps the f32 row sums: fp16 at head dim 128 on the
+    // 16 x 16 body with the sum check, everything else on the 32x32x16 bodies; other calls take the 16 x 16 bodies with the row sums on the matrix pipe
+    // (head dim 128; at head dim 64 the f32-scale 16 x 16 bodies do not beat the 32x32x16 body: profiles/r18_kbench_f32lm*.txt)
+    if (HD != 128) return kM16None;
+    if (p.exact_scale) return !bf16 ? kM16F32 : kM16None;
+#ifdef FA2_NO_F32_LM        // (developer A/B: the routing before the f32-scale lm bodies existed)
+    return !bf16 ? kM16F32 : kM16None;
 #else
-    const bool nf16 = !bf16;
+    return kM16F32Lm;
 #endif
-    if (HD == 64) return m16 && fold;      // head dim 64: the launches that fold the scale (fwd_asm.cpp has the measurements)
-    return m16 && HD == 128 && (fold ? p.vs[2] % 32 == 0 : nf16);
+}
+inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) { return fwd_asm_m16_kind(HD, bf16, p, fold, m16) != kM16None; }
+inline bool fwd_asm_lsum16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
+    const int k = fwd_asm_m16_kind(HD, bf16, p, fold, m16);
+    return k == kM16Fold || k == kM16F32Lm;
 }
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
 // dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).

@@ -10,9 +10,9 @@ namespace {
 // Persistent workgroups of the d128 kernel (non-causal launches): at most one workgroup per CU, each working through a
 // strided list of (head, q block) items and fetching the next item's first tiles while the current one finishes
 // (fa2_fwd_d128.hip.h).  Option "persist" = 0 launches one workgroup per item instead (A/B measurements, bit-identity tests).
-template <int HD, bool BF16, bool CAUSAL, bool FOLD, bool M16 = false>
+template <int HD, bool BF16, bool CAUSAL, bool FOLD, bool M16 = false, bool LM = false>
 int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL, FOLD, M16>;
+    constexpr auto kern = fa2::fwd_asm_kernel<HD, BF16, CAUSAL, FOLD, M16, LM>;
     constexpr int lds = fa2::AsmGeo<HD>::LDS_BYTES;
     if (int rc = fa2::set_lds<kern>(lds)) return rc;
     fa2::FwdParams p = p0;
@@ -65,11 +65,20 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
     // 32x32x16 folded body, one box (profiles/r18_kbench_d64_m16.txt): fp16 B2 H16 N4096 136.0 -> 123.7 us, B1 H24 N5120 151.1 -> 137.1 (+10 %);
     // the f32-scale 16 x 16 body (bf16 causal) LOSES 7 % there (75.4 -> 80.9 us: 64 more v_fma_f32 and the adds of the sum check on a body that is
     // VALU-bound to begin with) — those launches stay on the 32x32x16 body.
-    if (HD == 64 && fwd_asm_is_m16(HD, bf16, p, fold, m16)) {
+    // The f32-scale 16 x 16 bodies with the row sums on the matrix pipe (gen opt=lm without ct: constants in a[224:255], K fragments in the 32-register
+    // pool): every head-dim-128 launch that scales the f32 product and is not flagged FA2_FLAG_EXACT_SCALE — bf16 by default.  Against the routing
+    // before (bf16 on the 32x32x16 body), one box (profiles/r18_kbench_f32lm.txt, _c3.txt): bf16 B2 H16 N4096 non-causal 199.1 -> 187.8 us, causal (c3)
+    // 110.0 -> 106.7, B1 H32 N8192 causal 393.8 -> 373.2, B8 797 -> 764; head dim 64 bf16 causal 74.9 -> 74.7 (not taken).
+    const int kind = fwd_asm_m16_kind(HD, bf16, p, fold, m16);
+    if (kind == kM16F32Lm) {       // (head dim 128)
+        if (bf16) return causal ? launch_asm_t<128, true, true, false, true, true>(p, stream) : launch_asm_t<128, true, false, false, true, true>(p, stream);
+        return causal ? launch_asm_t<128, false, true, false, true, true>(p, stream) : launch_asm_t<128, false, false, false, true, true>(p, stream);
+    }
+    if (HD == 64 && kind != kM16None) {
         if (bf16) return causal ? launch_asm_t<64, true, true, true, true>(p, stream) : launch_asm_t<64, true, false, true, true>(p, stream);
         return causal ? launch_asm_t<64, false, true, true, true>(p, stream) : launch_asm_t<64, false, false, true, true>(p, stream);
     }
-    if (fwd_asm_is_m16(HD, bf16, p, fold, m16)) {
+    if (kind != kM16None) {
         if (fold) {
             if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
             return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);

@@ -132,8 +132,13 @@ class Gen16(base.Gen):
         # the kernel (tools/kbench.py, one box, profiles/r18_kbench_lm_*.txt): c2 196.6 -> 188.6 us, B8 788.8 -> 751.5, c4 387.9 -> 372.4 (-4.0 .. 4.7 %).
         # Windows (same files): the exp + pack streams anywhere (no check to stay ahead of, no packs to hold back), the V^T reads spread over 74 .. 110;
         # every variant within 0.5 % of the best — the optimum is flat.
+        # Without opt=ct (the f32-scale bodies: fast bodies are fma + exp + pack) the constants live in a[224:255]: at head dim 128 the K fragments
+        # shrink to the 32-register pool of the ct bodies (k-steps 2, 3 are read into the slots of 0, 1), at head dim 64 those registers are free.
         self.lm = "lm" in self.opt
-        assert self.ct or not self.lm, "opt=lm needs the folded scale (opt=ct): its constants live in the registers of the ct repair blocks"
+        self.ones16 = ONES16 if self.ct else [A(224 + 4 * qg, 4) for qg in range(4)]
+        if self.lm and not self.ct:
+            self.kf16 = KF_POOL
+            self.pool = hd == 128
         self.npv, self.nqk = 8 * ndg + (8 if self.lm else 0), 16 * nks
         self.ng = self.npv + self.nqk
         if self.lm:
@@ -176,7 +181,7 @@ class Gen16(base.Gen):
                 if self.lm and dg in (self.NDG // 2 - 1, self.NDG - 1):
                     # the row sums of q group 2 qb + h, this k-step (NDG P.V MFMAs between two links of the LSV chain)
                     h = int(dg == self.NDG - 1)
-                    out.append(mk(self.mfma, LSV, ONES16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), LSV, tag="mfma"))
+                    out.append(mk(self.mfma, LSV, self.ones16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), LSV, tag="mfma"))
         return out
 
     def qk_mfmas(self, par):
@@ -229,12 +234,16 @@ class Gen16(base.Gen):
             # exp and pack, nothing else (the row sums: pv_mfmas of the NEXT body; what replaces the check: __init__)
             prs = self._order()
             out = []
-            for k in range(16 + 2):
-                if k < 16:
+            for k in range(16 + 3):
+                if k < 16 and not self.fold:
                     e = prs[k]
+                    for x in (e, e + 1):
+                        out.append(mk("v_fma_f32", b[x], b[x], A_C, Neg(MC[e // 16][qb]), tag="valu"))
+                if 0 <= k - 1 < 16:
+                    e = prs[k - 1]
                     out += [mk("v_exp_f32", b[e], b[e], tag="trans"), mk("v_exp_f32", b[e + 1], b[e + 1], tag="trans")]
-                if 0 <= k - 2 < 16:
-                    e = prs[k - 2]
+                if 0 <= k - 3 < 16:
+                    e = prs[k - 3]
                     out.append(mk(self.cvt, b[8 * (e // 8) + (e % 8) // 2], b[e], b[e + 1], tag="valu"))
             return out
         ta, tb, ts = TMP[4 * qb], TMP[4 * qb + 1], TMP[4 * qb + 2]
@@ -482,7 +491,8 @@ class Gen16(base.Gen):
             r.append(mk("v_exp_f32", t2, t2))
             r.append(mk("v_mov_b32", MC[h][qb], t))
             r.append(mk("s_nop", 0))
-            r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
+            if not self.lm:         # (lm: with O, at the phase boundary — rare_rescale)
+                r.append(mk("v_mul_f32", LS[h][qb], LS[h][qb], t2))
             r.append(mk("v_mov_b32", FS[h][qb], t2))                     # (1.0 for a row whose reference stayed; one softmax per body: never two pending)
         if not first:               # the q block's first tile: O is still all zeros, nothing to rescale later
             r.append(mk("s_or_b32", S_FLAG, S_FLAG, 1 << qb))
@@ -622,9 +632,15 @@ class Gen16(base.Gen):
             p.emit("v_and_b32", TMP[0], 3, TMP[0])
             for qg in range(4):
                 p.emit("v_cmp_eq_u32", VCC, qg, TMP[0])
-                p.emit("v_cndmask_b32", ONES16[qg][0], 0, TMP[1], VCC)
-                for i in range(1, 4):
-                    p.emit("v_mov_b32", ONES16[qg][i], ONES16[qg][0])
+                if self.ct:
+                    p.emit("v_cndmask_b32", ONES16[qg][0], 0, TMP[1], VCC)
+                    for i in range(1, 4):
+                        p.emit("v_mov_b32", ONES16[qg][i], ONES16[qg][0])
+                else:
+                    p.emit("v_cndmask_b32", TMP[2], 0, TMP[1], VCC)
+                    p.emit("s_nop", 0)
+                    for i in range(4):
+                        p.emit("v_accvgpr_write_b32", self.ones16[qg][i], TMP[2])
         p.emit("s_lshr_b32", S_WAVE, A_LDSW, (g.SLOT_B // 4).bit_length() - 1)
         p.emit("s_mul_i32", S_QSB, S_WAVE, 64 * g.EPI_ROWB)
         p.emit("s_add_u32", S_QSB, S_QSB, g.EPI_BASE)
@@ -902,15 +918,16 @@ def main():
     cfg = base.parse_opts(a.opt)
     if base.is_probe(cfg) and not a.probe:
         sys.exit("fwd_m16_gen.py: %r contains timing-probe options; they need --probe" % a.opt)
-    for hd, bf16, fold in ((hd, bf16, fold) for hd in (128, 64) for bf16 in (False, True) for fold in (False, True)):
+    # per head dim and dtype: the f32-scale body with the sum check (calls flagged FA2_FLAG_EXACT_SCALE: the LSE a backward pass will consume adds the
+    # f32 P), the f32-scale body with the row sums on the matrix pipe ("_lm"), the folded body (row sums on the matrix pipe; opt=nolm: with the sum check)
+    for hd, bf16, kind in ((hd, bf16, kind) for hd in (128, 64) for bf16 in (False, True) for kind in ("", "_lm", "_fold")):
         if True:
             c = dict(cfg)
-            # the folded bodies ship with the row sums on the matrix pipe (opt=lm; opt=nolm builds them with the sum check of the f32-scale bodies)
-            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if fold else ())
-            if fold and "nolm" not in cfg.get("opt", ()):
+            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if kind == "_fold" else ())
+            if kind == "_lm" or (kind == "_fold" and "nolm" not in cfg.get("opt", ())):
                 c["opt"] += ("lm",)
             prog = Gen16(bf16, hd=hd, **c).build()
-            path = os.path.join(a.out, "fa2_fwd_m16_%s%s%s.inc" % ("d64_" if hd == 64 else "", "bf16" if bf16 else "f16", "_fold" if fold else ""))
+            path = os.path.join(a.out, "fa2_fwd_m16_%s%s%s.inc" % ("d64_" if hd == 64 else "", "bf16" if bf16 else "f16", kind))
             base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
             print(path, len(prog.ins), "instructions")
 

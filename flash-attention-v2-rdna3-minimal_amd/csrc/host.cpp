@@ -157,7 +157,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
         asm_kv_len_ok(HD, bf16, p, causal)) {
         // (the folded bodies built on v_mfma_f32_16x16x32 add the rounded P into the row sums — on the matrix pipe; csrc/gen/fwd_m16_gen.py, opt=lm)
-        const bool lsum16 = fold && fa2::fwd_asm_is_m16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+        const bool lsum16 = fa2::fwd_asm_lsum16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
         return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold};
     }
     return {rows == 256 ? FA2_KERNEL_HIP_256 : FA2_KERNEL_HIP_128, 0, rows, false};
@@ -216,7 +216,7 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             f.split = pl;
             f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
             const bool fold = f.split_asm && asm_folds(bf16, p);
-            const bool lsum16 = fold && fa2::fwd_asm_is_m16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+            const bool lsum16 = f.split_asm && fa2::fwd_asm_lsum16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
             f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}
                                  : RangePlan{FA2_KERNEL_HIP_256, 0, 256, false};
             return f;

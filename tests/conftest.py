@@ -36,6 +36,10 @@ FLOOR = {0: 1e-3, 1: 8e-3}          # vs truth, by dtype code (0 = fp16, 1 = bf1
 ATOL = {0: 1e-3, 1: 8e-3}           # vs same-contract oracle
 RTOL = {0: 2e-3, 1: 1.6e-2}
 LSE_TOL = 1e-3                      # vs the oracle run under the SAME scaling contract (fa2_fwd_prescales_q)
+# FA2_CONTRACT_LSUM_P16 (row sums of the ROUNDED P) in bf16: a P carries 2^-9 of relative rounding (0.0028 in log2 units); the kernel rounds P against
+# its deferred reference, the oracle against the running maximum — for a row that one key dominates the two roundings are independent and both show
+# in the LSE (up to 0.0056; measured 0.0050 on the one-hot rows of the redo test); fp16 (2^-12): inside LSE_TOL
+LSE_TOL_P16_BF16 = 6e-3
 # vs float64 truth: where Q is pre-scaled in the I/O dtype (the reference oracle's `scale * q_frags`,
 # pure_torch_ver.py:61) LSE carries that 16-bit rounding; the reference's own L is 6e-3 / 5e-2 off truth on the fixtures
 LSE_TRUTH_TOL = {0: 2e-3, 1: 1.6e-2}

@@ -15,7 +15,9 @@ import asm_emu_harness as harness  # noqa: E402
 
 # ("ct", "lm"): the folded bodies as shipped — row sums on the matrix pipe, fast bodies without adds or a check (FA2_CONTRACT_LSUM_P16: the LSE carries
 # the rounding of P; what the check guarded against sends the item through the safe-mode redo); ("ct",): the folded bodies with the sum check (gen opt=nolm)
-@pytest.fixture(autouse=True, params=[(), ("ct",), ("ct", "lm")], ids=["f32-scale", "folded-scale", "folded-lm"])
+# ("lm",): the f32-scale bodies with the row sums on the matrix pipe (constants in a[224:255], K fragments in the 32-register pool): what bf16 launches and
+# every other f32-scale call that is not flagged FA2_FLAG_EXACT_SCALE run
+@pytest.fixture(autouse=True, params=[(), ("ct",), ("ct", "lm"), ("lm",)], ids=["f32-scale", "folded-scale", "folded-lm", "f32-scale-lm"])
 def m16(request):
     saved = harness.HD, harness.OPT, harness.M16
     harness.HD, harness.OPT, harness.M16 = 128, request.param, True
@@ -97,7 +99,7 @@ def test_m16_persistent_workgroup_seams(seam):
     assert not m.errors, m.errors[:5]
     for (q, k, v, qb), (o, lse) in zip(items, outs):
         r0 = qb * 256
-        o_ref, lse_ref = harness.dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre=bool(harness.OPT))
+        o_ref, lse_ref = harness.dense(q[r0:r0 + o.shape[0]], k, v, causal, bf16=bf16, row0=r0, pre="ct" in harness.OPT)
         assert np.abs(o - o_ref).max() <= (8e-3 if bf16 else 1.1e-3)
         assert np.abs(lse - lse_ref).max() <= ((4e-3 if bf16 else 1e-3) if "lm" in harness.OPT else 1e-4)
 
@@ -135,7 +137,7 @@ def test_m16_kv_split_part_epilogue():
     items = [(q, k, v, 1), (q, k[:256], v[:256], 0, True), (q, k[256:], v[256:], 0, True)]      # parts: tiles [0, 4) and [4, 7) of q block 0
     outs, m = harness.run_items(items, False)
     assert not m.errors, m.errors[:5]
-    pre = bool(harness.OPT)
+    pre = "ct" in harness.OPT
     for (item, (o, lse)) in zip(items, outs):
         qq, kk, vv, qb = item[:4]
         o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre=pre)
@@ -195,13 +197,13 @@ def test_m16_head_dim_64_persistent_seams_and_text(m16_d64, tmp_path):
     outs, m = harness.run_items(items, False)
     assert not m.errors, m.errors[:5]
     for (q, k, v, qb), (o, lse) in zip(items, outs):
-        o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256, pre=bool(harness.OPT))
+        o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + o.shape[0]], k, v, False, row0=qb * 256, pre="ct" in harness.OPT)
         assert np.abs(o - o_ref).max() <= 1.1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in m16_d64 else 1e-4)
     q, k, v = (rng.standard_normal((768, 64)) for _ in range(3))
     outs, m = harness.run_items([(q, k, v, 2), (q, k, v, 0)], True)                  # a causal pair unit
     assert not m.errors, m.errors[:5]
     for qb, (o, lse) in zip((2, 0), outs):
-        o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + 256], k, v, True, row0=qb * 256, pre=bool(harness.OPT))
+        o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + 256], k, v, True, row0=qb * 256, pre="ct" in harness.OPT)
         assert np.abs(o - o_ref).max() <= 1.1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in m16_d64 else 1e-4)
     _assemble(64, tmp_path)
 
@@ -214,7 +216,7 @@ def test_m16_head_dim_64_kv_split_part_epilogue(m16_d64):
     items = [(q, k, v, 1), (q, k[:256], v[:256], 0, True), (q, k[256:], v[256:], 0, True)]
     outs, m = harness.run_items(items, False)
     assert not m.errors, m.errors[:5]
-    pre = bool(harness.OPT)
+    pre = "ct" in harness.OPT
     ltol = 1e-3 if "lm" in m16_d64 else 1e-4
     for (item, (o, lse)) in zip(items, outs):
         qq, kk, vv, qb = item[:4]

@@ -218,7 +218,7 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     # v_mfma_f32_16x16x32, adds the rounded P into the row sums — on the matrix pipe), bf16 does not
     FOLD128 = C.FA2_CONTRACT_PRESCALE_Q | C.FA2_CONTRACT_LSUM_P16
     for shape, dt, causal, contract in (((2, 16, 4096, 4096, 128), torch.float16, False, FOLD128),
-                                        ((2, 16, 4096, 4096, 128), torch.bfloat16, True, 0),
+                                        ((2, 16, 4096, 4096, 128), torch.bfloat16, True, C.FA2_CONTRACT_LSUM_P16),
                                         ((1, 32, 8192, 8192, 128), torch.float16, True, FOLD128),
                                         ((8, 16, 4096, 4096, 128), torch.float16, False, FOLD128)):
         p = _meta_plan(*shape, dt=dt, causal=causal)
@@ -244,7 +244,7 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     assert _meta_plan(2, 16, 4096, 4096, 128, scale=-0.1).kernel == K.FA2_KERNEL_HIP_256
     # the fold needs scale * log2(e) <= 1 (the prescaled Q must stay inside fp16's range): a larger scale runs the f32-scale body of the same schedule
     p = _meta_plan(2, 16, 4096, 4096, 128, scale=0.8)
-    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, 0)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
     p = _meta_plan(2, 16, 4096, 4096, 64, scale=0.8)           # head dim 64 without the fold: the 8-wave kernel non-causal (plan_range)
     assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
     # the KV-split of a partly filled last round needs the caller's workspace (fa2_fwd_ws); whole items and parts share one kernel and one contract
@@ -273,8 +273,10 @@ def test_option_fold_switches_the_contract_and_nothing_else():
     e0 = lib.fa2_get_option(b"epoch")
     with _fa2_lib.options(fold=0):
         assert lib.fa2_get_option(b"epoch") > e0
-        p = _meta_plan(2, 16, 4096, 4096, 128)
-        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, 0)
+        p = _meta_plan(2, 16, 4096, 4096, 128)                 # f32 scale; the row sums of the 16x16x32 bodies stay on the matrix pipe
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, _fa2_lib.FA2_CONTRACT_LSUM_P16)
+        with _fa2_lib.options(asm=3):                          # ... the 32x32x16 bodies add the f32 P
+            assert _meta_plan(2, 16, 4096, 4096, 128).contract == 0
         p = _meta_plan(2, 16, 4096, 4096, 64)                  # head dim 64 fp16 without the fold: back on the 8-wave kernel (non-causal)
         assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_HIP_256, 0)
         assert lib.fa2_fwd_prescales_q(128, 0.1) == 0

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ATOL, FLOOR, LSE_TOL, RTOL
+from conftest import ATOL, FLOOR, LSE_TOL, LSE_TOL_P16_BF16, RTOL
 from oracle import fa2_oracle as fo
 from rocwmma_fattn import _fa2_lib
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction, flash_attn_wmma
@@ -81,7 +81,7 @@ def _check_heads(o, lse, q, k, v, dt, heads, bnhd=False, plan=None):
         o_ref = fo.bits_to_f32(o_ref_bits, dt)
         diff = np.abs(got - o_ref)
         lse_err = np.abs(lse[b:b + 1, h:h + 1].cpu().numpy() - lse_ref).max()
-        lse_tol = 4e-3 if (dt == 1 and flags & fo.LSUM_P16) else LSE_TOL
+        lse_tol = LSE_TOL_P16_BF16 if (dt == 1 and flags & fo.LSUM_P16) else LSE_TOL
         assert not (diff > ATOL[dt] + RTOL[dt] * np.abs(o_ref)).any() and lse_err <= lse_tol, \
             "head %s under contract %d (kernel %d): max |O diff| %.3g, max |LSE diff| %.3g" % ((b, h), plan.contract, plan.kernel, float(diff.max()), float(lse_err))
 
@@ -117,7 +117,9 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     scale_o = max(1.0, float(o_pl.float().abs().max()))
     assert float((o_ws.float() - o_pl.float()).abs().max()) <= ulp * scale_o
     # (head dim 64, fp16: the whole rounds of the split launch run the folded-scale body, the plain call's 128-row kernels scale the f32 product)
-    assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if (D == 64 and dt == 0) else 1e-4)      # (at head dim 128 both calls fold)
+    # (at head dim 128 both calls run the same contract, but their row sums add the ROUNDED P — FA2_CONTRACT_LSUM_P16 — of different KV partitions,
+    #  each against its own reference: rounding-level differences of the LSE, 2^-12 per term in fp16, 2^-9 in bf16)
+    assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if dt == 0 else LSE_TOL_P16_BF16)
     # a fair share of the elements must be bit-identical (the unsplit items are the same launch geometry)
     # (not at head dim 64 in fp16, where the two calls run different scaling contracts: see the LSE bound above)
     same = (o_ws.view(torch.int16) == o_pl.view(torch.int16)).float().mean().item()

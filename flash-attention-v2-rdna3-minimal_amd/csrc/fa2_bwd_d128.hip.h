@@ -188,8 +188,12 @@ constexpr int kBwdKvLdBase = 49152, kBwdKvPSlots = 65536;
 
 // KFOLD: the body whose P side folds scale * log2(e) into its K fragments (rounded once to the I/O dtype) and takes L as the C operand of the S product
 // (csrc/gen/bwd_d128_gen.py, option "kfold"; host: option "fold", bwd_folds in host.cpp).
-template <bool BF16, bool CAUSAL, bool KFOLD>
+// M16 (round 5): the bodies built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dkv_m16_gen.py): same pipeline, rings, roles and operand list; a lane is (n = lane %
+// 16, g = lane / 16) there, the wave's 64 KV rows are four 16-row groups: operands 0, 1, 7, 10 carry the own-row offsets of the four groups, 6 the causal
+// limit of group 0 (the asm derives the others and the lane's L / -delta staging offset), the fragment / epilogue addresses differ.
+template <bool BF16, bool CAUSAL, bool KFOLD, bool M16 = false>
 __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p) {
+    static_assert(!(M16 && KFOLD), "the 16x16x32 dK / dV bodies scale the f32 scores");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,6 +226,18 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
         fo[kvb] = kr * f_rowb + 16u * hi;
         lim[kvb] = CAUSAL ? kvrow - kBwdTile * tile0 - 4 * hi : -(1 << 30);
     }
+    const uint32_t n16 = lane & 15, g4 = lane >> 4;
+    uint32_t fo2 = 0, fo3 = 0;
+    if constexpr (M16) {
+        uint32_t f[4];
+#pragma unroll
+        for (int kvg = 0; kvg < 4; ++kvg) {
+            const int kvrow = kvw0 + 16 * kvg + (int)n16;
+            f[kvg] = (uint32_t)(kvrow < p.Nkv ? kvrow : p.Nkv - 1) * f_rowb + 16u * g4;
+        }
+        fo[0] = f[0]; fo[1] = f[1]; fo2 = f[2]; fo3 = f[3];
+        lim[0] = CAUSAL ? kvw0 + (int)n16 - kBwdTile * tile0 - 4 * (int)g4 : -(1 << 30);
+    }
     const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
     const uint32_t gd0 = drow * g_rowb + ((dslot ^ bwd_swz(drow)) << 4);
 #ifdef FA2_BWD_QSPLIT     // (bodies generated with option "qsplit": of a pair's four Q pieces the P side stages row quad 0, the dS side quads 1..3)
@@ -231,12 +247,15 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
 #endif
     const uint32_t qdrow = qrow0 + (lane >> 4);
     const uint32_t qd0 = qdrow * q_rowb + ((dslot ^ bwd_swz(qdrow)) << 4);
-    const uint32_t kr0 = (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
-    const uint32_t vr0 = trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
-    const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = 16u * hi + 512u * role, l4 = 4u * lane;
+    const uint32_t tq16 = 4u * g4 + (n16 >> 2);
+    const uint32_t kr0 = M16 ? n16 * 256u + ((g4 ^ bwd_swz(n16)) << 4) : (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
+    const uint32_t vr0 = M16 ? tq16 * 256u + ((((n16 & 3u) >> 1) ^ bwd_swz(tq16)) << 4) + 8u * (n16 & 1u)
+                             : trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
+    const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = (M16 ? 16u * g4 : 16u * hi) + 512u * role, l4 = M16 ? fo3 : 4u * lane;
+    if constexpr (M16) lim[1] = (int)fo2;
     const uint32_t ldm0 = pair == 0 ? kBwdKvLdBase + 512u * role : 0u;        // pair 0's waves stage L (P side) / -delta (dS side) for the workgroup
-    const uint32_t epi = wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
+    const uint32_t epi = M16 ? wave * 64 * kBwdEpiRowB + n16 * kBwdEpiRowB + g4 * 8 : wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
 
     const uint64_t fbase = role ? (uint64_t)((const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1]) : (uint64_t)((const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1]);
     const uint64_t qa = (uint64_t)((const uint16_t*)p.q + b * p.qs[0] + h * p.qs[1]);
@@ -256,7 +275,19 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
       "s"(fbase), "s"(qrs), "s"(grs), "s"(lrs), "s"(c), "s"(oscale), "s"(n), "s"(qoff0), "s"(goff0), "s"(loff0), "s"(q_tile),     \
       "s"(g_tile), "s"(q_row4), "s"(g_row4), "s"(ldsw), "s"(role), "s"(ldm0), "s"(ldswq)                                          \
     :
-    if constexpr (BF16 && KFOLD) {
+    if constexpr (M16 && BF16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_m16_bf16.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    } else if constexpr (M16) {
+        asm volatile(
+#include FA2_BWD_INC(fa2_bwd_dkv_m16_f16.inc)
+            FA2_BWD_KV_OPERANDS
+#include FA2_BWD_INC(fa2_bwd_dkv_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16 && KFOLD) {
         asm volatile(
 #include FA2_BWD_INC(fa2_bwd_dkv_d128_bf16_fold.inc)
             FA2_BWD_KV_OPERANDS

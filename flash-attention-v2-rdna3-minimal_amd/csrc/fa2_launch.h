@@ -18,7 +18,7 @@ namespace fa2 {
 // read once when the library is loaded).  They select between kernels that all satisfy the same contract.
 struct Options {
     std::atomic<int> rows{0};      // FA2_ROWS: 0 = heuristic, 128 | 256 = rows per forward workgroup
-    std::atomic<int> asm_mask{195};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 = the head-dim-128 forward / dQ-pass
+    std::atomic<int> asm_mask{451};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 / 8 = the head-dim-128 forward / dQ-pass / dK-dV-pass
                                        // bodies built on v_mfma_f32_16x16x32 (round 5; off: the 32x32x16 bodies everywhere)
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
@@ -158,7 +158,9 @@ FA2_HIDDEN int launch_bwd_bias_hip_bf16(int HD, const BwdParams& p, bool causal,
 // neg_delta: the dQ pass writes -delta (the hand-scheduled dK/dV pass reads it as such; the HIP dK/dV passes read +delta)
 // kfold: the dK / dV body whose P side folds scale * log2(e) into its K fragments (option "fold"; host.cpp: bwd_folds)
 // dq16: the dQ pass built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dq_m16_gen.py)
-FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream, bool dq16 = false);
+// dkv16: likewise the dK / dV pass (csrc/gen/bwd_dkv_m16_gen.py)
+FA2_HIDDEN int launch_bwd_d128(bool bf16, const BwdParams& p, bool causal, int parts, bool neg_delta, bool kfold, hipStream_t stream, bool dq16 = false,
+                               bool dkv16 = false);
 
 constexpr int kBwdAsmParts = 3;      // passes the hand-scheduled backward covers: bit 0 = dQ, bit 1 = dK / dV
 

@@ -298,7 +298,7 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
         if (!(want & part)) continue;
         int rc;
-        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, kfold, stream, (m & 128) != 0);     // option "asm" bit 7: the 16x16x32 dQ pass
+        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, kfold, stream, (m & 128) != 0, (m & 256) != 0);     // option "asm" bits 7 / 8: the 16x16x32 dQ / dK-dV pass
         else rc = bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, part, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, part, stream);
         if (rc) return rc;
     }

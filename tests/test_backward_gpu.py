@@ -268,7 +268,7 @@ def test_pinned_workgroup_shapes_and_kernel_families():
     assert groups["small"] and groups["big"], groups
     n = 0
     for opts, names in (({"rows": 256}, groups["small"]), ({"rows": 128}, groups["big"]), ({"asm": 1}, groups["small"] + groups["big"]),
-                        ({"asm": 1, "rows": 256}, groups["small"]), ({"asm": 67}, groups["small"] + groups["big"])):     # 67: the 32x32x16 dQ pass (bit 7 clear)
+                        ({"asm": 1, "rows": 256}, groups["small"]), ({"asm": 67}, groups["small"] + groups["big"])):     # 67: the 32x32x16 dQ and dK / dV passes (bits 7, 8 clear)
         with _fa2_lib.options(**opts):
             for name in names:
                 n += _expand_and_call(getattr(mod, name))

@@ -18,15 +18,21 @@ DQ = gen.DQ
 _PROGS = {}
 QSPLIT = False          # mirror of the shell's -DFA2_BWD_QSPLIT (programs built with opt "qsplit")
 DQ_M16 = False          # the dQ pass built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dq_m16_gen.py) instead of GenDQ
+DKV_M16 = False         # the dK / dV pass built on v_mfma_f32_16x16x32 (csrc/gen/bwd_dkv_m16_gen.py) instead of GenDKV
 
 
 def program(kind, bf16):
     if kind == "dq" and DQ_M16:
         kind = "dq16"
+    if kind == "dkv" and DKV_M16:
+        kind = "dkv16"
     if (kind, bf16) not in _PROGS:
         if kind == "dq16":
             import bwd_dq_m16_gen
             _PROGS[(kind, bf16)] = bwd_dq_m16_gen.GenDQ16(bf16).build()
+        elif kind == "dkv16":
+            import bwd_dkv_m16_gen
+            _PROGS[(kind, bf16)] = bwd_dkv_m16_gen.GenDKV16(bf16).build()
         else:
             _PROGS[(kind, bf16)] = (gen.GenDQ if kind == "dq" else gen.GenDKV)(bf16).build()
     return _PROGS[(kind, bf16)]
@@ -220,6 +226,20 @@ def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
     v[9] = (hi * 16 + role * 512).astype(np.uint32)
     v[10] = (lane * 4).astype(np.uint32)
     v[11] = (w * 64 * KV.EPI_ROWB + l31 * KV.EPI_ROWB + hi * 16).astype(np.uint32)
+    if DKV_M16:
+        # the shell's M16 branch (fa2_bwd_d128.hip.h): lane = (n = lane % 16, g = lane / 16); operands 0, 1, 7, 10 carry the own-row offsets of the
+        # four 16-row KV groups, 6 the causal limit of group 0
+        n16, g4 = lane & 15, lane >> 4
+        for kvg, slot in enumerate((0, 1, 7, 10)):
+            kr = np.minimum(kvw0 + 16 * kvg + n16, Nkv - 1).astype(np.int64)
+            v[slot] = (kr * rb + 16 * g4).astype(np.uint32)
+        lim = (kvw0 + n16 - 32 * tile0 - 4 * g4) if causal else np.full(64, -(1 << 30))
+        v[6] = lim.astype(np.int32).view(np.uint32)
+        v[4] = (n16 * 256 + ((g4 ^ gen.f_swz(n16)) << 4)).astype(np.uint32)
+        tq = 4 * g4 + (n16 >> 2)
+        v[5] = (tq * 256 + ((((n16 & 3) >> 1) ^ gen.f_swz(tq)) << 4) + 8 * (n16 & 1)).astype(np.uint32)
+        v[9] = (g4 * 16 + role * 512).astype(np.uint32)
+        v[11] = (w * 64 * KV.EPI_ROWB + n16 * KV.EPI_ROWB + g4 * 8).astype(np.uint32)
     args = {k: Reg("v", k) for k in range(KV.N_VARGS)}
     args[12] = _pair(bases["v"] if role else bases["k"])
     args[13], args[14] = _srd(bases["q"], Nq), _srd(bases["do"], Nq)

@@ -40,6 +40,12 @@ def fillers(nofill=(), fill=None):
                 lst.append("v_add_f32 v%d, v%d, v%d" % (216 + j % 2, 216 + j % 2, 200 + (j * 3) % 8))
             elif kind == "cvt":
                 lst.append("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (220 + j % 4, 200 + (2 * j) % 8, 200 + (2 * j + 1) % 8))
+            elif kind == "cvtrtz":      # the pack with round-toward-zero / by byte permute (bf16 truncation): cheaper than the RNE pack?
+                lst.append("v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (220 + j % 4, 200 + (2 * j) % 8, 200 + (2 * j + 1) % 8))
+            elif kind == "perm":
+                lst.append("v_perm_b32 v%d, v%d, v%d, v183" % (220 + j % 4, 200 + (2 * j) % 8, 200 + (2 * j + 1) % 8))
+            elif kind == "cvtbf":
+                lst.append("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (220 + j % 4, 200 + (2 * j) % 8, 200 + (2 * j + 1) % 8))
             elif kind == "kread":
                 lst.append("ds_read_b128 v[%d:%d], %%3 offset:%d" % (224 + 4 * (j % 4), 227 + 4 * (j % 4), 1024 * (j % 16)))
             else:
@@ -137,7 +143,7 @@ def kernel(name, shape, nofill=(), fill=None, pv_steps=None, extra=None, hd=128)
     for i in range(8):
         lines.append("v_mov_b32 v%d, 0xbf000000" % (208 + i))        # exp sources: -0.5
         lines.append("v_mov_b32 v%d, 0" % (200 + i))
-    lines += ["v_mov_b32 v216, 0", "v_mov_b32 v217, 0"]
+    lines += ["v_mov_b32 v216, 0", "v_mov_b32 v217, 0", "v_mov_b32 v183, 0x07060302"]
     for i in range(16):
         lines.append("v_mov_b32 v%d, 0x3c003c00" % (184 + i))       # the ones operand of the row-sum MFMAs
     for i in range(200):
@@ -240,6 +246,11 @@ def main():
     FILL64 = {"exp": 64, "add": 64, "cvt": 32, "kread": 8, "vread": 16}
     variants += [("d64_body32", 32, (), FILL64, None, None, 64), ("d64_body16", 16, (), FILL64, None, None, 64),
                  ("d64_body16_sum16", 16, ("add",), FILL64, None, "sum16", 64), ("d64_body32_noadd", 32, ("add",), FILL64, None, None, 64)]
+    # the lm body (no adds, 8 sum MFMAs) with other ways to pack P
+    LM = {"exp": 64, "cvt": 32, "kread": 16, "vread": 32}
+    variants += [("lm_cvt", 16, (), LM, None, "sum16", 128), ("lm_cvtrtz", 16, (), dict(LM, cvt=0, cvtrtz=32), None, "sum16", 128),
+                 ("lm_perm", 16, (), dict(LM, cvt=0, perm=32), None, "sum16", 128), ("lm_cvtbf", 16, (), dict(LM, cvt=0, cvtbf=32), None, "sum16", 128),
+                 ("lm_nocvt", 16, (), dict(LM, cvt=0), None, "sum16", 128)]
     if len(sys.argv) > 2:
         variants = [v for v in variants if v[0] in sys.argv[2].split(",")]
     src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv, ex, hd) for n, s, nf, fl, pv, ex, hd in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))

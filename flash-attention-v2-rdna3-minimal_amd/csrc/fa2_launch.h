@@ -18,7 +18,7 @@ namespace fa2 {
 // read once when the library is loaded).  They select between kernels that all satisfy the same contract.
 struct Options {
     std::atomic<int> rows{0};      // FA2_ROWS: 0 = heuristic, 128 | 256 = rows per forward workgroup
-    std::atomic<int> asm_mask{451};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 / 8 = the head-dim-128 forward / dQ-pass / dK-dV-pass
+    std::atomic<int> asm_mask{963};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 / 8 = the head-dim-128 forward / dQ-pass / dK-dV-pass
                                        // bodies built on v_mfma_f32_16x16x32 (round 5; off: the 32x32x16 bodies everywhere)
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
@@ -104,26 +104,26 @@ FA2_HIDDEN int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t s
 // hand-scheduled forward, head dim exactly 128 or 64 (fwd_asm.cpp)
 // fold: the body that folds scale * log2(e) into Q (FA2_CONTRACT_PRESCALE_Q) instead of scaling the f32 product
 // m16: the body built on v_mfma_f32_16x16x32 (head dim 128, f32 scale, whole items only; csrc/gen/fwd_m16_gen.py) where it applies
-FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16 = false);
+// m16: 0 = the 32x32x16 bodies, 1 = the 16x16x32 bodies with the sum check (option "asm" bit 6), 2 = ... with the row sums on the matrix pipe (bits 6 and 9)
+FA2_HIDDEN int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, int m16 = 0);
+inline int fwd_m16_mode(int asm_mask) { return (asm_mask & 64) ? ((asm_mask & 512) ? 2 : 1) : 0; }
 // Does launch_fwd_asm(..., m16) run a body built on v_mfma_f32_16x16x32 (csrc/gen/fwd_m16_gen.py)?  ONE predicate: the launcher executes it, the plan
 // reports its contract (the folded 16 x 16 bodies add the ROUNDED P into the row sums: FA2_CONTRACT_LSUM_P16).  fwd_asm.cpp has the measurements.
-enum { kM16None = 0, kM16F32 = 1, kM16Fold = 2, kM16F32Lm = 3 };
-inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
+enum { kM16None = 0, kM16F32 = 1, kM16Fold = 2, kM16F32Lm = 3, kM16FoldNoLm = 4 };
+inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, int m16) {
     if (!m16) return kM16None;
-    if (fold) return (HD == 64 || p.vs[2] % 32 == 0) ? kM16Fold : kM16None;           // folded scale, row sums on the matrix pipe
+    const bool lm = m16 == 2;
+    // folded scale: row sums on the matrix pipe; without (m16 == 1) head dim 128 takes the folded sum-check body, head dim 64 the 32x32x16 bodies
+    if (fold) return (HD == 64 ? lm : p.vs[2] % 32 == 0) ? (lm ? kM16Fold : kM16FoldNoLm) : kM16None;
     // f32 scale.  A call flagged FA2_FLAG_EXACT_SCALE (a forward that will be differentiated) keeps the f32 row sums: fp16 at head dim 128 on the
     // 16 x 16 body with the sum check, everything else on the 32x32x16 bodies; other calls take the 16 x 16 bodies with the row sums on the matrix pipe
     // (head dim 128; at head dim 64 the f32-scale 16 x 16 bodies do not beat the 32x32x16 body: profiles/r18_kbench_f32lm*.txt)
     if (HD != 128) return kM16None;
     if (p.exact_scale) return !bf16 ? kM16F32 : kM16None;
-#ifdef FA2_NO_F32_LM        // (developer A/B: the routing before the f32-scale lm bodies existed)
-    return !bf16 ? kM16F32 : kM16None;
-#else
-    return kM16F32Lm;
-#endif
+    return lm ? kM16F32Lm : (!bf16 ? kM16F32 : kM16None);
 }
-inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) { return fwd_asm_m16_kind(HD, bf16, p, fold, m16) != kM16None; }
-inline bool fwd_asm_lsum16(int HD, bool bf16, const FwdParams& p, bool fold, bool m16) {
+inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, int m16) { return fwd_asm_m16_kind(HD, bf16, p, fold, m16) != kM16None; }
+inline bool fwd_asm_lsum16(int HD, bool bf16, const FwdParams& p, bool fold, int m16) {
     const int k = fwd_asm_m16_kind(HD, bf16, p, fold, m16);
     return k == kM16Fold || k == kM16F32Lm;
 }

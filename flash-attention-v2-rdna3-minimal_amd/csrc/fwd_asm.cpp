@@ -51,7 +51,7 @@ static int launch_asm_hd(const FwdParams& p, bool causal, bool fold, hipStream_t
     return causal ? launch_asm_t<HD, BF16, true, false>(p, stream) : launch_asm_t<HD, BF16, false, false>(p, stream);
 }
 
-int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, bool m16) {
+int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold, hipStream_t stream, int m16) {
     // The v_mfma_f32_16x16x32 bodies: head dim 128.  Measured against the 32x32x16 bodies on one box (tools/kbench.py,
     // profiles/r16_kbench_m16_*.txt): folded scale fp16 c2 +4.7 %, c4 +4.6 %, B8 +3.8 %; f32 scale fp16 +3.3 % / +3.3 % / +1.1 %; f32 scale bf16
     // -0.5 .. +0.5 % (c3, c2-shape, B8: the bf16 32x32x16 MFMA is the cheaper one to begin with, profiles/mfma_peak.json) -> those stay where they were.
@@ -74,14 +74,18 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
         if (bf16) return causal ? launch_asm_t<128, true, true, false, true, true>(p, stream) : launch_asm_t<128, true, false, false, true, true>(p, stream);
         return causal ? launch_asm_t<128, false, true, false, true, true>(p, stream) : launch_asm_t<128, false, false, false, true, true>(p, stream);
     }
-    if (HD == 64 && kind != kM16None) {
-        if (bf16) return causal ? launch_asm_t<64, true, true, true, true>(p, stream) : launch_asm_t<64, true, false, true, true>(p, stream);
-        return causal ? launch_asm_t<64, false, true, true, true>(p, stream) : launch_asm_t<64, false, false, true, true>(p, stream);
+    if (HD == 64 && kind != kM16None) {          // (kM16Fold)
+        if (bf16) return causal ? launch_asm_t<64, true, true, true, true, true>(p, stream) : launch_asm_t<64, true, false, true, true, true>(p, stream);
+        return causal ? launch_asm_t<64, false, true, true, true, true>(p, stream) : launch_asm_t<64, false, false, true, true, true>(p, stream);
+    }
+    if (kind == kM16FoldNoLm) {                  // option "asm" bit 9 clear: the folded sum-check bodies (in-place repair instead of the item redo)
+        if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
+        return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);
     }
     if (kind != kM16None) {
         if (fold) {
-            if (bf16) return causal ? launch_asm_t<128, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true>(p, stream);
-            return causal ? launch_asm_t<128, false, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true>(p, stream);
+            if (bf16) return causal ? launch_asm_t<128, true, true, true, true, true>(p, stream) : launch_asm_t<128, true, false, true, true, true>(p, stream);
+            return causal ? launch_asm_t<128, false, true, true, true, true>(p, stream) : launch_asm_t<128, false, false, true, true, true>(p, stream);
         }
         if (bf16) return causal ? launch_asm_t<128, true, true, false, true>(p, stream) : launch_asm_t<128, true, false, false, true>(p, stream);
         return causal ? launch_asm_t<128, false, true, false, true>(p, stream) : launch_asm_t<128, false, false, false, true>(p, stream);

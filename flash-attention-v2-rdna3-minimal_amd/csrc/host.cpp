@@ -157,7 +157,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
         asm_kv_len_ok(HD, bf16, p, causal)) {
         // (the folded bodies built on v_mfma_f32_16x16x32 add the rounded P into the row sums — on the matrix pipe; csrc/gen/fwd_m16_gen.py, opt=lm)
-        const bool lsum16 = fa2::fwd_asm_lsum16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+        const bool lsum16 = fa2::fwd_asm_lsum16(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
         return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold};
     }
     return {rows == 256 ? FA2_KERNEL_HIP_256 : FA2_KERNEL_HIP_128, 0, rows, false};
@@ -167,7 +167,7 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     const RangePlan r = plan_range(HD, bf16, p, causal);
     // option "asm" bit 6 (default): head dim 128 launches of whole items take the bodies built on v_mfma_f32_16x16x32 (round 5; fwd_asm.cpp)
     if (r.kernel == FA2_KERNEL_ASM)
-        return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+        return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, r.rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, r.rows, false, stream);
 }
 
@@ -216,7 +216,7 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             f.split = pl;
             f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
             const bool fold = f.split_asm && asm_folds(bf16, p);
-            const bool lsum16 = f.split_asm && fa2::fwd_asm_lsum16(HD, bf16, p, fold, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+            const bool lsum16 = f.split_asm && fa2::fwd_asm_lsum16(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
             f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}
                                  : RangePlan{FA2_KERNEL_HIP_256, 0, 256, false};
             return f;
@@ -253,7 +253,7 @@ int launch_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, hipStre
             // the hand-scheduled persistent kernel: every workgroup works through its whole items, then its parts (the item seam hides a
             // part's load phase like any other item's; the block stores a part's f32 tile itself)
             p.item_cap = f.split.full_items + f.split.split_items * f.split.nsplit;
-            rc = fa2::launch_fwd_asm(HD, bf16, p, false, f.main.fold, stream, (fa2::options().asm_mask.load(std::memory_order_relaxed) & 64) != 0);
+            rc = fa2::launch_fwd_asm(HD, bf16, p, false, f.main.fold, stream, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
         } else {
             rc = bf16 ? fa2::launch_fwd_hip_bf16(HD, p, false, 256, false, stream) : fa2::launch_fwd_hip_f16(HD, p, false, 256, false, stream);
         }

@@ -319,7 +319,10 @@ int fa2_fwd_prescales_q(int D, float scale);
  *                              forward body for non-causal launches too (default: causal only), bit 6: head dim 128 forward launches of whole items take the
  *                              bodies built on v_mfma_f32_16x16x32 (round 5: +3 .. 5 % on a power-limited chip, same contracts; KV-split launches and bit 6
  *                              clear: the 32x32x16 bodies), bits 7 / 8: the same for the dQ / the dK-dV pass of the head dim 128 backward (-7 .. 8 % of either
- *                              pass on fp16); default 451.  0 = compiler-scheduled HIP kernels everywhere
+ *                              pass on fp16), bit 9: the 16x16x32 forward bodies keep their row sums on the matrix pipe (FA2_CONTRACT_LSUM_P16; -4 % of a
+ *                              launch; no in-place repair: fp16 rows that outgrow the reference of their first tiles by 16 octaves cost their
+ *                              item a second sweep — clear the bit for such data: the sum-check bodies repair in place); default 963.
+ *                              0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
  *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws / fa2_bwd_ws may split the last round of workgroups (0: they are fa2_fwd / fa2_bwd)
    "fold"      FA2_FOLD       1 (default) | 0 | 2 — which launches of the hand-scheduled forward bodies fold scale*log2(e) into Q

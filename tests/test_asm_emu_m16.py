@@ -227,3 +227,21 @@ def test_m16_head_dim_64_kv_split_part_epilogue(m16_d64):
     o = o1 * np.exp2(l1 - lse)[:, None] + o2 * np.exp2(l2 - lse)[:, None]
     o_ref, lse_ref = harness.dense(q[:256], k, v, False, pre=pre)
     assert np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= 1e-3
+
+
+def test_m16_items_after_a_redo_start_in_safe_mode():
+    """The shell's sticky bit (fa2_fwd_d128.hip.h): once an item of a persistent workgroup went through the safe-mode redo, the items the workgroup
+    takes after it start in safe mode — prefetched through the item seam like any other (flag bits 0 and 4 together) — and are exact."""
+    rng = np.random.default_rng(99)
+    q = rng.standard_normal((512, 128)) * 3
+    k = rng.standard_normal((704, 128)) * 3
+    v = rng.standard_normal((704, 128))
+    k[200] = q[5] * 4                       # a hard spike in the first item: P = inf in a fast body -> flag -> redo
+    items = [(q, k, v, 0), (q, k, v, 1), (rng.standard_normal((256, 128)), rng.standard_normal((320, 128)), rng.standard_normal((320, 128)), 0)]
+    outs, m = harness.run_items(items, False)
+    assert not m.errors, m.errors[:5]
+    assert m.redos == 1                     # the first item only; the two after it never entered a fast body
+    lm = "lm" in harness.OPT
+    for (qq, kk, vv, qb), (o, lse) in zip(items, outs):
+        o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre="ct" in harness.OPT)
+        assert np.abs(o - o_ref).max() <= 3e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if lm else 1e-4)

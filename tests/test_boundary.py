@@ -288,8 +288,10 @@ def test_option_fold_switches_the_contract_and_nothing_else():
     p = _meta_plan(2, 16, 4096, 4096, 128)
     assert p.contract == fold128
     # the rounded-P row sums belong to the folded bodies built on v_mfma_f32_16x16x32 (option "asm" bit 6); the 32x32x16 bodies add the f32 P
-    with _fa2_lib.options(asm=3):
-        assert _meta_plan(2, 16, 4096, 4096, 128).contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
+    # (option "asm" bits 6 and 9; bit 9 clear: the 16x16x32 bodies with the sum check and its in-place repair — for fp16 data with very peaky rows)
+    for mask in (3, 67, 451):
+        with _fa2_lib.options(asm=mask):
+            assert _meta_plan(2, 16, 4096, 4096, 128).contract == _fa2_lib.FA2_CONTRACT_PRESCALE_Q
 
 
 def test_plan_struct_in_the_header_matches_the_ctypes_structure():

@@ -170,6 +170,7 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             addr += (arr.size + 0xffff) & ~0xffff
     m = None
     outs = []
+    sticky = 0           # the shell's bit 5: an item of this workgroup was redone -> the items after it start in safe mode (fa2_fwd_d128.hip.h)
     for it, item in enumerate(items):
         q, k, v, qblk = item[:4]
         Nq, Nkv = q.shape[0], k.shape[0]
@@ -177,7 +178,7 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
         if it + 1 < len(items):
             nq_, nk_, _, nqblk = items[it + 1][:4]
             nxt = (nqblk, nq_.shape[0], bases[it + 1][0], bases[it + 1][1], bases[it + 1][2], nk_.shape[0])
-        flags = (1 if it > 0 else 0) | (2 if nxt is not None else 0)
+        flags = (1 if it > 0 else 0) | (2 if nxt is not None else 0) | sticky
         if nxt is not None:
             n_nk = (nxt[5] + 63) // 64
             if causal:
@@ -202,7 +203,8 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             # safe mode (flag bit 4), nothing staged (the failed attempt's seam bodies fetched the NEXT item's Q / K / V over this item's)
             m.lds[geo().FAIL_OFF:geo().FAIL_OFF + 16] = 0
             m.redos += 1
-            flags = (flags & ~1) | 16
+            sticky = 16 | 32
+            flags = (flags & ~1) | sticky
             wa = [wave_args(w, qblk, Nq, Nkv, causal, scale, bases[it][0], bases[it][1], bases[it][2], flags=flags, nxt=nxt, ws_base=ws_addr.get(it, 0))
                   for w in range(4)]
             m.reenter(wa)

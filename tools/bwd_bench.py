@@ -98,7 +98,7 @@ def main():
         for lib in libs.values():
             if folds != [None]:
                 lib.fa2_set_option(b"fold", 1)
-            lib.fa2_set_option(b"asm", 451)
+            lib.fa2_set_option(b"asm", 963)
             lib.fa2_set_option(b"bwd_parts", 3)
         fwd_flops = 4.0 * B * H * N * N * D * (0.5 if causal else 1.0)
         print("-- %s: B%d H%d N%d D%d %s causal=%d  parts=%d" % (cname, B, H, N, D, str(dt)[6:], causal, a.parts))

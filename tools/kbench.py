@@ -63,7 +63,7 @@ def build(specs):
     for s in specs:
         name, _, flags = s.partition(":")
         fl = [f for f in flags.split(",") if f]
-        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "m16gen=", "only=", "opts="))]
+        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "m16gen=", "dq16gen=", "dkv16gen=", "only=", "opts="))]
         only = None if extra else ["fwd_asm", "bwd_asm"]          # generator-only variants: recompile just the units that include the bodies
         for f in fl:
             if f.startswith("only="):                            # only=fwd_asm+host: -D flags that matter to these units alone
@@ -76,6 +76,10 @@ def build(specs):
                 opts["bwd_d128_gen.py"] = f[5:].replace(";", ",")
             if f.startswith("m16gen="):      # options of csrc/gen/fwd_m16_gen.py (the 16x16x32 body)
                 opts["fwd_m16_gen.py"] = f[7:].replace(";", ",")
+            if f.startswith("dq16gen="):     # ... of the 16x16x32 backward passes (csrc/gen/bwd_dq_m16_gen.py, bwd_dkv_m16_gen.py; timed by tools/bwd_bench.py --libs)
+                opts["bwd_dq_m16_gen.py"] = f[8:].replace(";", ",")
+            if f.startswith("dkv16gen="):
+                opts["bwd_dkv_m16_gen.py"] = f[9:].replace(";", ",")
         gdir = os.path.join(VAR_DIR, name + "_gen")
         os.makedirs(gdir, exist_ok=True)
         b.generate(gdir, opts, probe=True)

@@ -472,6 +472,19 @@ class Machine:
             self.wr32(w, ops[0], (self.rd32(w, ops[1]).astype(np.uint64) + self.rd32(w, ops[2]).astype(np.uint64)).astype(np.uint32))
         elif op == "v_cvt_f32_u32":
             self.wr32(w, ops[0], self.rd32(w, ops[1]).astype(np.float32))
+        elif op == "v_sub_u32":
+            self.wr32(w, ops[0], (self.rd32(w, ops[1]).astype(np.int64) - self.rd32(w, ops[2]).astype(np.int64)).astype(np.uint32))
+        elif op == "v_max_u32":
+            self.wr32(w, ops[0], np.maximum(self.rd32(w, ops[1]), self.rd32(w, ops[2])))
+        elif op == "v_pk_mul_f16":      # two f16 products, each rounded to f16 (denormals kept)
+            a_, b_ = self.rd32(w, ops[1]), self.rd32(w, ops[2])
+            out = np.zeros(64, dtype=np.uint32)
+            for half in (0, 16):
+                x = f16_to_f32(((a_ >> half) & 0xffff).astype(np.uint16))
+                y = f16_to_f32(((b_ >> half) & 0xffff).astype(np.uint16))
+                with np.errstate(invalid="ignore", over="ignore"):
+                    out |= f32_to_f16_bits((x.astype(np.float64) * y.astype(np.float64)).astype(np.float32)).astype(np.uint32) << half
+            self.wr32(w, ops[0], out)
         elif op in ("v_pk_add_f32", "v_pk_fma_f32"):
             d, a_, b_ = R(0), R(1), R(2)
             neg2 = "1]" in str(ins.mods.get("neg_lo", ""))

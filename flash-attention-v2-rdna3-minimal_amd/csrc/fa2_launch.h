@@ -114,7 +114,8 @@ inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, in
     if (!m16) return kM16None;
     const bool lm = m16 == 2;
     // folded scale: row sums on the matrix pipe; without (m16 == 1) head dim 128 takes the folded sum-check body, head dim 64 the 32x32x16 bodies
-    if (fold) return (HD == 64 ? lm : p.vs[2] % 32 == 0) ? (lm ? kM16Fold : kM16FoldNoLm) : kM16None;
+    // (p.D < HD, a head dim below the body's: the general form of the LDS-DMA offsets, any row pitch — csrc/gen/fwd_m16_gen.py: trim_offsets)
+    if (fold) return (HD == 64 ? lm : (p.vs[2] % 32 == 0 || p.D < HD)) ? (lm ? kM16Fold : kM16FoldNoLm) : kM16None;
     // f32 scale.  A call flagged FA2_FLAG_EXACT_SCALE (a forward that will be differentiated) keeps the f32 row sums: fp16 at head dim 128 on the
     // 16 x 16 body with the sum check, everything else on the 32x32x16 bodies; other calls take the 16 x 16 bodies with the row sums on the matrix pipe
     // (head dim 128; at head dim 64 the f32-scale 16 x 16 bodies do not beat the 32x32x16 body: profiles/r18_kbench_f32lm*.txt)

@@ -301,6 +301,86 @@ class Gen16(base.Gen):
     def stream_pack(self, qb, par):
         return [] if self.lm else super().stream_pack(qb, par)          # (lm: packed by stream_exp_sum, a pair behind its exps)
 
+    def trim_offsets(self, image, dst, a0, s_piece):
+        """Head dims BELOW the body's (flag bits 8 .. 12 = nG, the 16-byte granules a row really has; D = 40 / 48 / 56 on the head-dim-64 body, 72 .. 120 on
+        the 128 one): the LDS-DMA source offsets of an image's pieces in their general form.  A lane fills LDS slot (row r0 + RPP i, slot dslot) of piece i
+        with the row's LOGICAL granule gl_i (the inverse of the image's read swizzle).  The fast path derives piece i from piece 0 by flipping offset bits,
+        which needs a row pitch that is a multiple of the image row; here the pitch is whatever the caller's rows are (80 bytes at D = 40), so the offset
+        is re-derived: a0 + ((gl_i - gl_0) << 4) + i * (RPP rows), and a granule the row does not have (gl_i >= nG) gets an offset beyond every
+        descriptor (bit 31): the load returns zeros — the image's padded columns are zero, so are the Q fragments read from it, and nothing of a
+        neighbouring row enters a product.  image: 'k' (also Q: the same swizzle), 'v'.  s_piece: SGPR holding RPP * row bytes - 1024 (the source stride
+        between two pieces, minus the 1024 the instruction offset adds).  Uses TMP[0:8], S_D, S_TMP (after the caller is done with it)."""
+        p, g = self.p, self.g
+        G = g.ROWB // 16
+        rpb = max(1, 256 // g.ROWB)
+        kmask, vmask = min(G, 16) - 1, min(g.ROWB // 64, 4) - 1
+        lane, dslot, r0, mark, gl0, t, t2 = TMP[7], TMP[6], TMP[5], TMP[4], TMP[3], TMP[0], TMP[1]
+        p.emit("v_mbcnt_lo_u32_b32", lane, -1, 0)
+        p.emit("v_mov_b32", mark, 0x80000000)
+        p.emit("v_mbcnt_hi_u32_b32", lane, -1, lane)
+        p.emit("s_lshr_b32", S_D, A_FLAGS, 8)
+        p.emit("s_and_b32", S_D, S_D, 31)
+        p.emit("v_and_b32", dslot, G - 1, lane)
+        p.emit("v_lshrrev_b32", r0, G.bit_length() - 1, lane)
+
+        def granule(dst_, i):
+            """dst_ = the logical granule this lane's slot of piece i holds"""
+            p.emit("v_add_u32", t2, g.RPP * i, r0)                         # row of the piece's lane (wave offsets are multiples of 16: they drop out)
+            p.emit("s_nop", 0)
+            if image == "k":
+                if rpb > 1:
+                    p.emit("v_lshrrev_b32", t2, rpb.bit_length() - 1, t2)
+                    p.emit("s_nop", 0)
+                p.emit("v_and_b32", t2, kmask, t2)
+                p.emit("s_nop", 0)
+                p.emit("v_xor_b32", dst_, t2, dslot)
+            else:
+                p.emit("v_lshrrev_b32", dst_, rpb.bit_length() - 1, t2) if rpb > 1 else p.emit("v_mov_b32", dst_, t2)
+                p.emit("s_nop", 0)
+                p.emit("v_and_b32", dst_, vmask, dst_)
+                p.emit("s_nop", 0)
+                p.emit("v_lshlrev_b32", dst_, 2, dst_)                       # chunk swizzle: granule bits 2 ..
+                if self.ct:                                                 # ... and the folded bodies' flipped 32-byte halves: granule bit 1
+                    p.emit("v_lshrrev_b32", t2, 2, t2)
+                    p.emit("s_nop", 0)
+                    p.emit("v_and_b32", t2, 1, t2)
+                    p.emit("s_nop", 0)
+                    p.emit("v_lshl_or_b32", dst_, t2, 1, dst_)
+                p.emit("s_nop", 0)
+                p.emit("v_xor_b32", dst_, dst_, dslot)
+            p.emit("s_nop", 0)
+
+        granule(gl0, 0)
+        p.emit("s_mov_b32", S_TMP, 0)
+        for i in range(len(dst)):
+            if i:
+                granule(t, i)
+                p.emit("s_add_u32", S_TMP, S_TMP, s_piece)
+                p.emit("v_sub_u32", t2, t, gl0)
+                p.emit("s_nop", 0)
+                p.emit("v_lshlrev_b32", t2, 4, t2)
+                p.emit("s_nop", 0)
+                p.emit("v_add_u32", dst[i], t2, a0)
+                p.emit("s_nop", 0)
+                p.emit("v_add_u32", dst[i], S_TMP, dst[i])
+                gi = t
+            else:
+                p.emit("v_mov_b32", dst[0], a0)
+                gi = gl0
+            p.emit("v_cmp_gt_u32", VCC, S_D, gi)                            # the row has this granule
+            p.emit("s_nop", 0)
+            p.emit("v_cndmask_b32", dst[i], mark, dst[i], VCC)
+
+    def trim_test(self, lab):
+        """scc1 -> the launch's head dim is the body's (flag bits 8 .. 12 hold 0 or G): the fast derivation of the piece offsets stands"""
+        p = self.p
+        p.emit("s_lshr_b32", S_D, A_FLAGS, 8)
+        p.emit("s_and_b32", S_D, S_D, 31)
+        p.emit("s_cmp_eq_u32", S_D, 0)
+        p.emit("s_cbranch_scc1", Label(lab))
+        p.emit("s_cmp_ge_u32", S_D, self.g.ROWB // 16)
+        p.emit("s_cbranch_scc1", Label(lab))
+
     def lm_fail_check(self, r, x, t, t2):
         """appends to r: a lane's share x of a row sum at or above LM_MAX, or NaN -> the wave raises its flag word (the shell redoes the item in safe mode)"""
         ok = self.p.fresh("lm_ok")
@@ -653,6 +733,9 @@ class Gen16(base.Gen):
             p.emit("v_xor_b32", QD[i], i << 6, A_QD0)
             p.emit("s_nop", 0)
             p.emit("v_add_u32", QD[i], S_TMP, QD[i])
+        self.trim_test("q_full")
+        self.trim_offsets("k", [QD[i] for i in range(g.NP)], A_QD0, S_TMP2)       # (the Q image of a 16-row group is laid out like a K tile's quarter)
+        p.label("q_full")
         p.emit("s_and_b32", S_PF, A_FLAGS, 1)
         p.emit("s_cmp_eq_u32", S_PF, 1)
         p.emit("s_cbranch_scc1", Label("have_q"))
@@ -692,6 +775,10 @@ class Gen16(base.Gen):
                 p.emit("v_add_u32", VD[i], S_TMP2, A_VD0)
             p.emit("s_nop", 0)
             p.emit("v_add_u32", KD[i], S_TMP, KD[i])
+        self.trim_test("kv_full")
+        self.trim_offsets("k", [KD[i] for i in range(g.NP)], A_KD0, A_KROW4)
+        self.trim_offsets("v", [VD[i] for i in range(g.NP)], A_VD0, A_VROW4)
+        p.label("kv_full")
         p.emit("s_mov_b32", S_T, -2)
         p.emit("s_mov_b32", S_FLAG, 0)
         p.emit("s_mov_b32", S_FIX, 0)

@@ -117,7 +117,10 @@ int tail_split_heads(const fa2::FwdParams& p, bool causal) {
 bool asm_pitch_ok(int64_t row_stride_elems, int HD) { return row_stride_elems % HD == 0; }
 // (round 5) Q is staged by LDS-DMA like K: its row pitch has to be a multiple of one tile row too, and the byte offsets of the (up to 63) rows a
 // workgroup's last wave reads past Nq — zero-filled by the descriptor — must not wrap
-bool asm_q_span_ok(const fa2::FwdParams& p) { return ((int64_t)(p.Nq + 64) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32) && p.qs[2] % (p.D > 0 ? p.D : 1) == 0; }
+// (any_pitch: launches of a head dim below the body's take the general form of the LDS-DMA offsets — csrc/gen/fwd_m16_gen.py: trim_offsets)
+bool asm_q_span_ok(const fa2::FwdParams& p, bool any_pitch = false) {
+    return ((int64_t)(p.Nq + 64) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32) && (any_pitch || p.qs[2] % (p.D > 0 ? p.D : 1) == 0);
+}
 // ... and pays a fixed head and tail per item (the Q tile through LDS, the first K / V tiles before any MFMA, the drain of the software pipeline):
 // over a short KV sweep (cross-attention, low-resolution self-attention) the compiler-scheduled kernels — two waves per SIMD hiding each
 // other's prologue — are faster.  tools/asm_kv_ab.py, one box, fp16, B4 H16 N4096, HIP time / hand-scheduled time at Nkv = 77, 256, 512,
@@ -154,8 +157,16 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     // (round 3) the body that folds the scale into Q beats the 8-wave kernel non-causal too (+9 %), so every launch that folds takes it.
     const bool fold = asm_folds(bf16, p);
     const bool d64_asm = HD == 64 && (causal || fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
-    if ((HD == 128 || d64_asm) && p.D == HD && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) &&
-        asm_kv_len_ok(HD, bf16, p, causal)) {
+    // Head dims BELOW the body's (round 5; the 16x16x32 bodies only): the padded columns of the Q / K / V images are zero-filled by the LDS-DMA itself (a
+    // granule the row does not have gets a source offset beyond the descriptor) and the piece offsets take their general form, so any row pitch goes.
+    // The body runs at D / HD of its rate: it takes the head dims where that still beats the trimmed compiler-scheduled kernels
+    // (tools/trim_asm_ab.py, profiles/r18_trim_asm_ab.txt, one box): fp16 D = 40 (SD 1.5's 64 x 64 self-attention, B2 H8 N4096) 72.0 -> 64.0 us, D = 48
+    // causal +5.8 %, D = 96 +6.5 %, D = 104 .. 120 +19 .. 20 %, D = 112 causal +13 %; bf16 (f32 scale) D = 112 +14 %, D = 96 causal -8.7 %: the folded
+    // bodies from 40 / 96 on, the f32-scale ones from 104 on.
+    const int m16_mode = fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed));
+    const bool trimmed = p.D < HD && p.D >= (HD == 64 ? 40 : fold ? 96 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
+    if ((HD == 128 || d64_asm) && (p.D == HD || trimmed) && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p, trimmed) &&
+        (trimmed || asm_pitch_ok(p.ks[2], HD)) && asm_kv_len_ok(HD, bf16, p, causal)) {
         // (the folded bodies built on v_mfma_f32_16x16x32 add the rounded P into the row sums — on the matrix pipe; csrc/gen/fwd_m16_gen.py, opt=lm)
         const bool lsum16 = fa2::fwd_asm_lsum16(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
         return {FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold};

@@ -245,3 +245,34 @@ def test_m16_items_after_a_redo_start_in_safe_mode():
     for (qq, kk, vv, qb), (o, lse) in zip(items, outs):
         o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre="ct" in harness.OPT)
         assert np.abs(o - o_ref).max() <= 3e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if lm else 1e-4)
+
+
+@pytest.mark.parametrize("hd,d,opt", [(64, 40, ("ct", "lm")), (64, 56, ("ct", "lm")), (64, 8, ("ct", "lm")), (128, 96, ("ct", "lm")), (128, 120, ("lm",)), (128, 104, ())])
+def test_m16_head_dims_below_the_bodys(hd, d, opt, m16):
+    """Head dims below the body's (SD 1.5's D = 40 on the 64 body, 96 .. 120 on the 128 body; host.cpp: plan_range): rows of 2 D bytes at any pitch, the
+    LDS-DMA offsets in their general form, and a granule the row does not have gets an offset beyond the descriptor — the image's padded columns are
+    zero-filled by the load itself (Gen16.trim_offsets).  The emulated matrices sit between NaN guard bands and are contiguous, so a granule that were
+    fetched from the neighbouring row, or a stray column of V, would show: O's padded columns must be exact zeros, the real ones match float64."""
+    if m16:
+        pytest.skip("one pass is enough")
+    saved = harness.HD, harness.OPT, harness.DTRIM
+    harness.HD, harness.OPT, harness.DTRIM = hd, opt, d
+    harness._PROGS.clear()
+    try:
+        rng = np.random.default_rng(hd + d)
+        q, k, v = rng.standard_normal((456, d)), rng.standard_normal((333, d)), rng.standard_normal((333, d))
+        items = [(q, k, v, 1), (q, k, v, 0)]                       # ragged Nq and Nkv, two items through the seam
+        outs, m = harness.run_items(items, False)
+        assert not m.errors, m.errors[:5]
+        for (qq, kk, vv, qb), (o, lse) in zip(items, outs):
+            o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + o.shape[0]], kk, vv, False, row0=qb * 256, pre="ct" in opt)
+            assert o.shape[1] == d and np.abs(o - o_ref).max() <= 1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in opt else 1e-4)
+        q, k, v = (rng.standard_normal((512, d)) for _ in range(3))
+        outs, m = harness.run_items([(q, k, v, 1), (q, k, v, 0)], True)            # a causal pair unit
+        assert not m.errors, m.errors[:5]
+        for qb, (o, lse) in zip((1, 0), outs):
+            o_ref, lse_ref = harness.dense(q[qb * 256:qb * 256 + 256], k, v, True, row0=qb * 256, pre="ct" in opt)
+            assert np.abs(o - o_ref).max() <= 1.1e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if "lm" in opt else 1e-4)
+    finally:
+        harness.HD, harness.OPT, harness.DTRIM = saved
+        harness._PROGS.clear()

@@ -1122,3 +1122,34 @@ def test_row_padded_v_on_the_hand_scheduled_head_dim_128_kernels(pitch):
             b, h = divmod(head, H)
             sl = (slice(b, b + 1), slice(h, h + 1))
             _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl].contiguous(), 0, causal, plan=plan, head=head)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,dt,causal", [(40, 0, False), (48, 0, True), (56, 0, False), (96, 0, False), (112, 0, True), (120, 0, False), (112, 1, False), (104, 1, True)])
+def test_head_dims_below_the_hand_scheduled_bodys(D, dt, causal):
+    """Round 5: head dims 40 .. 56 run on the head-dim-64 16x16x32 body and 96 .. 120 (f32 scale: 104 ..) on the 128 one — SD 1.5's D = 40 among them —
+    with the padded columns of the Q / K / V images zero-filled by the LDS-DMA itself (csrc/gen/fwd_m16_gen.py: trim_offsets; host.cpp: plan_range).
+    The plan must name the hand-scheduled kernel; results against the oracle under the planned contract; and — what the zero fill is for — with the
+    tensors cut out of wider allocations whose gaps hold NaNs (row pitch D + 8 and 2 D: nothing of a gap or of a neighbouring row may enter a product),
+    ragged Nq / Nkv included."""
+    B, H, N, Nkv = 2, 9, 2000, 2100                        # 144 items of 256 rows on 256-row workgroups (rows = 256 pins the shape below)
+    g = torch.Generator(device="cpu").manual_seed(40 + D)
+    tdt = TORCH_DT[dt]
+    with _fa2_lib.options(rows=256):
+        for pitch in (D, D + 8, 2 * D):
+            def cut(n):
+                wide = torch.full((B, H, n, pitch), float("nan"), dtype=tdt)
+                wide[..., :D] = torch.randn((B, H, n, D), generator=g).to(tdt)
+                return wide.to(_dev())[..., :D]
+            q, k, v = cut(N), cut(Nkv), cut(Nkv)
+            plan = _plan(q, k, causal)
+            assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.heads_main == B * H, (D, pitch, plan.as_dict())
+            o, lse = _cabi_forward(q, k, v, causal)
+            assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all(), (D, pitch)
+            for head in (0, B * H - 1):
+                b, h = divmod(head, H)
+                sl = (slice(b, b + 1), slice(h, h + 1))
+                _assert_close_to_oracle(o[sl], lse[sl], q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dt, causal, plan=plan, head=head)
+        # bit 6 clear: the trimmed compiler-scheduled kernels, as before
+        with _fa2_lib.options(asm=_fa2_lib.load().fa2_get_option(b"asm") & ~64):
+            assert _plan(q, k, causal).kernel != _fa2_lib.FA2_KERNEL_ASM

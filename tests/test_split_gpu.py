@@ -122,8 +122,12 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     assert float((lse_ws - lse_pl).abs().max()) <= (LSE_TOL if dt == 0 else LSE_TOL_P16_BF16)
     # a fair share of the elements must be bit-identical (the unsplit items are the same launch geometry)
     # (not at head dim 64 in fp16, where the two calls run different scaling contracts: see the LSE bound above)
+    # (... nor where the plain call runs a head dim below the body's on the hand-scheduled kernel — folded scale — and the split call the HIP kernels:
+    #  D = 96 fp16 since round 5)
+    qv, kv = (q.transpose(1, 2), k.transpose(1, 2)) if bnhd else (q, k)
+    other_contract = _fa2_lib.fwd_plan(qv, kv, False).contract != _plan_ws(q, k, bnhd, need).contract
     same = (o_ws.view(torch.int16) == o_pl.view(torch.int16)).float().mean().item()
-    assert same > (0.2 if (D == 64 and dt == 0) else 0.5), same
+    assert same > (0.2 if ((D == 64 and dt == 0) or other_contract) else 0.5), same
     # against the oracle on heads from the unsplit rounds and from the split tail (the last items of the order)
     heads = {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2), (B - 1, max(H - 8, 0))}
     plan = _plan_ws(q, k, bnhd, need)

@@ -17,6 +17,7 @@ _PROGS = {}
 OPT = ()                # generator options of the programs under test (default: the f32-scale body the library ships)
 HD = 128                # head dim of the programs under test (128 or 64)
 M16 = False             # the v_mfma_f32_16x16x32 generator (csrc/gen/fwd_m16_gen.py) instead of the 32x32x16 one
+DTRIM = None            # a head dim BELOW the body's (rows of 2 * DTRIM bytes; flag bits 8 .. 12 = DTRIM / 8: Gen16.trim_offsets), M16 only
 
 
 def program(bf16):
@@ -47,7 +48,9 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
     """The values the forward shell (fa2_fwd_d128.hip.h) hands to the asm statement, for wave w of the workgroup working on Q block
     qblk.  nxt = (qblk, Nq, q_base, k_base, v_base, Nkv) of the workgroup's next item (flags bit 1) or None."""
     g = geo()
-    row_bytes = g.ROWB if row_bytes is None else row_bytes
+    row_bytes = (g.ROWB if DTRIM is None else 2 * DTRIM) if row_bytes is None else row_bytes
+    if DTRIM is not None:
+        flags |= (DTRIM // 8) << 8
     lane = np.arange(64)
     l31, hi = lane & 31, lane >> 5
     pp, g1 = lane & 15, (lane >> 4) & 1
@@ -111,7 +114,7 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         v[13] = (g.EPI_BASE + w * 64 * g.EPI_ROWB + n16 * g.EPI_ROWB + g4 * 8).astype(np.uint32)
 
     def srd(base, nkv):
-        return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + g.ROWB, 0x00020000], dtype=np.uint32)
+        return np.array([base & 0xffffffff, base >> 32, (nkv - 1) * row_bytes + (g.ROWB if DTRIM is None else 2 * DTRIM), 0x00020000], dtype=np.uint32)
 
     def pair(base):
         return np.array([base & 0xffffffff, base >> 32], dtype=np.uint32)
@@ -147,7 +150,7 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
     """One persistent workgroup works through `items` = [(q [Nq,128], k [Nkv,128], v [Nkv,128], qblk), ...]: the asm
     statement runs once per item, registers / LDS / loads in flight carry over, and between two statements this harness
     plays the HIP shell (reads the O tile out of the LDS image, rebinds v0..15).  Returns [(o, lse)], machine."""
-    scale = HD ** -0.5 if scale is None else scale
+    scale = (HD if DTRIM is None else DTRIM) ** -0.5 if scale is None else scale
     pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)       # NaN guard bands around every matrix
     bufs, bases = [], []
     addr = 0x10000000
@@ -221,6 +224,9 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
         else:
             img = m.lds[g.EPI_BASE:g.EPI_BASE + 4 * 64 * g.EPI_ROWB].reshape(256, g.EPI_ROWB)[:, :g.ROWB].copy().view(np.uint16)
             o = from_bits(img, bf16)[:rows]
+            if DTRIM is not None:
+                assert not np.abs(o[:, DTRIM:]).any(), "the padded columns of O must be exact zeros (V's padded columns are zero-filled)"
+                o = o[:, :DTRIM]
         lse = np.empty(256, dtype=np.float32)
         for w in range(4):
             if M16:         # one output register: lane l hands over row l of the wave

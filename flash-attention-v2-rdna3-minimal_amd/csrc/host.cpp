@@ -147,6 +147,12 @@ bool asm_folds(bool bf16, const fa2::FwdParams& p) {
 // What one launch over the heads [p.bh0, p.bh0 + p.nbh) runs: the ONE place that decides it (launch_range executes the plan, fa2_fwd_plan reports it).
 struct RangePlan { int kernel, contract; int rows; bool fold; };
 
+// A head dim below the body's that the 16x16x32 bodies take (see plan_range)
+bool asm_trimmed(int HD, bool bf16, const fa2::FwdParams& p, bool fold) {
+    const int m16_mode = fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed));
+    return p.D < HD && p.D >= (HD == 64 ? 40 : fold ? 96 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
+}
+
 RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     const int rows = pick_rows(p, causal);
     // Head dim exactly 128 with a positive scale: the hand-scheduled 4-wave kernel (256-row workgroups).  Head dim 64 has its generated
@@ -163,8 +169,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     // (tools/trim_asm_ab.py, profiles/r18_trim_asm_ab.txt, one box): fp16 D = 40 (SD 1.5's 64 x 64 self-attention, B2 H8 N4096) 72.0 -> 64.0 us, D = 48
     // causal +5.8 %, D = 96 +6.5 %, D = 104 .. 120 +19 .. 20 %, D = 112 causal +13 %; bf16 (f32 scale) D = 112 +14 %, D = 96 causal -8.7 %: the folded
     // bodies from 40 / 96 on, the f32-scale ones from 104 on.
-    const int m16_mode = fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed));
-    const bool trimmed = p.D < HD && p.D >= (HD == 64 ? 40 : fold ? 96 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
+    const bool trimmed = asm_trimmed(HD, bf16, p, fold);
     if ((HD == 128 || d64_asm) && (p.D == HD || trimmed) && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p, trimmed) &&
         (trimmed || asm_pitch_ok(p.ks[2], HD)) && asm_kv_len_ok(HD, bf16, p, causal)) {
         // (the folded bodies built on v_mfma_f32_16x16x32 add the rounded P into the row sums — on the matrix pipe; csrc/gen/fwd_m16_gen.py, opt=lm)
@@ -184,8 +189,11 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
 
 // non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 when the launch folds the scale (plan_range)
 bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
-    const bool d64 = HD == 64 && (asm_folds(bf16, p) || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
-    return (HD == 128 || d64) && p.D == HD && !p.negate_q && asm_fwd() && asm_q_span_ok(p) && asm_pitch_ok(p.ks[2], HD) && asm_kv_len_ok(HD, bf16, p, false);
+    const bool fold = asm_folds(bf16, p);
+    const bool d64 = HD == 64 && (fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    const bool trimmed = asm_trimmed(HD, bf16, p, fold);
+    return (HD == 128 || d64) && (p.D == HD || trimmed) && !p.negate_q && asm_fwd() && asm_q_span_ok(p, trimmed) && (trimmed || asm_pitch_ok(p.ks[2], HD)) &&
+           asm_kv_len_ok(HD, bf16, p, false);
 }
 
 // KV-split tail (fa2_fwd_ws).  B*H*ceil(Nq/256) equal workgroups on the CUs take ceil(x / CUs) rounds however empty the last one is: SDXL's

@@ -150,7 +150,13 @@ struct RangePlan { int kernel, contract; int rows; bool fold; };
 // A head dim below the body's that the 16x16x32 bodies take (see plan_range)
 bool asm_trimmed(int HD, bool bf16, const fa2::FwdParams& p, bool fold) {
     const int m16_mode = fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed));
-    return p.D < HD && p.D >= (HD == 64 ? 40 : fold ? 96 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
+#ifndef FA2_TRIM_MIN64       // (developer A/B: tools/kbench.py build NAME:-DFA2_TRIM_MIN64=32,-DFA2_TRIM_MIN128=80,only=host)
+#define FA2_TRIM_MIN64 40
+#endif
+#ifndef FA2_TRIM_MIN128
+#define FA2_TRIM_MIN128 88      // (B2 H16 N4096 fp16, same file: D = 72 +4 %, 80 +2 %, 88 +7 %, 96 +6 %; D = 24 / 32 on the 64 body: -1 %)
+#endif
+    return p.D < HD && p.D >= (HD == 64 ? FA2_TRIM_MIN64 : fold ? FA2_TRIM_MIN128 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
 }
 
 RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
@@ -168,7 +174,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     // The body runs at D / HD of its rate: it takes the head dims where that still beats the trimmed compiler-scheduled kernels
     // (tools/trim_asm_ab.py, profiles/r18_trim_asm_ab.txt, one box): fp16 D = 40 (SD 1.5's 64 x 64 self-attention, B2 H8 N4096) 72.0 -> 64.0 us, D = 48
     // causal +5.8 %, D = 96 +6.5 %, D = 104 .. 120 +19 .. 20 %, D = 112 causal +13 %; bf16 (f32 scale) D = 112 +14 %, D = 96 causal -8.7 %: the folded
-    // bodies from 40 / 96 on, the f32-scale ones from 104 on.
+    // bodies from 40 / 88 on, the f32-scale ones from 104 on.
     const bool trimmed = asm_trimmed(HD, bf16, p, fold);
     if ((HD == 128 || d64_asm) && (p.D == HD || trimmed) && !p.negate_q && asm_fwd() && rows == 256 && pick_rows(p) == 256 && asm_q_span_ok(p, trimmed) &&
         (trimmed || asm_pitch_ok(p.ks[2], HD)) && asm_kv_len_ok(HD, bf16, p, causal)) {

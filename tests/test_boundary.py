@@ -239,7 +239,7 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     assert (p.heads_main, p.kernel, p.kernel_tail, p.contract_tail, p.rows_tail) == (32, K.FA2_KERNEL_ASM, K.FA2_KERNEL_HIP_128, 0, 128)
     # what the bodies cannot serve goes to the HIP kernels: other head dims, short KV sweeps, a K row pitch that is not a multiple of a tile row, a negative scale
     assert _meta_plan(2, 16, 4096, 4096, 80).kernel == K.FA2_KERNEL_HIP_256
-    # ... except the head dims just below a body's, which the 16x16x32 bodies serve with zero-filled padded columns (round 5): 40 .. 56 and 96 .. 120 (fp16,
+    # ... except the head dims just below a body's, which the 16x16x32 bodies serve with zero-filled padded columns (round 5): 40 .. 56 and 88 .. 120 (fp16,
     # folded scale), 104 .. 120 (f32 scale)
     for D, dt, want in ((96, torch.float16, K.FA2_KERNEL_ASM), (40, torch.float16, K.FA2_KERNEL_ASM), (120, torch.bfloat16, K.FA2_KERNEL_ASM),
                         (96, torch.bfloat16, K.FA2_KERNEL_HIP_256), (32, torch.float16, K.FA2_KERNEL_HIP_256)):

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn import _fa2_lib  # noqa: E402
 
 SHAPES = [("harness D-scan", 1, 24, 4096, d, torch.float16, False) for d in (40, 48, 56, 96, 104, 112, 120)] + [
+    ("B2 H16 D-scan", 2, 16, 4096, d, torch.float16, False) for d in (24, 32, 40, 48, 56, 72, 80, 88, 96)] + [
     ("sd15-64x64", 2, 8, 4096, 40, torch.float16, False), ("sd15-64x64 B4", 4, 8, 4096, 40, torch.float16, False),
     ("causal", 2, 16, 4096, 48, torch.float16, True), ("causal", 2, 16, 4096, 112, torch.float16, True), ("bf16", 2, 16, 4096, 112, torch.bfloat16, False),
     ("bf16 causal", 2, 16, 4096, 96, torch.bfloat16, True)]

@@ -119,6 +119,9 @@ inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, in
     // f32 scale.  A call flagged FA2_FLAG_EXACT_SCALE (a forward that will be differentiated) keeps the f32 row sums: fp16 at head dim 128 on the
     // 16 x 16 body with the sum check, everything else on the 32x32x16 bodies; other calls take the 16 x 16 bodies with the row sums on the matrix pipe
     // (head dim 128; at head dim 64 the f32-scale 16 x 16 bodies do not beat the 32x32x16 body: profiles/r18_kbench_f32lm*.txt)
+    // (head dim 64: the f32-scale body with the sum check loses to the 32x32x16 body, the one with the row sums on the matrix pipe wins a little —
+    //  bf16 B2 H16 N4096 non-causal 135.8 (8-wave HIP kernel) / 136.5 (32x32x16 body) -> 130.8 us, causal 75.6 -> 74.4: profiles/r18_kbench_d64_f32lm.txt)
+    if (HD == 64) return (lm && !p.exact_scale) ? kM16F32Lm : kM16None;
     if (HD != 128) return kM16None;
     if (p.exact_scale) return !bf16 ? kM16F32 : kM16None;
     return lm ? kM16F32Lm : (!bf16 ? kM16F32 : kM16None);

@@ -70,7 +70,11 @@ int launch_fwd_asm(int HD, bool bf16, const FwdParams& p, bool causal, bool fold
     // before (bf16 on the 32x32x16 body), one box (profiles/r18_kbench_f32lm.txt, _c3.txt): bf16 B2 H16 N4096 non-causal 199.1 -> 187.8 us, causal (c3)
     // 110.0 -> 106.7, B1 H32 N8192 causal 393.8 -> 373.2, B8 797 -> 764; head dim 64 bf16 causal 74.9 -> 74.7 (not taken).
     const int kind = fwd_asm_m16_kind(HD, bf16, p, fold, m16);
-    if (kind == kM16F32Lm) {       // (head dim 128)
+    if (kind == kM16F32Lm) {
+        if (HD == 64) {
+            if (bf16) return causal ? launch_asm_t<64, true, true, false, true, true>(p, stream) : launch_asm_t<64, true, false, false, true, true>(p, stream);
+            return causal ? launch_asm_t<64, false, true, false, true, true>(p, stream) : launch_asm_t<64, false, false, false, true, true>(p, stream);
+        }
         if (bf16) return causal ? launch_asm_t<128, true, true, false, true, true>(p, stream) : launch_asm_t<128, true, false, false, true, true>(p, stream);
         return causal ? launch_asm_t<128, false, true, false, true, true>(p, stream) : launch_asm_t<128, false, false, false, true, true>(p, stream);
     }

@@ -168,7 +168,9 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     // "asm" bit 4 sends every D = 64 launch to it (A/B measurements).
     // (round 3) the body that folds the scale into Q beats the 8-wave kernel non-causal too (+9 %), so every launch that folds takes it.
     const bool fold = asm_folds(bf16, p);
-    const bool d64_asm = HD == 64 && (causal || fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    // (round 5: and every launch the f32-scale 16x16x32 body with the row sums on the matrix pipe takes: calls that are not flagged FA2_FLAG_EXACT_SCALE)
+    const bool d64_asm = HD == 64 && (causal || fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16) ||
+                                      fa2::fwd_asm_m16_kind(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed))) == fa2::kM16F32Lm);
     // Head dims BELOW the body's (round 5; the 16x16x32 bodies only): the padded columns of the Q / K / V images are zero-filled by the LDS-DMA itself (a
     // granule the row does not have gets a source offset beyond the descriptor) and the piece offsets take their general form, so any row pitch goes.
     // The body runs at D / HD of its rate: it takes the head dims where that still beats the trimmed compiler-scheduled kernels
@@ -196,7 +198,8 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
 // non-causal launches the hand-scheduled persistent kernels take: head dim 128, and head dim 64 when the launch folds the scale (plan_range)
 bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
     const bool fold = asm_folds(bf16, p);
-    const bool d64 = HD == 64 && (fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16));
+    const bool d64 = HD == 64 && (fold || (fa2::options().asm_mask.load(std::memory_order_relaxed) & 16) ||
+                                  fa2::fwd_asm_m16_kind(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed))) == fa2::kM16F32Lm);
     const bool trimmed = asm_trimmed(HD, bf16, p, fold);
     return (HD == 128 || d64) && (p.D == HD || trimmed) && !p.negate_q && asm_fwd() && asm_q_span_ok(p, trimmed) && (trimmed || asm_pitch_ok(p.ks[2], HD)) &&
            asm_kv_len_ok(HD, bf16, p, false);

@@ -230,10 +230,13 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     # 8-wave HIP kernel; bf16 causal -> the 32x32x16 body, f32 scale
     p = _meta_plan(2, 16, 4096, 4096, 64)
     assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, FOLD128)
+    # (bf16, f32 scale: the 16x16x32 body with the row sums on the matrix pipe; option asm bit 9 clear: the 8-wave HIP kernel non-causal, the 32x32x16 body causal)
     p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16)
-    assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
     p = _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16, causal=True)
-    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, 0)
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
+    with _fa2_lib.options(asm=451):
+        assert (_meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16).kernel, _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16, causal=True).contract) == (K.FA2_KERNEL_HIP_256, 0)
     # two launches: 544 workgroups = two full rounds of the body + the last two heads as 128-row workgroups of the HIP kernel
     p = _meta_plan(2, 17, 4096, 4096, 64)
     assert (p.heads_main, p.kernel, p.kernel_tail, p.contract_tail, p.rows_tail) == (32, K.FA2_KERNEL_ASM, K.FA2_KERNEL_HIP_128, 0, 128)
@@ -252,8 +255,8 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     # the fold needs scale * log2(e) <= 1 (the prescaled Q must stay inside fp16's range): a larger scale runs the f32-scale body of the same schedule
     p = _meta_plan(2, 16, 4096, 4096, 128, scale=0.8)
     assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
-    p = _meta_plan(2, 16, 4096, 4096, 64, scale=0.8)           # head dim 64 without the fold: the 8-wave kernel non-causal (plan_range)
-    assert (p.kernel, p.contract) == (K.FA2_KERNEL_HIP_256, 0)
+    p = _meta_plan(2, 16, 4096, 4096, 64, scale=0.8)           # head dim 64 without the fold: the f32-scale 16x16x32 body too
+    assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
     # the KV-split of a partly filled last round needs the caller's workspace (fa2_fwd_ws); whole items and parts share one kernel and one contract
     lib = _fa2_lib.load(build_if_missing=False)
     need = lib.fa2_fwd_workspace_bytes(_fa2_lib.FA2_DTYPE_F16, 2, 10, 4096, 4096, 64, 0)
@@ -284,8 +287,10 @@ def test_option_fold_switches_the_contract_and_nothing_else():
         assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, _fa2_lib.FA2_CONTRACT_LSUM_P16)
         with _fa2_lib.options(asm=3):                          # ... the 32x32x16 bodies add the f32 P
             assert _meta_plan(2, 16, 4096, 4096, 128).contract == 0
-        p = _meta_plan(2, 16, 4096, 4096, 64)                  # head dim 64 fp16 without the fold: back on the 8-wave kernel (non-causal)
-        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_HIP_256, 0)
+        p = _meta_plan(2, 16, 4096, 4096, 64)                  # head dim 64 fp16 without the fold: the f32-scale 16x16x32 body (row sums on the matrix pipe)
+        assert (p.kernel, p.contract) == (_fa2_lib.FA2_KERNEL_ASM, _fa2_lib.FA2_CONTRACT_LSUM_P16)
+        with _fa2_lib.options(asm=451):                        # ... bit 9 clear: back on the 8-wave kernel (non-causal)
+            assert (_meta_plan(2, 16, 4096, 4096, 64).kernel, _meta_plan(2, 16, 4096, 4096, 64).contract) == (_fa2_lib.FA2_KERNEL_HIP_256, 0)
         assert lib.fa2_fwd_prescales_q(128, 0.1) == 0
     fold128 = _fa2_lib.FA2_CONTRACT_PRESCALE_Q | _fa2_lib.FA2_CONTRACT_LSUM_P16
     with _fa2_lib.options(fold=2):

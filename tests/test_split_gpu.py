@@ -133,7 +133,7 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     heads = {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2), (B - 1, max(H - 8, 0))}
     plan = _plan_ws(q, k, bnhd, need)
     assert plan.nsplit > 1 and plan.split_items > 0
-    if D == 128 or (D in (40, 64, 96) and dt == 0):       # whole items and parts inside the hand-scheduled persistent kernel (round 5: also head dims just below a body's)
+    if D in (64, 128) or (D in (40, 96) and dt == 0):       # whole items and parts inside the hand-scheduled persistent kernel (round 5: also head dims just below a body's)
         assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM
     else:
         assert plan.kernel == _fa2_lib.FA2_KERNEL_HIP_256 and plan.contract == 0

@@ -1153,3 +1153,13 @@ def test_head_dims_below_the_hand_scheduled_bodys(D, dt, causal):
         # bit 6 clear: the trimmed compiler-scheduled kernels, as before
         with _fa2_lib.options(asm=_fa2_lib.load().fa2_get_option(b"asm") & ~64):
             assert _plan(q, k, causal).kernel != _fa2_lib.FA2_KERNEL_ASM
+        # the forward of a call that will be differentiated (FA2_FLAG_EXACT_SCALE): fp16 at 104 .. 120 runs the f32-scale 16x16x32 body with the sum check
+        # (contract 0), everything else the compiler-scheduled kernels — either way the reference kernel's contract
+        flags = (_fa2_lib.FA2_FLAG_CAUSAL if causal else 0) | _fa2_lib.FA2_FLAG_EXACT_SCALE
+        plan = _fa2_lib.fwd_plan(q, k, flags)
+        assert plan.contract == 0 and (plan.kernel == _fa2_lib.FA2_KERNEL_ASM) == (dt == 0 and D >= 104), (D, plan.as_dict())
+        o, lse = _cabi_forward(q, k, v, flags)
+        for head in (0, B * H - 1):
+            b, h = divmod(head, H)
+            sl = (slice(b, b + 1), slice(h, h + 1))
+            _assert_close_to_oracle(o[sl], lse[sl], q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dt, causal, plan=plan, head=head)

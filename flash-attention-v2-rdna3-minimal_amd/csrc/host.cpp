@@ -128,10 +128,14 @@ bool asm_q_span_ok(const fa2::FwdParams& p, bool any_pitch = false) {
 // bf16 keeps its two-tile sweeps on the hand-scheduled body, fp16 measured 0.94 .. 1.006 there).  The crossover is the same at B2 and at Nq = 1024.
 // Causal self-attention sweeps half the sequence on average: B8 H16, N = 512 768 1024 1536 2048: D = 64 0.90 0.90 0.97 0.88 1.10, D = 128 0.92 0.90
 // 0.96 0.89 1.07 (bf16 alike) — the hand-scheduled body from N = 1792 (profiles/r06_asm_kv_ab.txt).  Option "asm" bit 5 and option "rows" = 256 ignore this rule (A/B measurements, tests).
+bool asm_folds(bool bf16, const fa2::FwdParams& p);
 bool asm_kv_len_ok(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     if ((fa2::options().asm_mask.load(std::memory_order_relaxed) & 32) || forced_rows() == 256) return true;     // (option rows = 256 pins the
     if (causal) return p.Nkv >= 1792;                                                                              //  hand-scheduled kernels: tests)
-    if (p.Nkv >= 896) return true;
+    // Round 5, re-measured with the 16x16x32 bodies (tools/asm_kv_ab.py, profiles/r18_asm_kv_ab.txt; HIP time / hand-scheduled time at Nkv = 256, 512,
+    // 768, 1024, 1536): D = 128 fp16 0.90 1.01 1.07 1.11 1.16, bf16 0.91 1.01 1.05 1.07 1.09 -> from 512 on; D = 64 fp16 (folded) 0.82 0.92 0.99 1.03
+    // 1.10 -> from 896 on as before; D = 64 bf16 (f32 scale) 0.81 0.88 0.92 0.97 1.02 -> from 1280 on.
+    if (p.Nkv >= (HD == 128 ? 512 : (asm_folds(bf16, p) ? 896 : 1280))) return true;
     return HD == 128 && bf16 && p.Nkv <= 2 * fa2::kKvTile;
 }
 

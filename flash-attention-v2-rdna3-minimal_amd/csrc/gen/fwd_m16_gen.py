@@ -869,6 +869,16 @@ class Gen16(base.Gen):
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc0", Label("dispatch"))
         self.body(1, guarded=False, name="F1")
+        if self.lm:
+            # every other tile: has a row sum of this wave gone to inf (an fp16 P beyond 65504) / beyond LM_MAX?  The item will be redone in safe mode
+            # whatever this wave does from here on, so it stops computing: flag up, then stage-only bodies (its share of the LDS-DMA, the barriers)
+            # to the end of the sweep — a failed fast sweep costs the workgroup its memory traffic instead of a whole pass (tools/growth_cliff.py)
+            p.emit("v_max3_f32", TMP[0], LSV[0], LSV[1], LSV[2])
+            p.emit("s_nop", 0)
+            p.emit("v_max_f32", TMP[0], TMP[0], LSV[3])
+            p.emit("s_nop", 0)
+            p.emit("v_cmp_ngt_f32", VCC, LM_MAX, TMP[0])
+            p.emit("s_cbranch_vccnz", Label("lm_abort"))
         p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc1", Label("fast0"))
@@ -988,6 +998,23 @@ class Gen16(base.Gen):
                 p.emit("s_nop", 3)             # (a store of more than 64 bits: its data registers must not be rewritten right behind it)
         p.emit("s_waitcnt", vmcnt=0)           # the stores, and whatever the item seam prefetched: the next statement counts loads only
         p.emit("s_branch", Label("lse_out"))
+        if self.lm:
+            # ---- a wave whose row sums overflowed in the fast loop (see there): raise the flag, stage to the end of the sweep, leave without an epilogue
+            p.label("lm_abort")
+            blk = []
+            self.lm_fail_check(blk, TMP[0], TMP[2], TMP[3])
+            p.ins.extend(blk)
+            p.label("lm_abort_loop")
+            p.emit("s_cmp_ge_i32", S_T, A_NTWG)
+            p.emit("s_cbranch_scc1", Label("end"))
+            p.emit("s_and_b32", S_TMP, S_T, 1)
+            p.emit("s_cmp_eq_u32", S_TMP, 1)
+            p.emit("s_cbranch_scc1", Label("lm_abort_odd"))
+            self.body(0, pv=False, s1=False, s2=False, name="ST0a")
+            p.emit("s_branch", Label("lm_abort_loop"))
+            p.label("lm_abort_odd")
+            self.body(1, pv=False, s1=False, s2=False, name="ST1a")
+            p.emit("s_branch", Label("lm_abort_loop"))
         for r in self.rare:
             p.extend(r)
         p.label("end")

@@ -70,9 +70,14 @@ def test_m16_fast_bodies_carry_no_cross_lane_instruction():
     ops = [i.op for i in prog.ins[lo:hi]]
     lm = "lm" in harness.OPT
     assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 2 * (136 if lm else 128)
-    assert not any(o.startswith("v_permlane") or o.startswith("v_max") for o in ops)
-    if lm:      # exp + pack and nothing else: no add, no compare, no branch into a repair block
-        assert not any(o in ("v_add_f32", "v_cmp_nge_f32", "s_cbranch_vccnz") for o in ops)
+    assert not any(o.startswith("v_permlane") for o in ops)
+    if lm:
+        # exp + pack and nothing else: no add, no per-tile check, no repair block; per two tiles ONE look at the wave's four row sums (v_max3 + v_max +
+        # v_cmp + branch: the per-wave abort of a sweep that is going to be redone anyway)
+        assert not any(o in ("v_add_f32", "v_cmp_nge_f32") for o in ops)
+        assert [o for o in ops if o.startswith("v_max") or o.startswith("v_cmp") or o == "s_cbranch_vccnz"] == ["v_max3_f32", "v_max_f32", "v_cmp_ngt_f32", "s_cbranch_vccnz"]
+    else:
+        assert not any(o.startswith("v_max") for o in ops)
         assert sum(o == "v_exp_f32" for o in ops) == 2 * 64 and sum(o.startswith("v_cvt_pk") for o in ops) == 2 * 32
 
 

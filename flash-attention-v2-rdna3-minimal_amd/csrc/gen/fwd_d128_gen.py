@@ -79,6 +79,8 @@ A_EPI = Arg(21)                                    # per-lane LDS byte address o
 # an item stage the NEXT item's Q fragments and its K(0), K(1), V(0) tiles, and the next statement is told to skip its loads
 A_FLAGS = Arg(22, "s")                             # bit 0: this item's Q / K(0) / K(1) / V(0) are already staged; bit 1: a next item exists; bit 2: ... with >= 2 KV tiles; bit 3: this item is a KV-split part
                                                    # bit 4: safe mode — no fast bodies (the redo of an item whose sum check met a non-finite P: see Gen.rare_sum)
+                                                   # bit 5: the shell's own (sticky safe mode after a redo: it sets bit 4 with it); bits 8 .. 12, fwd_m16_gen.py only:
+                                                   # the 16-byte granules a row really has when the head dim is below the body's (0: all — Gen16.trim_offsets)
 A_NQW = Arg(23, "s")                               # the next item: byte offset of this wave's first Q row; Q / K / V descriptors
 A_QT16 = Arg(24, "s")                              # 16 * Q row bytes: source stride between the 16-row groups of Q
 A_NQRS = Arg(25, "s", 4)

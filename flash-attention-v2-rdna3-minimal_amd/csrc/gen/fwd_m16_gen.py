@@ -1039,15 +1039,14 @@ def main():
     for hd, bf16, kind in ((hd, bf16, kind) for hd in (128, 64) for bf16 in (False, True) for kind in ("", "_lm", "_fold", "_fold_nolm")):
         if kind == "_fold_nolm" and hd == 64:
             continue
-        if True:
-            c = dict(cfg)
-            c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if kind.startswith("_fold") else ())
-            if kind == "_lm" or (kind == "_fold" and "nolm" not in cfg.get("opt", ())):
-                c["opt"] += ("lm",)
-            prog = Gen16(bf16, hd=hd, **c).build()
-            path = os.path.join(a.out, "fa2_fwd_m16_%s%s%s.inc" % ("d64_" if hd == 64 else "", "bf16" if bf16 else "f16", kind))
-            base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
-            print(path, len(prog.ins), "instructions")
+        c = dict(cfg)
+        c["opt"] = tuple(o for o in cfg.get("opt", ()) if o not in ("ct", "lm", "nolm")) + (("ct",) if kind.startswith("_fold") else ())
+        if kind == "_lm" or (kind == "_fold" and "nolm" not in cfg.get("opt", ())):
+            c["opt"] += ("lm",)
+        prog = Gen16(bf16, hd=hd, **c).build()
+        path = os.path.join(a.out, "fa2_fwd_m16_%s%s%s.inc" % ("d64_" if hd == 64 else "", "bf16" if bf16 else "f16", kind))
+        base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
+        print(path, len(prog.ins), "instructions")
 
 
 if __name__ == "__main__":

@@ -816,6 +816,13 @@ class Gen:
         """(first, last) gap of the MFMAs that read the C tuple(s) of q block qb: the first Q.K^T k-step of the NEXT tile."""
         return self.npv + 2 * qb, self.npv + 2 * qb + 1
 
+    def qk_phase(self, par, s1, s2, fast):
+        """the MFMAs of a body's second phase (fwd_m16_gen.py adds the row-sum links of its lm bodies)"""
+        return self.qk_mfmas(par) if s2 else [None] * self.nqk
+
+    def body_end(self, par, name, fast, s1):
+        """hook: behind a body's last gap, ahead of its book-keeping and barrier (fwd_m16_gen.py: the row-sum check of the lm fast bodies)"""
+
     # ------------------------------------------------------------------ one body
     def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True, qpre=False):
         """B(t) with t & 1 == par.  pv: PV(t); s1: softmax of tile t+1 (M0, M1, E0, E1) and the V(t+1) reads; s2: K(t+2)
@@ -832,7 +839,7 @@ class Gen:
         mf = []
         mf += self.pv_mfmas(par, 0) if pv else [None] * (self.npv // 2)
         mf += self.pv_mfmas(par, 1) if pv else [None] * (self.npv // 2)
-        mf += self.qk_mfmas(par) if s2 else [None] * self.nqk
+        mf += self.qk_phase(par, s1, s2, fast)
         if "mfma" in abl:
             mf = [None] * ng
         trace = fast and 0 < cfg["trace"][0] < 9
@@ -989,6 +996,7 @@ class Gen:
                 p.ins.extend(item if isinstance(item, list) else [item])
         if self.pool:
             p.ins[body_start:] = self.lds_waits(p.ins[body_start:])
+        self.body_end(par, name, fast and not abl, s1)
         # end of body: DMA landed, my LDS reads done, then everybody
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)

@@ -35,8 +35,15 @@ import fwd_d128_gen as base  # noqa: E402
 from fwd_d128_gen import (A_C, A_EPI, A_FLAGS, A_WSB, A_KD0, A_KR0, A_KRS, A_KROW4, A_KTILE, A_LDSW, A_LIM0, A_LIM1, A_LSE0, A_NKRS, A_NQRS,  # noqa: E402,F401
                           A_NQW, A_NTW, A_NTWG, A_NVRS, A_QD0, A_QRS, A_QT16, A_QW, A_VD0, A_VR0, A_VROW4, A_VRS, A_VTILE, KD, NEG_INF,
                           PSUM_MAX, QD, SB, S_D, S_FLAG, S_FIX, S_KOFF, S_NFAST, S_NOVM, S_PF, S_QH, S_QM0, S_QSB, S_QSOFF, S_SUM, S_T, S_TMP,
-                          S_TMP2, S_VOFF, S_WAVE, THR, VBASE, VD)
+                          S_TMP2, S_VOFF, S_WAVE, VBASE, VD)
 from isa import A, V, Ins, Label, M0, Neg, VCC, mk  # noqa: E402
+
+# Deferred-rescale threshold of the max-first bodies, log2 units: the reference of a row moves when a score outgrows it by more than this, so P <= 2^14 —
+# inside fp16 (65504) with two octaves to spare; rounding is relative and O, l are f32, so where the reference sits changes nothing else.  The base
+# generator's 8 (and the HIP kernels') dates from round 1; since round 6 the max-first bodies also carry the rest of a sweep whose fast bodies met a P
+# beyond the 16-bit range (Gen16.lm_repair), on exactly the data whose row maxima keep climbing: on N(0, 6^2) logits a wave moves a reference (rare_m +
+# the O rescale, ~half a body) in 15 % of its tiles at 8 and in 4.6 % at 14 (a simulation of the recurrence; tools/growth_cliff.py has the GPU times)
+THR = 14.0
 
 # ---- register map (everything the base generator does not fix)
 KR = [V(208 + i) for i in range(4)]                # K / Q fragment read addresses, k-step ks (32 head-dim columns each)
@@ -88,6 +95,7 @@ VRO = [V(196 + i) for i in range(4)]               # "ct": read addresses of the
 # partial sums the v_add chains keep.  The constants take the registers the repair blocks of the sum check no longer need.
 ONES16 = [V(192, 4), V(200, 4), V(204, 4), V(248, 4)]
 LSV = V(228, 4)                                    # = LS[h][qb] at index 2 qb + h
+TS = V(240, 4)                                     # = TMP[0:4]: the other end of the fast bodies' row-sum chain (Gen16.sum_links)
 LM_MAX = float(2.0 ** 40)                          # a lane's share of a row sum at or above this (or NaN): redo the item in safe mode (see Gen16.__init__)
 CT16 = [V(176 + 4 * qg, 4) for qg in range(4)]     # -(reference) of this lane's row of q group qg, four copies (the C operand of a 16 x 16 tile)
 DSH16 = [[V(192), V(193)], [V(194), V(195)]]       # [h][qb]: pending shift of the NEXT tile's scores of row h of q block qb (see rare_fix)
@@ -135,15 +143,19 @@ class Gen16(base.Gen):
         # Without opt=ct (the f32-scale bodies: fast bodies are fma + exp + pack) the constants live in a[224:255]: at head dim 128 the K fragments
         # shrink to the 32-register pool of the ct bodies (k-steps 2, 3 are read into the slots of 0, 1), at head dim 64 those registers are free.
         self.lm = "lm" in self.opt
+        self.repairs = set()
         self.ones16 = ONES16 if self.ct else [A(224 + 4 * qg, 4) for qg in range(4)]
         if self.lm and not self.ct:
             self.kf16 = KF_POOL
             self.pool = hd == 128
-        self.npv, self.nqk = 8 * ndg + (8 if self.lm else 0), 16 * nks
+        # (round 6) the eight row-sum links of the tile a body's softmax streams produce (tile t + 1) ride in the LAST 24 gaps of that body's Q.K^T phase
+        # — behind the pack stream, AHEAD of P.V(t + 1) — so a fast body can look at the sums before a P beyond the 16-bit range has touched O: see
+        # qk_phase, body_end and lm_repair
+        self.npv, self.nqk = 8 * ndg, 16 * nks + (8 if self.lm else 0)
         self.ng = self.npv + self.nqk
         if self.lm:
-            lmw = ({"e": (20.0, 136.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 136.0), "kread_ct": (16.0, 72.0)} if hd == 128 else
-                   {"e": (12.0, 72.0), "vread": (40.0, 60.0), "se0": (0.0, 56.0), "se1": (8.0, 72.0), "kread_ct": (8.0, 40.0)})
+            lmw = ({"e": (20.0, 110.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 122.0), "kread_ct": (16.0, 60.0)} if hd == 128 else
+                   {"e": (12.0, 46.0), "vread": (40.0, 60.0), "se0": (0.0, 46.0), "se1": (8.0, 58.0), "kread_ct": (8.0, 30.0)})
             for k, w in lmw.items():
                 if k not in user:
                     self.cfg[k] = w
@@ -163,6 +175,16 @@ class Gen16(base.Gen):
                 for (kind, lo, hi) in base.Gen._regs(x)[0]:
                     for r in range(lo, hi):
                         last[(kind, r)] = i
+        if self.lm:
+            # the row-sum links read the packed P of the tile this body's softmax streams produce: every pack that writes a link's B registers must be
+            # ahead of it (the exp / pack windows are inputs: tools/kbench.py sweeps them)
+            ones = {(o.kind, o.idx) for o in self.ones16}
+            for i, x in enumerate(ins):
+                if x.op.startswith("v_mfma") and (x.ops[1].kind, x.ops[1].idx) in ones:
+                    lo, hi = x.ops[2].idx, x.ops[2].idx + x.ops[2].n
+                    for j in range(i + 1, len(ins)):
+                        if ins[j].op == self.cvt and lo <= ins[j].ops[0].idx < hi and ins[j].ops[0].kind == "v":
+                            raise ValueError("illegal schedule: a row-sum link (%s) ahead of a pack of its P registers (%s)" % (x, ins[j]))
         for i, x in enumerate(ins):
             if x.op == "ds_read_b64_tr_b16":
                 for (kind, lo, hi) in base.Gen._regs(x)[1]:
@@ -178,11 +200,51 @@ class Gen16(base.Gen):
                 for h in range(2):
                     acc = self.oacc16(dg, 2 * qb + h)
                     out.append(mk(self.mfma, acc, self.vf16(dg, kvs), b.sub(16 * h + 8 * kvs, 4), acc, tag="mfma"))
-                if self.lm and dg in (self.NDG // 2 - 1, self.NDG - 1):
-                    # the row sums of q group 2 qb + h, this k-step (NDG P.V MFMAs between two links of the LSV chain)
-                    h = int(dg == self.NDG - 1)
-                    out.append(mk(self.mfma, LSV, self.ones16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), LSV, tag="mfma"))
         return out
+
+    def sum_links(self, par_s, mode):
+        """opt=lm: the eight row-sum MFMAs of the tile whose packed P sits in the banks of parity par_s — (q block, P.V k-step, h), the order the pack
+        streams finish the registers in.  mode 'acc': D = C = LSV (max-first bodies: their P cannot overflow); 'to_ts': the chain starts from LSV and
+        ends in TS; 'to_lsv': from TS into LSV — the fast bodies alternate, so the tuple a chain started from still holds the sums of the tiles before
+        when the check behind the chain (body_end) fails."""
+        src, dst = {"acc": (LSV, LSV), "to_ts": (LSV, TS), "to_lsv": (TS, LSV)}[mode]
+        out = []
+        for qb in range(2):
+            b = SB(qb, par_s)
+            for kvs in range(2):
+                for h in range(2):
+                    out.append(mk(self.mfma, dst, self.ones16[2 * qb + h], b.sub(16 * h + 8 * kvs, 4), dst if out else src, tag="mfma"))
+        return out
+
+    def qk_phase(self, par, s1, s2, fast):
+        nq = 16 * self.NKS16
+        qk = self.qk_mfmas(par) if s2 else [None] * nq
+        if not self.lm:
+            return qk
+        links = self.sum_links(par ^ 1, ("to_ts" if par == 0 else "to_lsv") if fast else "acc") if s1 else [None] * 8
+        out = qk[:nq - 16]
+        for j in range(8):                # (link, two Q.K^T MFMAs) x 8: the chain's links three MFMAs apart, two MFMAs behind the last one
+            out += [links[j], qk[nq - 16 + 2 * j], qk[nq - 16 + 2 * j + 1]]
+        return out
+
+    def body_end(self, par, name, fast, s1):
+        """opt=lm, fast bodies: did the tile just packed (t + 1) overflow?  An fp16 P beyond 65504 is inf, its row sum inf, the other registers of the link's
+        tuple NaN (0 * inf); a share at or beyond LM_MAX fails too.  Nothing of that tile has touched O yet: lm_repair recomputes it in place."""
+        if not (self.lm and fast and s1):
+            return
+        p = self.p
+        x = TS if par == 0 else LSV
+        lab = "lm_repair_%d" % par
+        p.emit("v_max3_f32", TMP[4], x[0], x[1], x[2])
+        p.emit("s_nop", 0)
+        p.emit("v_max_f32", TMP[4], TMP[4], x[3])
+        p.emit("s_nop", 0)
+        p.emit("v_cmp_ngt_f32", VCC, LM_MAX, TMP[4])
+        p.emit("s_cbranch_vccnz", Label(lab))
+        p.label(lab + "_ret")
+        if lab not in self.repairs:
+            self.repairs.add(lab)
+            self.rare.append(self.lm_repair(lab, par))
 
     def qk_mfmas(self, par):
         out = []
@@ -395,6 +457,116 @@ class Gen16(base.Gen):
         r.append(mk("ds_write_b32", t, t2))
         r.append(mk("s_waitcnt", lgkmcnt=0))
         r.append(Ins("label", (Label(ok),)))
+
+    def lm_repair(self, lab, par):
+        """Out of line, end of fast body t (parity par; round 6): the row-sum chain of tile t + 1 came back inf / NaN / beyond LM_MAX — some P of that tile left
+        the 16-bit range (fp16: a score 16 octaves above its row's reference, which the fast bodies never move).  Nothing of the tile has touched O or the
+        sums yet (the links ride AHEAD of P.V(t + 1): qk_phase; the tuple the chain started from is intact: sum_links), so the tile is formed again IN
+        PLACE — the reference kernel's own recurrence (kernel_fp16.cu:434-490) for this one tile — and no work is thrown away:
+          K(t + 1) has left its LDS slot (K(t + 3) is landing there), so its fragments come straight from memory (L2: the tile was staged two bodies ago)
+          in the MFMA A layout, two k-steps at a time through the K fragment registers (idle between the bodies); Q.K^T(t + 1) again into the tile's
+          banks; the max-first streams of the head / tail bodies (stream_max -> the reference moves, stream_exp) on them, emitted in line; the scores of
+          tile t + 2 — all four k-steps done against the OLD reference — get the shift; O and the sums are rescaled at once (rare_rescale, in line); the
+          eight links again.  From here on the wave leaves the fast loop (S_NFAST = 0: the max-first bodies carry the rest of its sweep, ~12 % slower)
+          and asks the shell (flag word value 2: sticky, no redo) to start the workgroup's later items in safe mode: data that outgrew the fast
+          bodies once tends to do it again.
+        Cost: ~2 body times, once per wave and item at most."""
+        g = self.g
+        ps = par ^ 1
+        r = [Ins("label", (Label(lab),))]
+        e = r.append
+        e(mk("s_nop", 15))
+        e(mk("s_nop", 15))
+        if par == 1:                        # the chain ran TS -> LSV: TS holds the sums of the tiles before
+            for i in range(4):
+                e(mk("v_mov_b32", LSV[i], TS[i]))
+        # the sticky request first: a fail check further down (rare_rescale; the bodies behind the loop) overwrites it with the redo request, which implies it
+        e(mk("v_mov_b32", TMP[4], S_WAVE))
+        e(mk("v_mov_b32", TMP[5], 2))
+        e(mk("v_lshlrev_b32", TMP[4], 2, TMP[4]))
+        e(mk("s_nop", 0))
+        e(mk("v_add_u32", TMP[4], g.FAIL_OFF, TMP[4]))
+        e(mk("s_nop", 0))
+        e(mk("ds_write_b32", TMP[4], TMP[5]))
+        e(mk("s_waitcnt", lgkmcnt=0))
+        # ---- per-lane byte offsets of the K fragments: row n = lane % 16 of a 16-row kv group, granule 4 ks + g4 (g4 = lane / 16) of the row
+        lane, n, g4, t, mark = TMP[7], TMP[6], TMP[5], TMP[4], FS[0][0]
+        s_ng, s_tile, s_grp, s_off = S_SUM                                     # (trace builds only use them otherwise; the 16x16 generator has none)
+        e(mk("v_mbcnt_lo_u32_b32", lane, -1, 0))
+        e(mk("s_lshr_b32", s_grp, A_KTILE, 6))                                 # K row pitch in bytes
+        e(mk("v_mbcnt_hi_u32_b32", lane, -1, lane))
+        e(mk("s_lshr_b32", s_ng, A_FLAGS, 8))
+        e(mk("s_and_b32", s_ng, s_ng, 31))
+        e(mk("s_cmp_eq_u32", s_ng, 0))
+        e(mk("s_cselect_b32", s_ng, 64, s_ng))                                 # granules a row really has (trimmed head dims: trim_offsets; 0 = all)
+        e(mk("v_and_b32", n, 15, lane))
+        e(mk("v_lshrrev_b32", g4, 4, lane))
+        e(mk("v_mov_b32", mark, 0x80000000))
+        e(mk("v_mul_lo_u32", n, n, s_grp))
+        e(mk("v_lshlrev_b32", t, 4, g4))
+        e(mk("s_nop", 0))
+        e(mk("v_add_u32", n, n, t))
+        e(mk("s_sub_u32", s_tile, S_KOFF, A_KTILE))                            # S_KOFF: tile t + 3 (the LDS-DMA runs three tiles ahead)
+        e(mk("s_sub_u32", s_tile, s_tile, A_KTILE))
+        e(mk("s_lshl_b32", s_grp, s_grp, 4))                                   # 16 rows
+        for ks in range(self.NKS16):
+            e(mk("v_add_u32", t, 4 * ks, g4))
+            e(mk("v_add_u32", TMP[ks], 64 * ks, n))
+            e(mk("v_cmp_gt_u32", VCC, s_ng, t))                                # the row has this granule; otherwise an offset beyond every descriptor: zeros
+            e(mk("s_nop", 0))
+            e(mk("v_cndmask_b32", TMP[ks], mark, TMP[ks], VCC))
+        qk = self.qk_mfmas(ps)                                                 # ks major, 16 per k-step
+        for k0 in range(0, self.NKS16, 2):
+            e(mk("s_mov_b32", s_off, s_tile))
+            for kg in range(4):
+                for ks in (k0, k0 + 1):
+                    e(mk("buffer_load_dwordx4", self.kf16(kg, ks), TMP[ks], A_KRS, s_off, offen=True))
+                if kg < 3:
+                    e(mk("s_add_u32", s_off, s_off, s_grp))
+            e(mk("s_waitcnt", vmcnt=0))
+            r.extend(qk[16 * k0:16 * k0 + 32])
+            e(mk("s_nop", 15))
+        e(mk("s_nop", 15))
+        # ---- the tile's softmax, max-first: the reference moves (rare_m: MC, the C tuples, the bank's scores, FS, S_FLAG) ...
+        if self.fold:
+            for qb in range(2):
+                for h in range(2):
+                    e(mk("v_mov_b32", LIMQ[qb][h], MC[h][qb]))                 # (the limits of the masked bodies are set where they are used)
+
+        def inline(items):
+            for it in items:
+                for x in (it if isinstance(it, list) else [it]):
+                    e(x)
+                    if x.op != "label" and not x.op.startswith("s_"):
+                        e(mk("s_nop", 1))
+        for qb in range(2):
+            inline(self.stream_max(qb, ps, False))
+        if self.fold:
+            # ... the scores of tile t + 2 were formed against the old references
+            for qb in range(2):
+                b2 = SB(qb, par)
+                for h in range(2):
+                    e(mk("v_sub_f32", LIMQ[qb][h], MC[h][qb], LIMQ[qb][h]))
+                    e(mk("s_nop", 1))
+                    for i in range(16):
+                        e(mk("v_sub_f32", b2[16 * h + i], b2[16 * h + i], LIMQ[qb][h]))
+        # ... everything accumulated at the old references (O, the sums through tile t) is scaled now
+        rr = self.p.fresh("rare_r")
+        r.extend(self.rare_rescale(rr))
+        e(Ins("label", (Label(rr + "_ret"),)))
+        for qb in range(2):
+            inline(self.stream_exp(qb, ps))
+        e(mk("s_nop", 7))
+        for x in self.sum_links(ps, "acc"):
+            e(x)
+            e(mk("s_nop", 7))
+        e(mk("s_nop", 15))
+        if par == 0:                        # (F0's exit copies TS to LSV)
+            for i in range(4):
+                e(mk("v_mov_b32", TS[i], LSV[i]))
+        e(mk("s_mov_b32", S_NFAST, 0))
+        e(mk("s_branch", Label(lab + "_ret")))
+        return r
 
     def _row_reduce_max(self, r, x, t):
         """x = max of x over the four lanes of a row (l % 16 equal): exchange with the lane 16 away, then 32 away (t: scratch)"""
@@ -867,18 +1039,14 @@ class Gen16(base.Gen):
         self.body(0, guarded=False, name="F0")
         p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
-        p.emit("s_cbranch_scc0", Label("dispatch"))
-        self.body(1, guarded=False, name="F1")
         if self.lm:
-            # every other tile: has a row sum of this wave gone to inf (an fp16 P beyond 65504) / beyond LM_MAX?  The item will be redone in safe mode
-            # whatever this wave does from here on, so it stops computing: flag up, then stage-only bodies (its share of the LDS-DMA, the barriers)
-            # to the end of the sweep — a failed fast sweep costs the workgroup its memory traffic instead of a whole pass (tools/growth_cliff.py)
-            p.emit("v_max3_f32", TMP[0], LSV[0], LSV[1], LSV[2])
-            p.emit("s_nop", 0)
-            p.emit("v_max_f32", TMP[0], TMP[0], LSV[3])
-            p.emit("s_nop", 0)
-            p.emit("v_cmp_ngt_f32", VCC, LM_MAX, TMP[0])
-            p.emit("s_cbranch_vccnz", Label("lm_abort"))
+            # (F0's row-sum chain ended in TS: the max-first bodies behind the loop keep the sums in LSV)
+            p.emit("s_cbranch_scc0", Label("f0_exit"))
+            self.rare.append([Ins("label", (Label("f0_exit"),))] + [mk("v_mov_b32", LSV[i], TS[i]) for i in range(4)] +
+                             [mk("s_nop", 0), mk("s_branch", Label("dispatch"))])
+        else:
+            p.emit("s_cbranch_scc0", Label("dispatch"))
+        self.body(1, guarded=False, name="F1")
         p.emit("s_sub_u32", S_NFAST, S_NFAST, 1)
         p.emit("s_cmp_gt_i32", S_NFAST, 0)
         p.emit("s_cbranch_scc1", Label("fast0"))
@@ -998,23 +1166,6 @@ class Gen16(base.Gen):
                 p.emit("s_nop", 3)             # (a store of more than 64 bits: its data registers must not be rewritten right behind it)
         p.emit("s_waitcnt", vmcnt=0)           # the stores, and whatever the item seam prefetched: the next statement counts loads only
         p.emit("s_branch", Label("lse_out"))
-        if self.lm:
-            # ---- a wave whose row sums overflowed in the fast loop (see there): raise the flag, stage to the end of the sweep, leave without an epilogue
-            p.label("lm_abort")
-            blk = []
-            self.lm_fail_check(blk, TMP[0], TMP[2], TMP[3])
-            p.ins.extend(blk)
-            p.label("lm_abort_loop")
-            p.emit("s_cmp_ge_i32", S_T, A_NTWG)
-            p.emit("s_cbranch_scc1", Label("end"))
-            p.emit("s_and_b32", S_TMP, S_T, 1)
-            p.emit("s_cmp_eq_u32", S_TMP, 1)
-            p.emit("s_cbranch_scc1", Label("lm_abort_odd"))
-            self.body(0, pv=False, s1=False, s2=False, name="ST0a")
-            p.emit("s_branch", Label("lm_abort_loop"))
-            p.label("lm_abort_odd")
-            self.body(1, pv=False, s1=False, s2=False, name="ST1a")
-            p.emit("s_branch", Label("lm_abort_loop"))
         for r in self.rare:
             p.extend(r)
         p.label("end")

@@ -52,11 +52,17 @@ def test_m16_block_matches_dense_attention(case, m16):
     assert not m.errors, m.errors[:5]
     tol = (8e-3 if bf16 else 1e-3) * (3 if spike else 1)
     lm = "lm" in m16
-    assert err <= tol and lerr <= ((4e-3 if bf16 else 1e-3) if lm else 1e-4), (err, lerr)
+    # (lm, bf16: a row with one dominant key carries the rounding of that P — up to log2(1 + 2^-8) = 5.6e-3 — unless the reference sits exactly on its score:
+    #  tests/conftest.py LSE_TOL_P16_BF16; the spike cases make such rows)
+    assert err <= tol and lerr <= (((6e-3 if spike else 4e-3) if bf16 else 1e-3) if lm else 1e-4), (err, lerr)
     if spike == 2 and not lm:
-        assert m.redos == 0            # repaired in place (lm: no repair — a P beyond the 16-bit range costs the item a second sweep)
+        assert m.redos == 0            # repaired in place by the sum check's rare block
     if spike in (True, 3):
-        assert m.redos == 1
+        # the sum-check bodies cannot repair P = inf / growth beyond 120 octaves: redo.  The lm bodies (round 6) see the row sums of a tile AHEAD of its
+        # P.V, form the tile again in place with the max-first streams and finish the sweep on the max-first bodies: nothing is redone (Gen16.lm_repair)
+        assert m.redos == (0 if lm else 1)
+    if lm and spike:
+        assert getattr(m, "repairs", 0) >= 1 or spike == 2
 
 
 def test_m16_fast_bodies_carry_no_cross_lane_instruction():
@@ -72,10 +78,10 @@ def test_m16_fast_bodies_carry_no_cross_lane_instruction():
     assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 2 * (136 if lm else 128)
     assert not any(o.startswith("v_permlane") for o in ops)
     if lm:
-        # exp + pack and nothing else: no add, no per-tile check, no repair block; per two tiles ONE look at the wave's four row sums (v_max3 + v_max +
-        # v_cmp + branch: the per-wave abort of a sweep that is going to be redone anyway)
+        # exp + pack and nothing else: no add, no row maximum; per tile ONE look at the wave's four row sums of the tile just packed — v_max3 + v_max +
+        # v_cmp + branch, behind the body's last MFMA and AHEAD of the tile's P.V (round 6: the in-place repair, Gen16.lm_repair, is out of line)
         assert not any(o in ("v_add_f32", "v_cmp_nge_f32") for o in ops)
-        assert [o for o in ops if o.startswith("v_max") or o.startswith("v_cmp") or o == "s_cbranch_vccnz"] == ["v_max3_f32", "v_max_f32", "v_cmp_ngt_f32", "s_cbranch_vccnz"]
+        assert [o for o in ops if o.startswith("v_max") or o.startswith("v_cmp") or o == "s_cbranch_vccnz"] == 2 * ["v_max3_f32", "v_max_f32", "v_cmp_ngt_f32", "s_cbranch_vccnz"]
     else:
         assert not any(o.startswith("v_max") for o in ops)
         assert sum(o == "v_exp_f32" for o in ops) == 2 * 64 and sum(o.startswith("v_cvt_pk") for o in ops) == 2 * 32
@@ -193,7 +199,7 @@ def test_m16_head_dim_64_block_matches_dense_attention(case, m16_d64):
     lm = "lm" in m16_d64
     assert err <= (8e-3 if bf16 else 1e-3) * (3 if spike else 1) and lerr <= ((4e-3 if bf16 else 1e-3) if lm else 1e-4), (err, lerr)
     if spike:
-        assert m.redos == 1
+        assert m.redos == (0 if lm else 1) and (not lm or m.repairs >= 1)       # (lm, round 6: repaired in place — Gen16.lm_repair)
 
 
 def test_m16_head_dim_64_persistent_seams_and_text(m16_d64, tmp_path):
@@ -245,11 +251,77 @@ def test_m16_items_after_a_redo_start_in_safe_mode():
     items = [(q, k, v, 0), (q, k, v, 1), (rng.standard_normal((256, 128)), rng.standard_normal((320, 128)), rng.standard_normal((320, 128)), 0)]
     outs, m = harness.run_items(items, False)
     assert not m.errors, m.errors[:5]
-    assert m.redos == 1                     # the first item only; the two after it never entered a fast body
     lm = "lm" in harness.OPT
+    if lm:
+        # round 6: the tile is repaired in place (no redo); the wave asks for the sticky bit all the same, and the items after it never enter a fast body
+        assert m.redos == 0 and m.repairs >= 1 and [f & 48 for f in m.item_flags] == [0, 48, 48]
+    else:
+        assert m.redos == 1                 # the first item only; the two after it never entered a fast body
     for (qq, kk, vv, qb), (o, lse) in zip(items, outs):
         o_ref, lse_ref = harness.dense(qq[qb * 256:qb * 256 + 256], kk, vv, False, pre="ct" in harness.OPT)
         assert np.abs(o - o_ref).max() <= 3e-3 and np.abs(lse - lse_ref).max() <= (1e-3 if lm else 1e-4)
+
+
+REPAIRS = [
+    # opt, head dim of the body, D (None: the body's), bf16, causal, Nq, Nkv, q block, spikes [(row, kv, factor)], the repair blocks that must run
+    (("ct", "lm"), 128, None, False, False, 256, 704, 0, [(5, 200, 2.7)], {"lm_repair_0"}),             # tile 3: found by F0 (t = 2)
+    (("ct", "lm"), 128, None, False, False, 256, 704, 0, [(70, 150, 2.7)], {"lm_repair_1"}),            # tile 2: found by F1 (t = 1), wave 1
+    (("ct", "lm"), 128, None, False, False, 256, 704, 0, [(5, 200, 2.7), (40, 130, 2.0), (200, 330, 3.0)], {"lm_repair_0", "lm_repair_1"}),
+    (("ct", "lm"), 128, None, True, False, 256, 704, 0, [(5, 200, 5.0)], {"lm_repair_0"}),              # bf16 folded: a share beyond 2^40
+    (("lm",), 128, None, True, False, 256, 704, 0, [(5, 200, 5.0), (130, 150, 5.0)], {"lm_repair_0", "lm_repair_1"}),   # the f32-scale bodies (bf16's default)
+    (("lm",), 128, None, False, False, 256, 704, 0, [(5, 200, 2.7)], {"lm_repair_0"}),
+    (("ct", "lm"), 128, None, False, True, 1024, 1024, 3, [(800, 200, 2.7), (1000, 400, 2.7)], {"lm_repair_0", "lm_repair_1"}),   # causal: waves of different sweep lengths
+    (("ct", "lm"), 128, 96, False, False, 256, 704, 0, [(5, 200, 3.0)], {"lm_repair_0"}),               # a head dim below the body's: the padded columns read as zeros
+    (("lm",), 128, 120, True, False, 256, 704, 0, [(5, 150, 6.0)], {"lm_repair_1"}),
+    (("ct", "lm"), 64, None, False, False, 256, 704, 0, [(5, 200, 3.5), (70, 150, 3.5)], {"lm_repair_0", "lm_repair_1"}),
+    (("ct", "lm"), 64, 40, False, False, 256, 704, 0, [(5, 200, 5.0)], {"lm_repair_0"}),
+    (("lm",), 64, None, True, False, 256, 704, 0, [(5, 200, 8.0)], {"lm_repair_0"}),
+]
+
+
+@pytest.mark.parametrize("case", REPAIRS)
+def test_m16_lm_bodies_repair_an_overflowing_tile_in_place(case, m16):
+    """Round 6.  The fast bodies of the lm kernels never move the reference; a score 16 octaves above it (fp16: P = inf) used to send the whole ITEM through
+    a second, safe-mode sweep.  Now the row-sum links of a tile ride ahead of its P.V, the fast body looks at them, and a wave that finds inf / NaN / a
+    share beyond 2^40 forms that one tile again — K fragments straight from memory, the max-first streams — and finishes its sweep on the max-first
+    bodies (Gen16.lm_repair): exact results, nothing redone, the sticky request raised.  Both parities of the fast loop, every kernel kind that ships."""
+    if m16:
+        pytest.skip("one pass is enough")
+    import asm_emu
+    opt, hd, d, bf16, causal, Nq, Nkv, qblk, spikes, blocks = case
+    saved = harness.HD, harness.OPT, harness.DTRIM
+    harness.HD, harness.OPT, harness.DTRIM = hd, opt, d
+    harness._PROGS.clear()
+    hits = set()
+    step = asm_emu.Machine.step
+
+    def counting_step(self, w):
+        ins = self.ins[w.pc]
+        if ins.op == "label" and ins.ops[0].name in ("lm_repair_0", "lm_repair_1"):
+            hits.add(ins.ops[0].name)
+        return step(self, w)
+    asm_emu.Machine.step = counting_step
+    try:
+        D = d or hd
+        rng = np.random.default_rng(Nq + Nkv + D)
+        q, k, v = rng.standard_normal((Nq, D)), rng.standard_normal((Nkv, D)), rng.standard_normal((Nkv, D))
+        for (row, kv, f) in spikes:
+            k[kv] = q[row] * f * (128.0 / D) ** 0.5
+        # a second item behind it: starts in safe mode (sticky), prefetched through the seam like any other
+        items = [(q, k, v, qblk), (q, k[:320], v[:320], 0)]
+        outs, m = harness.run_items(items, causal, bf16=bf16)
+        assert not m.errors, m.errors[:5]
+        assert m.redos == 0 and m.repairs >= 1 and hits == blocks, (m.redos, m.repairs, hits)
+        assert [f & 48 for f in m.item_flags] == [0, 48]
+        for (qq, kk, vv, qb), (o, lse) in zip(items, outs):
+            r0 = qb * 256
+            o_ref, lse_ref = harness.dense(qq[r0:r0 + o.shape[0]], kk, vv, causal, bf16=bf16, row0=r0, pre="ct" in opt)
+            assert np.isfinite(o).all() and np.isfinite(lse).all()
+            assert np.abs(o - o_ref).max() <= (2.4e-2 if bf16 else 3e-3) and np.abs(lse - lse_ref).max() <= (6e-3 if bf16 else 1e-3)
+    finally:
+        asm_emu.Machine.step = step
+        harness.HD, harness.OPT, harness.DTRIM = saved
+        harness._PROGS.clear()
 
 
 @pytest.mark.parametrize("hd,d,opt", [(64, 40, ("ct", "lm")), (64, 56, ("ct", "lm")), (64, 8, ("ct", "lm")), (128, 96, ("ct", "lm")), (128, 120, ("lm",)), (128, 104, ())])

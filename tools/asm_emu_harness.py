@@ -195,12 +195,21 @@ def run_items(items, causal, scale=None, bf16=False, check_hazards=True):
             m = asm_emu.Machine(program(bf16), wa, geo().LDS_BYTES, bufs, bf16=bf16, check_hazards=check_hazards)
             m.lds[geo().FAIL_OFF:geo().FAIL_OFF + 16] = 0           # (the shell clears the workgroup's flag words before the first statement)
             m.redos = 0
+            m.repairs = 0
+            m.item_flags = []
         else:
             m.reenter(wa)
         m.allow_vm_in_flight = nxt is not None
+        m.item_flags.append(flags)
         for w, a in zip(m.waves, wa):
             w.v[:24] = a["vregs"]
         m.run()
+        fw = m.lds[geo().FAIL_OFF:geo().FAIL_OFF + 16].view(np.uint32).copy()
+        if fw.any() and not (fw & 1).any():
+            # value 2: a wave of the lm bodies repaired a tile in place (Gen16.lm_repair) — no redo, but the items after this one start in safe mode
+            m.lds[geo().FAIL_OFF:geo().FAIL_OFF + 16] = 0
+            m.repairs += int((fw == 2).sum())
+            sticky = 16 | 32
         if m.lds[geo().FAIL_OFF:geo().FAIL_OFF + 16].any():
             # a sum-check body met a non-finite P (fwd_d128_gen.py: rare_sum): like the shell, clear the flag words and run the SAME item again in
             # safe mode (flag bit 4), nothing staged (the failed attempt's seam bodies fetched the NEXT item's Q / K / V over this item's)

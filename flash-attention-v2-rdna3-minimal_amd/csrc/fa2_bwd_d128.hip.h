@@ -30,6 +30,9 @@ typedef uint32_t bwd_u32x4s __attribute__((ext_vector_type(4)));
 // granule swizzle of the unified LDS image format (f_swz of the generator): one image serves ds_read_b128 row reads and
 // ds_read_b64_tr_b16 transposed reads
 __device__ __forceinline__ uint32_t bwd_swz(uint32_t r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); }
+// ... under the 16x16x32 dK / dV bodies (f_swz16 of the generator, round 6): their lane groups hit every bank twice with the one above
+__device__ __forceinline__ uint32_t bwd_swz16(uint32_t r) { return (r & 7u) << 1; }
+template <bool M16> __device__ __forceinline__ uint32_t bwd_swz_of(uint32_t r) { return M16 ? bwd_swz16(r) : bwd_swz(r); }
 
 // ---------------------------------------------------------------------------------------------------------
 // dQ pass: workgroup = 256 Q rows (4 waves x 64), sweep over KV tiles of 32.  Also writes delta = rowsum(dO * O).
@@ -105,11 +108,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_d128_kernel(const BwdParams p) 
 #else
     const uint32_t kd0 = drow * k_rowb + ((dslot ^ (drow & 15u)) << 4);                                   // row images: granule ^ (row & 15)
     const uint32_t vd0 = drow * v_rowb + ((dslot ^ (drow & 15u)) << 4);
-    const uint32_t td0 = drow * k_rowb + (((((dslot >> 2) ^ (drow & 3u)) << 2) | (dslot & 3u)) << 4);     // "tr" image: 64-B chunk ^ (row & 3)
+    // "tr" image: 64-B chunk ^ (row & 3); under the 16x16x32 body (round 6) the 32-byte half of a chunk is also flipped for rows with (row >> 2) & 1:
+    // a transposed read serves rows r and r + 4 in one cycle there, which the plain image keeps in the same banks (SQ_LDS_BANK_CONFLICT 26 % of the
+    // pass's LDS cycles, profiles/r19_bwd_c2_pmc.txt; the forward's "ct" V image is the same fix)
+    const uint32_t td0 = drow * k_rowb + (((((dslot >> 2) ^ (drow & 3u)) << 2) | ((dslot & 3u) ^ (M16 ? ((drow >> 2) & 1u) << 1 : 0u))) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1;
     const uint32_t trow16 = 4u * g4 + (n16 >> 2);
     const uint32_t kr0 = M16 ? (uint32_t)n16 * 256u + (((uint32_t)g4 ^ (uint32_t)n16) << 4) : (uint32_t)l31 * 256u + (((uint32_t)hi ^ ((uint32_t)l31 & 15u)) << 4);
-    const uint32_t vr0 = M16 ? trow16 * 256u + ((trow16 & 3u) << 6) + 8u * (n16 & 3) : (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
+    const uint32_t vr0 = M16 ? trow16 * 256u + ((trow16 & 3u) << 6) + 32u * ((trow16 >> 2) & 1u) + 8u * (n16 & 3) : (4u * hi + (pp >> 2)) * 256u + ((pp >> 2) << 6) + 32u * g1 + 8u * (pp & 3);
 #endif
     const uint32_t epi = M16 ? kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + n16 * kBwdEpiRowB + g4 * 8
                              : kBwdDqEpiBase + wave * 64 * kBwdEpiRowB + l31 * kBwdEpiRowB + hi * 16;
@@ -239,18 +245,18 @@ __global__ __launch_bounds__(256, 1) void bwd_dkv_d128_kernel(const BwdParams p)
         lim[0] = CAUSAL ? kvw0 + (int)n16 - kBwdTile * tile0 - 4 * (int)g4 : -(1 << 30);
     }
     const uint32_t drow = 8u * wave + (lane >> 4), dslot = lane & 15;
-    const uint32_t gd0 = drow * g_rowb + ((dslot ^ bwd_swz(drow)) << 4);
+    const uint32_t gd0 = drow * g_rowb + ((dslot ^ bwd_swz_of<M16>(drow)) << 4);
 #ifdef FA2_BWD_QSPLIT     // (bodies generated with option "qsplit": of a pair's four Q pieces the P side stages row quad 0, the dS side quads 1..3)
     const uint32_t qrow0 = 16u * pair + (role ? 4u : 0u);
 #else
     const uint32_t qrow0 = 8u * wave;
 #endif
     const uint32_t qdrow = qrow0 + (lane >> 4);
-    const uint32_t qd0 = qdrow * q_rowb + ((dslot ^ bwd_swz(qdrow)) << 4);
+    const uint32_t qd0 = qdrow * q_rowb + ((dslot ^ bwd_swz_of<M16>(qdrow)) << 4);
     const uint32_t pp = lane & 15, g1 = (lane >> 4) & 1, ti = pp >> 2, tj = pp & 3, trow = 4u * hi + ti;
     const uint32_t tq16 = 4u * g4 + (n16 >> 2);
-    const uint32_t kr0 = M16 ? n16 * 256u + ((g4 ^ bwd_swz(n16)) << 4) : (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
-    const uint32_t vr0 = M16 ? tq16 * 256u + ((((n16 & 3u) >> 1) ^ bwd_swz(tq16)) << 4) + 8u * (n16 & 1u)
+    const uint32_t kr0 = M16 ? n16 * 256u + ((g4 ^ bwd_swz16(n16)) << 4) : (uint32_t)l31 * 256u + (((uint32_t)hi ^ bwd_swz(l31)) << 4);
+    const uint32_t vr0 = M16 ? tq16 * 256u + ((((n16 & 3u) >> 1) ^ bwd_swz16(tq16)) << 4) + 8u * (n16 & 1u)
                              : trow * 256u + (((2u * g1 + (tj >> 1)) ^ bwd_swz(trow)) << 4) + 8u * (tj & 1);
     const uint32_t pxa = kBwdKvPSlots + pair * 8192 + lane * 16, lda = (M16 ? 16u * g4 : 16u * hi) + 512u * role, l4 = M16 ? fo3 : 4u * lane;
     if constexpr (M16) lim[1] = (int)fo2;

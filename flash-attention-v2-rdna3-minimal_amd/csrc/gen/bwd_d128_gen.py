@@ -54,6 +54,15 @@ def _flat(items):
     return out
 
 
+def f_swz16(r):
+    """the unified image's granule swizzle under the 16x16x32 bodies (round 6; bwd_dkv_m16_gen.py).  A lane is (n = l % 16, g = l / 16) there: a row
+    read's lane group holds g = a for n in {0..3, 12..15} and g = a ^ 1 for n in {4..11}, a transposed read serves rows 4 g + (n >> 2) of two 16-lane
+    groups per cycle — under f_swz both kinds hit every bank twice (SQ_LDS_BANK_CONFLICT 3.4e7 of 8.6e7 LDS cycles per c2 launch,
+    profiles/r19_bwd_c2_pmc.txt; round 4's 32 x 32 bodies: 2.6e5).  (r & 7) << 1 gives a row read's 16 lanes 16 different slots ((4 ks + g) ^ f: the
+    even slots to one half of the group, the odd ones to the other) and the eight rows of a transposed read eight different 32-byte slot pairs."""
+    return (r & 7) << 1
+
+
 class BodyEmitter:
     """What the bodies of both backward kernels share: fillers placed into MFMA gaps, counted LDS waits, the end-of-body sync."""
 

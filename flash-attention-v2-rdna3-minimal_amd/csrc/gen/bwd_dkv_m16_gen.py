@@ -29,7 +29,7 @@ from isa import A, V, Arg, Ins, Label, M0, Neg, VCC, mk  # noqa: E402
 # ---- operands: GenDKV's list (fa2_bwd_d128.hip.h) with four positions re-read
 A_FO = [Arg(0), Arg(1), Arg(7), Arg(10)]           # byte offset of this lane's 16 bytes (k-step 0) of its own K / V row of group kvg: clamp(row) * pitch + 16 g
 A_LIM0 = Arg(6)                                    # P side, causal: kv row of group 0 minus the first tile's q0 minus 4 g; -2^30 otherwise
-# (A_KR0: n * 256 + ((g ^ f(n)) << 4);  A_VR0: q * 256 + ((((n & 3) >> 1) ^ f(q)) << 4) + 8 (n & 1), q = 4 g + (n >> 2);  A_LDA: 16 g + 512 role;
+# (A_KR0: n * 256 + ((g ^ f(n)) << 4);  A_VR0: q * 256 + ((((n & 3) >> 1) ^ f(q)) << 4) + 8 (n & 1), q = 4 g + (n >> 2), f = f_swz16;  A_LDA: 16 g + 512 role;
 #  A_EPI: wave * 64 * 272 + n * 272 + 8 g)
 
 # ---- registers (KV's map where the meaning is the same: banks v16..79, row fragments v112..143, transposed fragments v144..175, PR, TMP, XA, QD, GD)
@@ -239,11 +239,11 @@ class GenDKV16(base.GenDKV):
             for ks in range(4):
                 p.emit("global_load_dwordx4", FF16(kvg, ks), A_FO[kvg], KV.A_FB, offset=64 * ks)
         p.emit("v_lshlrev_b32", L4R, 2, L4R)
-        # DMA source offsets of piece 1: rows 4 further down flip bit 0 of the unified granule swizzle
+        # DMA source offsets of piece 1: rows 4 further down flip bit 3 of this generator's granule swizzle (bwd_d128_gen.f_swz16: (r & 7) << 1)
         p.emit("v_mov_b32", KV.QD[0], KV.A_QD0)
         p.emit("v_mov_b32", KV.GD[0], KV.A_GD0)
-        p.emit("v_xor_b32", KV.QD[1], 16, KV.A_QD0)
-        p.emit("v_xor_b32", KV.GD[1], 16, KV.A_GD0)
+        p.emit("v_xor_b32", KV.QD[1], 128, KV.A_QD0)
+        p.emit("v_xor_b32", KV.GD[1], 128, KV.A_GD0)
         p.emit("v_mov_b32", KV.XA, KV.A_PXA)
         p.emit("v_add_u32", KV.QD[1], KV.A_QROW4, KV.QD[1])
         p.emit("v_add_u32", KV.GD[1], KV.A_GROW4, KV.GD[1])

@@ -38,7 +38,8 @@ A_LIM0, A_LIM1 = DQ.A_LIM0, DQ.A_LIM1  # masks of the wave's last two tiles: row
 # ---- register map (what differs from DQ's; KD / VD / TD, the SGPRs and the LDS layout are DQ's: GenDQ.dma_group is inherited)
 KR = [V(216 + i) for i in range(4)]                # row-fragment read addresses, k-step ks (32 head-dim columns)
 NL = [V(220 + i) for i in range(4)]                # -LSE of this lane's row of q group qg
-VR = DQ.VR                                         # transposed read addresses, 64-byte chunk dg >> 1 (v224..227)
+VR = DQ.VR                                         # transposed read addresses, 64-byte chunk dg >> 1 (v224..227), even d groups ...
+VRO = DQ.VRB                                       # ... and odd ones (v246..249): the other 32-byte half, whose side depends on the lane's row (stream_trread)
 DD = [V(234 + i) for i in range(4)]                # delta of this lane's row of q group qg
 TMP = DQ.TMP                                       # v238..245
 LIMQ = [[V(250), V(251)], [V(252), V(253)]]        # masked bodies: limits of the two rows of q block qb
@@ -151,10 +152,15 @@ class GenDQ16(base.GenDQ):
 
     def stream_trread(self, par):
         out = []
+        # A read's lanes 0..31 are the 16-lane groups g = 0, 1: rows 4 g + (n >> 2), i.e. rows r and r + 4 of the tile in one cycle.  The "tr" image
+        # (64-byte chunk ^ (row & 3)) kept those in the same banks: a 2-way conflict on every read, 26 % of the pass's LDS cycles
+        # (profiles/r19_bwd_c2_pmc.txt).  Round 6: the image flips the 32-byte half of a chunk for rows with (row >> 2) & 1 (fa2_bwd_d128.hip.h: td0, vr0),
+        # and the odd d groups — the other half, on a side that depends on the lane's row — are read through a second address set.
         for dg in range(8):
-            off = DQ.TR_RING + par * DQ.TR_SLOT + 32 * (dg & 1)
-            out.append(mk("ds_read_b64_tr_b16", TP(dg).sub(0, 2), VR[dg >> 1], tag="lds", offset=off))
-            out.append(mk("ds_read_b64_tr_b16", TP(dg).sub(2, 2), VR[dg >> 1], tag="lds", offset=off + 16 * 256))
+            off = DQ.TR_RING + par * DQ.TR_SLOT
+            adr = (VRO if dg & 1 else VR)[dg >> 1]
+            out.append(mk("ds_read_b64_tr_b16", TP(dg).sub(0, 2), adr, tag="lds", offset=off))
+            out.append(mk("ds_read_b64_tr_b16", TP(dg).sub(2, 2), adr, tag="lds", offset=off + 16 * 256))
         return out
 
     # ------------------------------------------------------------------ one body
@@ -211,6 +217,7 @@ class GenDQ16(base.GenDQ):
             p.emit("v_xor_b32", KR[ks], ks << 6, DQ.A_KR0)
         for j in range(4):
             p.emit("v_xor_b32", VR[j], j << 6, DQ.A_VR0)
+            p.emit("v_xor_b32", VRO[j], (j << 6) | 32, DQ.A_VR0)
         # ---- fragment loads.  Row offsets of this lane's four rows: min(ROW0 + 16 qg, Nq - 1) * pitch + 16 g, per matrix (T[0..3]: Q, T[4..7]: dO;
         #      O after the dO loads are issued, in T[4..7] again; the L offsets reuse the clamped rows)
         tg, to = V(24, 64), V(88, 64)              # dO / O pass through the (still unused) S / dP banks for delta
@@ -253,7 +260,9 @@ class GenDQ16(base.GenDQ):
         p.emit("v_mov_b32", DQ.TD[0], DQ.A_TD0)
         p.emit("v_xor_b32", DQ.KD[1], 64, DQ.A_KD0)
         p.emit("v_xor_b32", DQ.VD[1], 64, DQ.A_VD0)
-        p.emit("v_add_u32", DQ.TD[1], DQ.A_KROW4, DQ.A_TD0)
+        p.emit("v_xor_b32", DQ.TD[1], 32, DQ.A_TD0)                     # piece 1: rows 4 further down — the flipped half of the "tr" image
+        p.emit("s_nop", 0)
+        p.emit("v_add_u32", DQ.TD[1], DQ.A_KROW4, DQ.TD[1])
         p.emit("s_nop", 0)
         p.emit("v_add_u32", DQ.KD[1], DQ.A_KROW4, DQ.KD[1])
         p.emit("v_add_u32", DQ.VD[1], DQ.A_VROW4, DQ.VD[1])

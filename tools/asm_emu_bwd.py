@@ -123,7 +123,10 @@ def dq_wave_args(w, qblk, Nq, Nkv, causal, scale, bases):
         v[8] = v[9] = 0
         v[13] = (n16 * 256 + ((g4 ^ n16) << 4)).astype(np.uint32)
         trow = 4 * g4 + (n16 >> 2)
-        v[14] = (trow * 256 + ((trow & 3) << 6) + 8 * (n16 & 3)).astype(np.uint32)
+        # the 16x16x32 body's own "tr" image (round 6): the 32-byte half of a 64-byte chunk is flipped for rows with (row >> 2) & 1 — a transposed read
+        # serves rows r and r + 4 in one cycle, which the plain image keeps in the same banks
+        v[12] = (drow * rb + (((((dslot >> 2) ^ (drow & 3)) << 2) | ((dslot & 3) ^ (((drow >> 2) & 1) << 1))) << 4)).astype(np.uint32)
+        v[14] = (trow * 256 + ((trow & 3) << 6) + 32 * ((trow >> 2) & 1) + 8 * (n16 & 3)).astype(np.uint32)
         l0 = ((qw0 + n16) if causal else np.full(64, 0x3fff0000)) - 32 * (ntw - 1) - 4 * g4
         cap = np.full(64, Nkv - 1) - 32 * (ntw - 1) - 4 * g4
         v[15] = l0.astype(np.int32).view(np.uint32)
@@ -235,9 +238,10 @@ def dkv_wave_args(w, kblk, Nq, Nkv, causal, scale, bases):
             v[slot] = (kr * rb + 16 * g4).astype(np.uint32)
         lim = (kvw0 + n16 - 32 * tile0 - 4 * g4) if causal else np.full(64, -(1 << 30))
         v[6] = lim.astype(np.int32).view(np.uint32)
-        v[4] = (n16 * 256 + ((g4 ^ gen.f_swz(n16)) << 4)).astype(np.uint32)
+        v[2] = v[3] = (drow * rb + ((dslot ^ gen.f_swz16(drow)) << 4)).astype(np.uint32)       # (the 16x16x32 bodies' own granule swizzle: f_swz16)
+        v[4] = (n16 * 256 + ((g4 ^ gen.f_swz16(n16)) << 4)).astype(np.uint32)
         tq = 4 * g4 + (n16 >> 2)
-        v[5] = (tq * 256 + ((((n16 & 3) >> 1) ^ gen.f_swz(tq)) << 4) + 8 * (n16 & 1)).astype(np.uint32)
+        v[5] = (tq * 256 + ((((n16 & 3) >> 1) ^ gen.f_swz16(tq)) << 4) + 8 * (n16 & 1)).astype(np.uint32)
         v[9] = (g4 * 16 + role * 512).astype(np.uint32)
         v[11] = (w * 64 * KV.EPI_ROWB + n16 * KV.EPI_ROWB + g4 * 8).astype(np.uint32)
     args = {k: Reg("v", k) for k in range(KV.N_VARGS)}

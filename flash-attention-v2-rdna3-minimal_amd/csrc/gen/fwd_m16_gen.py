@@ -154,14 +154,24 @@ class Gen16(base.Gen):
         self.npv, self.nqk = 8 * ndg, 16 * nks + (8 if self.lm else 0)
         self.ng = self.npv + self.nqk
         if self.lm:
-            lmw = ({"e": (20.0, 110.0), "vread": (74.0, 110.0), "se0": (0.0, 96.0), "se1": (24.0, 122.0), "kread_ct": (16.0, 60.0)} if hd == 128 else
-                   {"e": (12.0, 46.0), "vread": (40.0, 60.0), "se0": (0.0, 46.0), "se1": (8.0, 58.0), "kread_ct": (8.0, 30.0)})
+            # link gaps lk0 .. lk3 (q block 0: P.V k-step 0, 1; q block 1: k-step 0, 1): a link needs the packs of ITS registers only, and a pack stream
+            # finishes k-step 0 of both rows at its half — so only the last two links wait for the end of q block 1's stream
+            # Measured against the round-5 library (links inside the NEXT body's P.V phase, no per-tile check), one box, tools/kbench.py
+            # (profiles/r20_kbench_windows*.txt): links in the last 24 gaps + the round-5 windows squeezed in front of them -2.2 % (c2), -4 % (head dim 64);
+            # these link gaps -1.1 %; with the V^T reads moved into the gaps the squeeze left empty (vread 104:136 / 52:72) -0.5 % (c2), -0.3 % (c4),
+            # -0.6 .. 1.7 % (head dim 64): what the repair costs data that never needs it.
+            lmw = ({"e": (20.0, 110.0), "vread": (104.0, 136.0), "se0": (0.0, 96.0), "se1": (24.0, 128.0), "kread_ct": (16.0, 60.0),
+                    "lk0": (100.0, 103.0), "lk1": (106.0, 109.0), "lk2": (112.0, 115.0), "lk3": (130.0, 132.0)} if hd == 128 else
+                   {"e": (12.0, 46.0), "vread": (52.0, 72.0), "se0": (0.0, 50.0), "se1": (8.0, 66.0), "kread_ct": (8.0, 30.0),
+                    "lk0": (52.0, 54.0), "lk1": (56.0, 58.0), "lk2": (60.0, 62.0), "lk3": (67.0, 69.0)})
             for k, w in lmw.items():
                 if k not in user:
                     self.cfg[k] = w
-            for k, w in user.items():         # "lm_<key>": a schedule tunable of the lm bodies only (window sweeps, tools/kbench.py)
-                if k.startswith("lm_"):
+            for k, w in cfg.items():          # "lm_<key>" (head dim 128) / "d64_lm_<key>" (64): a schedule tunable of the lm bodies only (window sweeps, tools/kbench.py)
+                if hd == 128 and k.startswith("lm_"):
                     self.cfg[k[3:]] = w
+                elif hd == 64 and k.startswith("d64_lm_"):
+                    self.cfg[k[7:]] = w
 
     def body(self, par, *args, **kw):
         start = len(self.p.ins)
@@ -222,9 +232,20 @@ class Gen16(base.Gen):
         if not self.lm:
             return qk
         links = self.sum_links(par ^ 1, ("to_ts" if par == 0 else "to_lsv") if fast else "acc") if s1 else [None] * 8
-        out = qk[:nq - 16]
-        for j in range(8):                # (link, two Q.K^T MFMAs) x 8: the chain's links three MFMAs apart, two MFMAs behind the last one
-            out += [links[j], qk[nq - 16 + 2 * j], qk[nq - 16 + 2 * j + 1]]
+        # the links sit in the gaps cfg lk0 .. lk3 name (two each, chain order), the Q.K^T MFMAs in the phase's other gaps in their own order.  Behind
+        # Q.K^T MFMA 31 at the earliest: place_pool_kreads counts on the first two k-steps sitting in gaps npv .. npv + 31
+        # (the max-first bodies run both q blocks' exp / pack streams over one window, cfg e, that ends ahead of the last 24 gaps: their links sit there)
+        at = [int(x) for k in ("lk0", "lk1", "lk2", "lk3") for x in self.cfg[k]] if fast else [self.ng - 24 + 3 * j for j in range(8)]
+        assert at == sorted(set(at)) and self.npv + (32 if self.pool else 0) <= at[0] and at[-1] < self.ng, at
+        out, qi, li = [], 0, 0
+        for gap in range(self.npv, self.ng):
+            if li < 8 and gap == at[li]:
+                out.append(links[li])
+                li += 1
+            else:
+                out.append(qk[qi])
+                qi += 1
+        assert qi == nq and li == 8
         return out
 
     def body_end(self, par, name, fast, s1):

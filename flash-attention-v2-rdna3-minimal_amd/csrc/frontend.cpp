@@ -63,6 +63,19 @@ int64_t workspace_pool_bytes() {
     return n;
 }
 
+constexpr size_t kWsKeep = (size_t)4 << 20;      // a block up to this size stays whatever the next call needs
+
+// a call on `stream` that needs no scratch: a pooled block above kWsKeep is released (the caching allocator keeps it; the next call that splits takes
+// it back) — the operator's footprint follows the calls being made, not the largest one ever made (bench_with_sdpa.py:34 records the peak per run)
+void workspace_unused(int dev, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (size_t i = 0; i < g_ws_pool.size(); ++i)
+        if (g_ws_pool[i].dev == dev && g_ws_pool[i].stream == stream) {
+            if ((size_t)g_ws_pool[i].ws.numel() > kWsKeep) g_ws_pool.erase(g_ws_pool.begin() + i);
+            return;
+        }
+}
+
 at::Tensor workspace(size_t bytes, const at::Tensor& like, hipStream_t stream) {
     static const bool pool_on = [] { const char* e = std::getenv("FA2_WS_POOL"); return !(e && e[0] == '0'); }();
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -74,7 +87,12 @@ at::Tensor workspace(size_t bytes, const at::Tensor& like, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_ws_mu);
     for (size_t i = 0; i < pool.size(); ++i)
         if (pool[i].dev == dev && pool[i].stream == stream) {
-            if ((size_t)pool[i].ws.numel() < bytes) pool[i].ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+            // grown when a call needs more, let go when a call needs less than half of a block above kWsKeep (round 6: the pool was a high-water mark)
+            const size_t have = (size_t)pool[i].ws.numel();
+            if (have < bytes || (have > kWsKeep && have > 2 * bytes)) {
+                pool[i].ws = at::Tensor();
+                pool[i].ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+            }
             Slot s = pool[i];
             pool.erase(pool.begin() + i);
             pool.push_back(s);                      // most recently used last
@@ -150,6 +168,7 @@ std::vector<at::Tensor> forward(at::Tensor q, at::Tensor k, at::Tensor v, int64_
     at::Tensor ws;
     const size_t ws_bytes = causal ? 0 : cached_ws_bytes(0, dtype_code, q.device().index(), b, h, n, n_kv, d_kernel);
     if (ws_bytes) ws = workspace(ws_bytes, q, stream);
+    else workspace_unused(q.device().index(), stream);
     const int rc = fa2_fwd_ws(dtype_code, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), O.data_ptr(), L.data_ptr<float>(), (int)b, (int)h,
                               (int)n, (int)n_kv, (int)d_kernel, qs, ks, vs, os, ls, (float)scale, (int)(flags & 3),
                               ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);
@@ -189,6 +208,7 @@ std::vector<at::Tensor> backward(at::Tensor Q, at::Tensor K, at::Tensor V, at::T
     at::Tensor ws;
     const size_t ws_bytes = causal ? 0 : cached_ws_bytes(1, dtype_code, Q.device().index(), b, h, act_n, act_nkv, dk);
     if (ws_bytes) ws = workspace(ws_bytes, Q, stream);
+    else workspace_unused(Q.device().index(), stream);
     const int rc = fa2_bwd_ws(dtype_code, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr<float>(), dQ.data_ptr(),
                               dK.data_ptr(), dV.data_ptr(), delta.data_ptr<float>(), (int)b, (int)h, (int)act_n, (int)act_nkv, (int)dk, qs, ks, vs, os, gs,
                               dqs, dks, dvs, ls, (float)scale, causal ? 1 : 0, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, (void*)stream);

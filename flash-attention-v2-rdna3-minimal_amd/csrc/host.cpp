@@ -118,8 +118,10 @@ bool asm_pitch_ok(int64_t row_stride_elems, int HD) { return row_stride_elems % 
 // (round 5) Q is staged by LDS-DMA like K: its row pitch has to be a multiple of one tile row too, and the byte offsets of the (up to 63) rows a
 // workgroup's last wave reads past Nq — zero-filled by the descriptor — must not wrap
 // (any_pitch: launches of a head dim below the body's take the general form of the LDS-DMA offsets — csrc/gen/fwd_m16_gen.py: trim_offsets)
+// (any_pitch launches mark a granule the row does not have with byte offset 0x80000000 — "beyond every descriptor": true only while the Q span
+//  itself stays below 2 GiB, as K's and V's do)
 bool asm_q_span_ok(const fa2::FwdParams& p, bool any_pitch = false) {
-    return ((int64_t)(p.Nq + 64) * p.qs[2] + p.D) * 2 < ((int64_t)1 << 32) && (any_pitch || p.qs[2] % (p.D > 0 ? p.D : 1) == 0);
+    return ((int64_t)(p.Nq + 64) * p.qs[2] + p.D) * 2 < ((int64_t)1 << (any_pitch ? 31 : 32)) && (any_pitch || p.qs[2] % (p.D > 0 ? p.D : 1) == 0);
 }
 // ... and pays a fixed head and tail per item (the Q tile through LDS, the first K / V tiles before any MFMA, the drain of the software pipeline):
 // over a short KV sweep (cross-attention, low-resolution self-attention) the compiler-scheduled kernels — two waves per SIMD hiding each
@@ -424,6 +426,8 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
                     float scale, int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
                     void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr, fa2_fwd_plan_t* plan_out = nullptr) {
     // `causal` carries the call's flags: bit 0 = causal mask, bit 1 = FA2_FLAG_EXACT_SCALE (this call scales the f32 product whatever option "fold" says)
+    // Until round 5 any non-zero value meant "causal"; a caller that still passes another truthy int would silently get a non-causal forward: refuse it
+    if (causal & ~(FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE)) return FA2_ERR_BAD_SHAPE;
     const bool exact_scale = (causal & FA2_FLAG_EXACT_SCALE) != 0;
     causal &= 1;
     // ws_need / plan_out: validate and plan only (fa2_fwd_workspace_bytes, fa2_fwd_plan) — the data pointers are stand-ins then
@@ -517,13 +521,17 @@ static int fwd_impl(int dtype, const void* q, const void* k, const void* v, void
         // The size query has no scale argument, and the split plan depends on the scale at head dim 64 (a launch that folds the scale — c <= 1 — runs
         // the parts inside the hand-scheduled kernel: other fixed costs, possibly another S): the answer is the larger of the two plans, so a
         // workspace of this size serves the call whatever its scale (the callers' caches are keyed without the scale).
+        // Likewise FA2_FLAG_EXACT_SCALE (the forward of a call that will be differentiated never folds: another kernel, other fixed costs, possibly
+        // another S): both settings are planned, whatever the query's flag says — the callers' caches are keyed without it too.
         size_t need = 0;
-        for (const float c_try : {0.5f, 2.0f}) {
-            fa2::FwdParams pt = p;
-            pt.c = c_try;
-            const fa2::SplitPlan pl = plan_split(pt, HD, dtype == FA2_DTYPE_BF16, causal != 0);
-            if (pl.nsplit > 1) need = std::max(need, (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD));
-        }
+        for (const float c_try : {0.5f, 2.0f})
+            for (const int exact_try : {0, 1}) {
+                fa2::FwdParams pt = p;
+                pt.c = c_try;
+                pt.exact_scale = exact_try;
+                const fa2::SplitPlan pl = plan_split(pt, HD, dtype == FA2_DTYPE_BF16, causal != 0);
+                if (pl.nsplit > 1) need = std::max(need, (size_t)fa2::split_ws_bytes(pl.split_items, pl.nsplit, HD));
+            }
         *ws_need = need;
     }
     if (plan_out) {     // fa2_fwd_plan: what launch_fwd would do with a (16-byte aligned) workspace of ws_bytes bytes
@@ -608,6 +616,7 @@ static int bwd_impl(int dtype, const void* q, const void* k, const void* v, cons
             const int64_t dk_strides[3], const int64_t dv_strides[3], const int64_t lse_strides[2], float scale,
             int causal, const void* bias, int bias_kind, const int64_t bias_strides[3], void* hip_stream,
             void* ws = nullptr, size_t ws_bytes = 0, size_t* ws_need = nullptr) {
+    if (causal & ~(FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE)) return FA2_ERR_BAD_SHAPE;      // (as in fwd_impl: no value but the documented flag bits)
     causal &= 1;          // (bit 1, FA2_FLAG_EXACT_SCALE, is what the backward does anyway unless option "kfold" is set)
     if (ws_need) *ws_need = 0;
     if (bias_kind != FA2_BIAS_NONE) {

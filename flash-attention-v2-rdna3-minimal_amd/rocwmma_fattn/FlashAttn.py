@@ -33,10 +33,16 @@ class _FlashAttnWmma:
     def forward(q, k, v, Br, Bc, causal, scale, permute_NH):
         """forward() of the reference's module: the compiled front end (csrc/frontend.cpp, same logic in C++: ~6 us of host
         time per call instead of ~11) when it was built, else forward_py below."""
+        # A caller of the reference's module-level API who pairs forward() with backward() himself (host.cpp:30-58) passes a plain bool: when an input
+        # requires a gradient the forward is flagged FA2_FLAG_EXACT_SCALE for him — the backward recomputes P from scores scaled in f32, and an L formed
+        # from a folded / rounded-P forward would not match them (2-4x the gradient tolerance at |logit| > 30: ADVICE r5).  Anyone else sets the flag.
+        flags = _fa2_lib.call_flags(causal)
+        if q.requires_grad or k.requires_grad or v.requires_grad:
+            flags |= _fa2_lib.FA2_FLAG_EXACT_SCALE
         fe = _frontend()
         if fe is not None:
-            return fe.forward(q, k, v, int(Br), int(Bc), _fa2_lib.call_flags(causal), float(scale), bool(permute_NH))
-        return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, causal, scale, permute_NH)
+            return fe.forward(q, k, v, int(Br), int(Bc), flags, float(scale), bool(permute_NH))
+        return _FlashAttnWmma.forward_py(q, k, v, Br, Bc, flags, scale, permute_NH)
 
     @staticmethod
     def forward_bias(q, k, v, bias, Br, Bc, causal, scale, permute_NH):
@@ -209,6 +215,15 @@ class _FlashAttnWmma:
 
 _WS_POOL = {}            # (device index, raw stream) -> uint8 tensor: the split's scratch, allocated once per stream and reused (grown when a call needs more)
 _WS_POOL_MAX = 8         # streams with a pooled workspace (least recently used dropped beyond that)
+_WS_KEEP = 4 << 20       # a block up to this size stays whatever the next call needs
+
+
+def _workspace_unused(dev, stream):
+    """A call on `stream` that needs no scratch: a pooled block above _WS_KEEP is released (the allocator caches it; the next call that splits takes it
+    back) — the operator's footprint follows the calls being made, not the largest one ever made."""
+    ws = _WS_POOL.get((dev, stream))
+    if ws is not None and ws.numel() > _WS_KEEP:
+        del _WS_POOL[(dev, stream)]
 
 
 def _workspace(need, device, dev, stream):
@@ -221,7 +236,10 @@ def _workspace(need, device, dev, stream):
         return torch.empty(need, dtype=torch.uint8, device=device)
     key = (dev, stream)
     ws = _WS_POOL.pop(key, None)
-    if ws is None or ws.numel() < need:
+    # grown when a call needs more — and (round 6) let go when a call needs less than half of a block above _WS_KEEP: the pool was a high-water mark,
+    # every later call of the process carried the largest block any call had needed (the reference harness's D scan: +60 MB on every row)
+    if ws is None or ws.numel() < need or (ws.numel() > _WS_KEEP and ws.numel() > 2 * need):
+        ws = None                # (drop the old block first: the allocator can hand the same memory back)
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         while len(_WS_POOL) >= _WS_POOL_MAX:
             _WS_POOL.pop(next(iter(_WS_POOL)))
@@ -258,7 +276,10 @@ def _launch_fwd(lib, fn, args, dev, device, may_split):
             stream = _raw_stream(dev)
             ws = _workspace(need, device, dev, stream)
             return lib.fa2_fwd_ws(*args, ws.data_ptr(), need, stream)
-    return fn(*args, _raw_stream(dev))
+    stream = _raw_stream(dev)
+    if _WS_POOL:
+        _workspace_unused(dev, stream)
+    return fn(*args, stream)
 
 
 _FRONTEND = [False]      # False = not looked for yet, None = absent
@@ -366,7 +387,8 @@ class FlashAttentionFunction(torch.autograd.Function):
 
         # a call that will be differentiated scales the f32 product (FA2_FLAG_EXACT_SCALE: the reference kernel's contract, kernel_fp16.cu:164) whatever
         # option "fold" says: the backward then recomputes P from the very scores L was formed from
-        needs_grad = ctx is not None and q.requires_grad
+        # (q, k OR v: the reference looks at q alone, FlashAttn.py:73, and a call in which only K / V need gradients fails in its backward)
+        needs_grad = ctx is not None and (q.requires_grad or k.requires_grad or v.requires_grad)
         flags = (_fa2_lib.FA2_FLAG_CAUSAL if causal else 0) | (_fa2_lib.FA2_FLAG_EXACT_SCALE if needs_grad else 0)
         ret = flash_attn_wmma.forward(q, k, v, Br, Bc, flags if needs_grad else bool(causal), scale, BNHD_fmt)
 
@@ -453,7 +475,5 @@ def flash_attention(q, k, v, mask=None, causal=False, scale=None, BNHD_fmt=False
         scale = D ** -0.5
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
         return _MaskedAttentionFunction.apply(q, k, v, mask, causal, scale, BNHD_fmt)
-    if scale is None:
-        scale = D ** -0.5
     Br = 32 if D > 384 else 64                      # FlashAttn.py:56-67
     return flash_attn_wmma.forward_bias(q, k, v, mask, Br, 128, bool(causal), scale, BNHD_fmt)[0]

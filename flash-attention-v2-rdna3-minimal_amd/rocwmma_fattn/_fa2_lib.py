@@ -159,7 +159,10 @@ def call_flags(causal):
     bit 1, FA2_FLAG_EXACT_SCALE, marks the forward of a call that will be differentiated."""
     if isinstance(causal, bool) or causal is None:
         return FA2_FLAG_CAUSAL if causal else 0
-    return int(causal) & 3
+    c = int(causal)
+    if c & ~(FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE):
+        raise ValueError("fa2: `causal` is a bool or the flag word FA2_FLAG_CAUSAL | FA2_FLAG_EXACT_SCALE (0 .. 3), got %r" % (causal,))
+    return c
 
 
 def fwd_plan(q, k, causal, scale=None, bias_kind=FA2_BIAS_NONE, workspace_bytes=0):

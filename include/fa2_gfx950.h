@@ -39,7 +39,11 @@
  *   causal: (i, j) masked iff j > i, top-left aligned (kernel_fp16.cu:403-410).  The `causal` argument of every entry point carries the call's
  *   flags: bit 0 (FA2_FLAG_CAUSAL, i.e. the reference's 0 / 1) and bit 1, FA2_FLAG_EXACT_SCALE: this forward call scales the f32 product like the
  *   reference kernel (kernel_fp16.cu:164) whatever option "fold" says — the operator sets it on the forward of calls that will be differentiated, so
- *   that the backward recomputes P from the very scores the saved L was formed from; the backward entry points accept and ignore it
+ *   that the backward recomputes P from the very scores the saved L was formed from; the backward entry points accept and ignore it.  Any other
+ *   bit set is FA2_ERR_BAD_SHAPE (until round 5 every non-zero value meant "causal": a caller that passes another truthy int is told so instead of
+ *   silently getting a non-causal forward).  A caller that pairs fa2_fwd* with fa2_bwd* itself — the reference's module-level
+ *   flash_attn_wmma.forward / .backward (host.cpp:30-58) — sets FA2_FLAG_EXACT_SCALE on the forward; the Python front end does it for such callers
+ *   whenever an input requires a gradient
  *   online softmax in f32 (running max m, running sum l), P rounded to the I/O dtype (RNE) for P·V,
  *   O accumulated in f32 registers, O = O / l rounded once to the I/O dtype,
  *   lse[i] = m + log2(l)  — the LOG2-domain log-sum-exp of the scaled scores, i.e.
@@ -278,7 +282,8 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
  *                                 with a constant operand per (16 rows, 32 kv) instead of 64 v_add_f32 per tile, -4 % of a launch.
  * Kernels.
  *   FA2_KERNEL_HIP_256 / _128     compiler-scheduled HIP kernel, 8-wave 256-row / 4-wave 128-row workgroups (csrc/fa2_fwd_kernel.hip.h)
- *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py), head dims exactly 64 and 128
+ *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py, fwd_m16_gen.py): head dims 64 and 128, and — on the
+ *                                 16x16x32 bodies, padded columns zero-filled by the LDS-DMA — 40 .. 56 and 88 .. 120 (f32-scale kinds from 104)
  *   FA2_KERNEL_HIP_BIAS           the BIAS forms of the HIP kernel (fa2_fwd_bias); `rows` is reported as 0 = unspecified for it: the load form, and with it
  *                                 128- or 256-row workgroups, depends on the bias strides and alignment, which this query does not take
  * A call is at most two launches: heads [0, heads_main) of the flattened (b * H + h) order run `kernel` under `contract`, the others (head dims
@@ -316,12 +321,15 @@ int fa2_fwd_prescales_q(int D, float scale);
  *   "rows"  FA2_ROWS   0 (default: heuristic on the grid size) | 128 | 256 — Q rows per forward (and dQ-pass) workgroup
  *   "asm"       FA2_ASM        bit 0: hand-scheduled forward bodies (head dims 64 and 128), bit 1: hand-scheduled backward
  *                              bodies (head dim 128), bits 2 / 3: ... except its dQ pass / its dK-dV pass, bit 4: the head-dim-64
- *                              forward body for non-causal launches too (default: causal only), bit 6: head dim 128 forward launches of whole items take the
- *                              bodies built on v_mfma_f32_16x16x32 (round 5: +3 .. 5 % on a power-limited chip, same contracts; KV-split launches and bit 6
- *                              clear: the 32x32x16 bodies), bits 7 / 8: the same for the dQ / the dK-dV pass of the head dim 128 backward (-7 .. 8 % of either
- *                              pass on fp16), bit 9: the 16x16x32 forward bodies keep their row sums on the matrix pipe (FA2_CONTRACT_LSUM_P16; -4 % of a
- *                              launch; no in-place repair: fp16 rows that outgrow the reference of their first tiles by 16 octaves cost their
- *                              item a second sweep — clear the bit for such data: the sum-check bodies repair in place); default 963.
+ *                              forward body for non-causal launches too (default: causal only), bit 6: the forward launches the hand-scheduled kernel
+ *                              takes — whole items and KV-split parts alike — run the bodies built on v_mfma_f32_16x16x32 (round 5: +3 .. 5 % on a
+ *                              power-limited chip, same contracts; bit 6 clear: the 32x32x16 bodies), bits 7 / 8: the same for the dQ / the dK-dV pass
+ *                              of the head dim 128 backward (-7 .. 8 % of either pass on fp16), bit 9: the 16x16x32 forward bodies keep their row sums
+ *                              on the matrix pipe (FA2_CONTRACT_LSUM_P16; -4 % of a launch).  Their fast loop never moves the reference; since
+ *                              round 6 a tile in which a P leaves the 16-bit range (fp16: a score 16 octaves above its row's reference) is formed again
+ *                              in place and the wave finishes its sweep on the max-first bodies — <= 1.09x the sum-check bodies (bit 9 clear) on
+ *                              N(0, amp^2) logits for every amp, 0.97x on benign data (profiles/r20_growth_cliff.txt; round 5 redid the item: 1.3 ..
+ *                              1.7x).  Default 963.
  *                              0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels
  *   "split"     FA2_SPLIT      1 (default) | 0 — fa2_fwd_ws / fa2_bwd_ws may split the last round of workgroups (0: they are fa2_fwd / fa2_bwd)

@@ -150,6 +150,43 @@ def test_autograd_through_the_operator_matches_torch():
             assert np.abs(got.float().cpu().numpy() - want).max() <= GRAD_TOL[dt] * max(1.0, np.abs(want).max())
 
 
+def test_calls_in_which_only_k_and_v_need_gradients():
+    """The reference decides on q.requires_grad alone whether to save anything for the backward (FlashAttn.py:73-75): a call in which only K / V need
+    gradients — a frozen query projection, a KV-cache being tuned — builds an autograd node whose backward finds no ctx.args.  Here any of q, k, v
+    counts; both front ends, and the module-level forward() flags such a call FA2_FLAG_EXACT_SCALE on its own."""
+    from rocwmma_fattn import FlashAttn
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for python_front_end in (False, True):
+        saved = FlashAttn._FRONTEND[0]
+        if python_front_end:
+            FlashAttn._FRONTEND[0] = None
+        try:
+            for dtype, causal, D in ((torch.float16, False, 64), (torch.bfloat16, True, 128)):
+                q = torch.randn((2, 3, 200, D), generator=g).to(dtype).to(_dev())
+                k = torch.randn((2, 3, 264, D), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+                v = torch.randn((2, 3, 264, D), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+                do = torch.randn((2, 3, 200, D), generator=g).to(dtype).to(_dev())
+                o = FlashAttentionFunction.apply(q, k, v, None, causal)
+                assert o.requires_grad
+                o.backward(do)
+                torch.cuda.synchronize()
+                assert q.grad is None and k.grad.shape == k.shape and v.grad.shape == v.shape
+                truth = grads_truth(*(t.detach().float().cpu().numpy() for t in (q, k, v, do)), causal)
+                dt = 0 if dtype == torch.float16 else 1
+                for got, want in zip((k.grad, v.grad), truth[1:]):
+                    assert np.abs(got.float().cpu().numpy() - want).max() <= GRAD_TOL[dt] * max(1.0, np.abs(want).max())
+        finally:
+            FlashAttn._FRONTEND[0] = saved
+    # the reference's module-level API (host.cpp:30-58), forward() with a plain bool: the plan of what it launches is the exact-scale one
+    q = torch.randn((2, 16, 4096, 128), generator=g).half().to(_dev())
+    k, v = (torch.randn((2, 16, 4096, 128), generator=g).half().to(_dev()).requires_grad_(True) for _ in range(2))
+    o1 = flash_attn_wmma.forward(q, k, v, 64, 128, False, 128 ** -0.5, False)[0]
+    o2 = flash_attn_wmma.forward(q, k.detach(), v.detach(), 64, 128, _fa2_lib.FA2_FLAG_EXACT_SCALE, 128 ** -0.5, False)[0]
+    o3 = flash_attn_wmma.forward(q, k.detach(), v.detach(), 64, 128, False, 128 ** -0.5, False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)          # (the default fp16 launch folds the scale: other bits)
+
+
 def test_backward_is_deterministic_and_bnhd_matches_bhnd():
     g = torch.Generator(device="cpu").manual_seed(23)
     q, k, v, do = (torch.randn((2, 4, 300, 64), generator=g).half().to(_dev()) for _ in range(4))

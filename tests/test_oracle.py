@@ -3,7 +3,7 @@ pure_torch_ver.py (tests/golden/make_golden.py) and against dense float64 attent
 import numpy as np
 import pytest
 
-from conftest import ATOL, FLOOR, GRAD_TOL, LSE_TOL, LSE_TRUTH_TOL, RTOL, grads_truth, load_golden
+from conftest import ATOL, FLOOR, GRAD_TOL, LSE_TOL, LSE_TOL_P16_BF16, LSE_TRUTH_TOL, RTOL, grads_truth, load_golden
 from oracle import fa2_oracle as fo
 
 
@@ -84,6 +84,31 @@ def test_c_oracle_prescaled_q_contract_against_golden(golden):
         o0, lse0 = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal)
         assert np.abs(_f32(o_bits, dt) - _f32(o0, dt)).max() <= ATOL[dt] + RTOL[dt]      # the two contracts agree within tolerance
         assert np.abs(lse - lse0).max() <= LSE_TRUTH_TOL[dt]
+
+
+@pytest.mark.parametrize("flags", [fo.LSUM_P16, fo.PRESCALE_Q | fo.LSUM_P16], ids=["lsum_p16", "prescale_q+lsum_p16"])
+def test_c_oracle_lsum_p16_contract_against_golden(golden, flags):
+    """LSUM_P16 — the row sums add the P that was rounded to the I/O dtype for the P.V product, so the weights O applies sum to exactly one — is the
+    contract fa2_fwd_plan reports for the default launches of BASELINE configs 2, 3 and 4 since round 5 (fp16: PRESCALE_Q | LSUM_P16, bf16: LSUM_P16;
+    csrc/gen/fwd_m16_gen.py opt=lm), and the GPU tests compare those launches with the oracle under it.  Pinned like the other modes
+    (pure_torch_ver.py:54-85 sums the f32 P of its 16-bit scores; the reference kernel's 16-bit S carries the same class of rounding): the O bar against
+    truth, never worse than 2x the reference's own oracle; the LSE within the rounding of P — 2^-11 (fp16) / 2^-8 (bf16) relative per term — of the dense
+    log2 LSE and closer to it than the reference's 16-bit L; and within tolerance of the plain contract."""
+    dt = golden["dtype"]
+    lse_bar = LSE_TRUTH_TOL[dt] if flags & fo.PRESCALE_Q else (1e-3 if dt == 0 else LSE_TOL_P16_BF16)
+    for causal, var in golden["variants"].items():
+        o_bits, lse = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal, flags=flags)
+        err = np.abs(_f32(o_bits, dt) - var["o_true"]).max()
+        ref_err = np.abs(_f32(var["o_ref"], dt) - var["o_true"]).max()
+        assert err <= max(2 * ref_err, FLOOR[dt]), (golden["name"], causal, err, ref_err)
+        lse_err = np.abs(lse - var["lse2_true"]).max()
+        assert lse_err <= max(lse_bar, LSE_TOL_P16_BF16 if dt else 0.0), (golden["name"], causal, lse_err)
+        n = golden["N"]
+        ref_lse_err = np.abs(var["l_ref"][:, :, :n] * fo.LOG2E - var["lse2_true"]).max()
+        assert lse_err <= ref_lse_err, "the rounded-P LSE should be at least as close to truth as the reference's 16-bit L"
+        o0, lse0 = fo.fwd_c(golden["q"], golden["k"], golden["v"], dt, causal, flags=flags & fo.PRESCALE_Q)
+        assert np.abs(_f32(o_bits, dt) - _f32(o0, dt)).max() <= ATOL[dt] + RTOL[dt]      # the contracts agree within tolerance
+        assert np.abs(lse - lse0).max() <= (1e-3 if dt == 0 else LSE_TOL_P16_BF16)
 
 
 def test_c_oracle_reference_rounding_mode_tracks_reference(golden):

@@ -395,6 +395,45 @@ def test_split_scratch_is_one_block_per_stream_not_one_per_call():
 
 
 @pytest.mark.gpu
+def test_split_scratch_follows_the_calls_being_made():
+    """the per-stream block was a high-water mark — after one call that needed tens of MB every later call of the process carried
+    them (the reference harness's D scan: +60 MB on every row, 4.3x torch SDPA's footprint at D = 16; bench_with_sdpa.py:34 records the peak per run).
+    Now a call that needs less than half of a block above 4 MiB gets a right-sized one, and a call that needs none releases it; both front ends."""
+    from rocwmma_fattn import FlashAttn
+    lib = _fa2_lib.load(build_if_missing=False)
+    dev = _dev()
+    big = (1, 24, 5632, 64)                             # bench_with_sdpa.py's N scan: a large split
+    small = (1, 24, 512, 64)
+    need_big = lib.fa2_fwd_workspace_bytes(0, *big[:3], big[2], big[3], 0)
+    need_small = lib.fa2_fwd_workspace_bytes(0, *small[:3], small[2], small[3], 0)
+    assert need_big > (8 << 20) and need_small < need_big // 2, (need_big, need_small)
+    qb, kb, vb = (torch.rand(big, device=dev).half() for _ in range(3))
+    qs, ks, vs = (torch.rand(small, device=dev).half() for _ in range(3))
+    # (the pools also hold the blocks earlier tests left on other streams: differences of the total, not the total)
+    for python_front_end in (False, True):
+        saved = FlashAttn._FRONTEND[0]
+        if python_front_end:
+            FlashAttn._FRONTEND[0] = None
+        try:
+            FlashAttentionFunction.apply(qb, kb, vb, None, False)
+            torch.cuda.synchronize()
+            p1 = FlashAttn.workspace_pool_bytes()
+            o_ref = FlashAttentionFunction.apply(qs, ks, vs, None, False)                  # needs less than half (here: none): the block goes
+            torch.cuda.synchronize()
+            p2 = FlashAttn.workspace_pool_bytes()
+            assert p1 - p2 >= need_big - need_small - (4 << 20) and p1 - p2 > 0, (p1, p2, need_big, need_small)
+            FlashAttentionFunction.apply(qb, kb, vb, None, False)                           # ... a large call takes it back
+            torch.cuda.synchronize()
+            assert FlashAttn.workspace_pool_bytes() - p2 >= need_big - need_small - (4 << 20)
+            FlashAttentionFunction.apply(qs, ks, vs, None, True)                            # a causal call: no split, no scratch
+            torch.cuda.synchronize()
+            assert FlashAttn.workspace_pool_bytes() <= p2 + (4 << 20)
+            assert torch.equal(o_ref, FlashAttentionFunction.apply(qs, ks, vs, None, False))      # results do not depend on which block served a call
+        finally:
+            FlashAttn._FRONTEND[0] = saved
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,dt", [(64, 0), (128, 1)])
 def test_split_parts_with_one_workgroup_per_item(D, dt):
     """Option persist = 0 launches one workgroup per list entry of the hand-scheduled kernels — whole items and KV-split parts alike — instead of

@@ -124,7 +124,8 @@ inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, in
     if (HD == 64) return (lm && !p.exact_scale) ? kM16F32Lm : kM16None;
     if (HD != 128) return kM16None;
     if (p.exact_scale) return !bf16 ? kM16F32 : kM16None;
-    return lm ? kM16F32Lm : (!bf16 ? kM16F32 : kM16None);
+    // (round 6: the lm bodies keep the conflict-free V image of the folded ones — the same condition on V's row pitch, see `fold` above)
+    return (lm && (p.vs[2] % 32 == 0 || p.D < HD)) ? kM16F32Lm : (!bf16 ? kM16F32 : kM16None);
 }
 inline bool fwd_asm_is_m16(int HD, bool bf16, const FwdParams& p, bool fold, int m16) { return fwd_asm_m16_kind(HD, bf16, p, fold, m16) != kM16None; }
 inline bool fwd_asm_lsum16(int HD, bool bf16, const FwdParams& p, bool fold, int m16) {

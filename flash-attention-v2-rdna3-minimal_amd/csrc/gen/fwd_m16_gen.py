@@ -144,6 +144,11 @@ class Gen16(base.Gen):
         # shrink to the 32-register pool of the ct bodies (k-steps 2, 3 are read into the slots of 0, 1), at head dim 64 those registers are free.
         self.lm = "lm" in self.opt
         self.repairs = set()
+        # the conflict-free V image (32-byte halves flipped for rows with (row >> 2) & 1, odd d groups read through a second address set: stream_vread):
+        # the folded bodies since round 5; round 6: the f32-scale lm bodies too — bf16's default, config 3: SQ_LDS_BANK_CONFLICT 4.6e6 of 1.37e7 LDS
+        # cycles per launch with the plain image (profiles/r20_c3_summary.txt) — whose second address set takes v[248:251] (free without the sum check)
+        self.vflip = self.ct or self.lm
+        self.vro = VRO if self.ct else EPX
         self.ones16 = ONES16 if self.ct else [A(224 + 4 * qg, 4) for qg in range(4)]
         if self.lm and not self.ct:
             self.kf16 = KF_POOL
@@ -423,7 +428,7 @@ class Gen16(base.Gen):
                 p.emit("v_and_b32", dst_, vmask, dst_)
                 p.emit("s_nop", 0)
                 p.emit("v_lshlrev_b32", dst_, 2, dst_)                       # chunk swizzle: granule bits 2 ..
-                if self.ct:                                                 # ... and the folded bodies' flipped 32-byte halves: granule bit 1
+                if self.vflip:                                              # ... and the flipped 32-byte halves of the conflict-free V image: granule bit 1
                     p.emit("v_lshrrev_b32", t2, 2, t2)
                     p.emit("s_nop", 0)
                     p.emit("v_and_b32", t2, 1, t2)
@@ -853,8 +858,8 @@ class Gen16(base.Gen):
         for kvs in range(2):
             for dg in range(self.NDG):
                 off = g.V_BASE + par * g.SLOT_B + 32 * kvs * g.ROWB
-                if self.ct:
-                    adr = (VRO if dg & 1 else VR)[dg >> 1]
+                if self.vflip:
+                    adr = (self.vro if dg & 1 else VR)[dg >> 1]
                 else:
                     adr, off = VR[dg >> 1], off + 32 * (dg & 1)
                 out.append(mk("ds_read_b64_tr_b16", self.vf16(dg, kvs).sub(0, 2), adr, tag="lds", offset=off))
@@ -895,9 +900,9 @@ class Gen16(base.Gen):
             p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
         for j in range(ndg // 2):
             p.emit("v_xor_b32", VR[j], j << 6, A_VR0)
-        if self.ct:
+        if self.vflip:
             for j in range(ndg // 2):
-                p.emit("v_xor_b32", VRO[j], (j << 6) | 32, A_VR0)      # the other 32-byte half
+                p.emit("v_xor_b32", self.vro[j], (j << 6) | 32, A_VR0)      # the other 32-byte half
         if self.lm:
             # the constant A tuples of the row-sum MFMAs: 0.25 (two packed 16-bit values) on the lanes of rows m = lane % 16 with m % 4 == qg
             p.emit("v_lshrrev_b32", TMP[0], g.ROWB.bit_length() - 1, A_KR0)      # A_KR0 = n * ROWB + (swizzled granule << 4), n = lane % 16
@@ -959,7 +964,7 @@ class Gen16(base.Gen):
             p.emit("s_add_u32", S_TMP, S_TMP, A_KROW4)
             p.emit("s_add_u32", S_TMP2, S_TMP2, A_VROW4)
             p.emit("v_xor_b32", KD[i], i << 6, A_KD0)
-            if self.ct and ((g.RPP * i) & 4):       # the rows of such a piece have (row >> 2) & 1 set where piece 0's have it clear: their 32-byte halves are
+            if self.vflip and ((g.RPP * i) & 4):       # the rows of such a piece have (row >> 2) & 1 set where piece 0's have it clear: their 32-byte halves are
                                                      # flipped in the "ct" V image (head dim 128: the odd pieces; 64: a piece is eight rows, none)
                 p.emit("v_xor_b32", VD[i], 32, A_VD0)
                 p.emit("s_nop", 0)

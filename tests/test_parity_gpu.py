@@ -154,9 +154,12 @@ def test_large_logits_do_not_cost_the_default_fp16_forward_a_second_sweep(causal
     finally:
         lib.fa2_set_option(b"asm", full)
     t = {a: sorted(x)[len(x) // 2] for a, x in ts.items()}
-    for amp in (4.0, 8.0):
-        assert t[(amp, full)] <= 1.30 * t[(1.0, full)], t                     # (measured 1.08 / 1.17; round 5: 1.56 / 1.48)
-        assert t[(amp, full)] <= 1.15 * t[(amp, full & ~512)], t              # (measured 1.04 .. 1.09; round 5: 1.29 .. 1.69)
+    for amp, bound in ((4.0, 1.30), (8.0, 1.55)):
+        # against benign data (measured 1.08 .. 1.15 at amp 4, 1.17 .. 1.42 at amp 8 — logits that large cost EVERY body kind its reference moves: the
+        # sum-check bodies 1.10 .. 1.34 —; round 5: 1.56 .. 1.83 / 1.48 .. 1.70) ...
+        assert t[(amp, full)] <= bound * t[(1.0, full)], t
+        # ... and against the sum-check bodies on the same data (measured 1.04 .. 1.09; round 5: 1.29 .. 1.69)
+        assert t[(amp, full)] <= 1.15 * t[(amp, full & ~512)], t
     q, k, v = data[4.0]
     o1, lse1 = _cabi_forward(q, k, v, causal)
     o2, lse2 = _cabi_forward(q, k, v, causal)

@@ -99,7 +99,7 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, row_bytes
         # xors (dg >> 1) << 6 and adds 32 (dg & 1))
         trow = 4 * g4 + (n16 >> 2)
         v[10] = (trow * g.ROWB + (((trow // rpb) & vmask) << 6) + 8 * (n16 & 3)).astype(np.uint32)
-        if "ct" in OPT:
+        if "ct" in OPT or "lm" in OPT:
             # the folded bodies' own V image: the 32-byte half of a chunk is flipped for rows with (row >> 2) & 1 (conflict-free transposed reads)
             v[10] = v[10] + (32 * (g4 & 1)).astype(np.uint32)
             drow = (64 // 4) * w + lane // gran

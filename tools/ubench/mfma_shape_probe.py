@@ -64,6 +64,9 @@ def fillers(nofill=(), fill=None):
 # A operand (ones in the rows m % 4 == q group: one 4-register accumulator collects all four q groups); "sum4" = v_mfma_f32_4x4x4_16b_f16 with a ones
 # row as A: every lane's four packed P values land, summed, in one accumulator register (per-lane partial sums, as the v_add chain leaves them)
 def sum_mfmas(kind):
+    if kind == "sum16h":      # (32 Q rows per wave: two q groups x two k-steps)
+        return ["v_mfma_f32_16x16x32_f16 a[192:195], v[%d:%d], v[%d:%d], a[192:195]" % (184 + 4 * (j % 4), 187 + 4 * (j % 4), 48 + 4 * (j % 8), 51 + 4 * (j % 8))
+                for j in range(4)]
     if kind == "sum16":
         return ["v_mfma_f32_16x16x32_f16 a[192:195], v[%d:%d], v[%d:%d], a[192:195]" % (184 + 4 * (j % 4), 187 + 4 * (j % 4), 48 + 4 * (j % 8), 51 + 4 * (j % 8))
                 for j in range(8)]
@@ -173,6 +176,81 @@ __global__ __launch_bounds__(256, 1) void %s(const u32x4* __restrict__ ops, floa
 """ % (name, text, clob)
 
 
+def kernel_w2(name, sums=True):
+    """Round 6: the lm body with TWO waves per SIMD — 8-wave workgroups, 32 Q rows and a 256-register budget per wave.  Per wave and
+    tile: 32 P.V-like + 32 Q.K^T-like MFMAs of 16x16x32 (+ 4 row-sum MFMAs), 32 exp, 16 pack — half the 4-wave body's — but ALL of the tile's fragment
+    reads (16 ds_read_b128 + 32 ds_read_b64_tr_b16: every wave needs the whole K and V tile, so the CU reads each twice as often per FLOP).  128 bodies per
+    wave and launch: the same FLOPs per launch as the 4-wave variants.  Registers: operands v16..79, fillers v80..127, accumulators a0..127."""
+    fl = []
+    streams = [["v_exp_f32 v%d, v%d" % (80 + j % 8, 88 + j % 8) for j in range(32)],
+               ["v_cvt_pk_f16_f32 v%d, v%d, v%d" % (100 + j % 4, 80 + (2 * j) % 8, 80 + (2 * j + 1) % 8) for j in range(16)],
+               ["ds_read_b128 v[%d:%d], %%3 offset:%d" % (104 + 4 * (j % 4), 107 + 4 * (j % 4), 1024 * (j % 16)) for j in range(16)],
+               ["ds_read_b64_tr_b16 v[%d:%d], %%4 offset:%d" % (120 + 2 * (j % 4), 121 + 2 * (j % 4), 16384 + 512 * (j % 32)) for j in range(32)]]
+    pos = []
+    for st in streams:
+        for j, ins in enumerate(st):
+            pos.append(((j + 0.5) / len(st), ins))
+    pos.sort(key=lambda x: x[0])
+    fl = [ins for _, ins in pos]
+    mf = []
+    for ks in range(2):                      # P.V-like: 16 accumulators (a64..127) x 2 k-steps
+        for acc in range(16):
+            a0 = 64 + 4 * acc
+            mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
+                                                                                    48 + 4 * ((acc + 4 * ks) % 8), 51 + 4 * ((acc + 4 * ks) % 8), a0, a0 + 3))
+    if sums:                                 # 4 row-sum MFMAs (2 q groups x 2 k-steps), spread over the P.V-like phase
+        for j in range(4):
+            mf.insert(8 * j + 7 + j, "v_mfma_f32_16x16x32_f16 a[32:35], v[16:19], v[%d:%d], a[32:35]" % (48 + 4 * (j % 8), 51 + 4 * (j % 8)))
+    for ks in range(4):                      # Q.K^T-like: 8 accumulators (a0..31) x 4 k-steps, the first from C = 0
+        for acc in range(8):
+            a0 = 4 * acc
+            c = "0" if ks == 0 else "a[%d:%d]" % (a0, a0 + 3)
+            mf.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], %s" % (a0, a0 + 3, 16 + 4 * ((acc // 4 + ks) % 8), 19 + 4 * ((acc // 4 + ks) % 8),
+                                                                              48 + 4 * ((acc + ks) % 8), 51 + 4 * ((acc + ks) % 8), c))
+    n = len(mf)
+    body_ = []
+    fi = 0
+    for g in range(n):
+        body_.append(mf[g])
+        want = (g + 1) * len(fl) // n
+        while fi < want:
+            body_.append(fl[fi])
+            fi += 1
+    body_.append("s_waitcnt lgkmcnt(0)")
+    lines = ["s_mov_b32 s60, %1", "v_mov_b32 v126, %5"]
+    for i in range(16):
+        lines.append("global_load_dwordx4 v[%d:%d], v126, %%2" % (16 + 4 * i, 19 + 4 * i))
+        lines.append("v_add_u32 v126, 0x1000, v126")
+    for i in range(8):
+        lines.append("v_mov_b32 v%d, 0xbf000000" % (88 + i))
+        lines.append("v_mov_b32 v%d, 0" % (80 + i))
+    for i in range(128):
+        lines.append("v_accvgpr_write_b32 a%d, 0" % i)
+    lines.append("s_waitcnt vmcnt(0)")
+    lines.append(".Lprobe_%s_%%=:" % name)
+    lines += body_
+    lines += ["s_sub_u32 s60, s60, 1", "s_cmp_gt_i32 s60, 0", "s_cbranch_scc1 .Lprobe_%s_%%=" % name]
+    lines.append("s_nop 7")
+    lines.append("v_accvgpr_read_b32 %0, a64")
+    text = "\n".join('        "%s\\n"' % l for l in lines)
+    clob = ", ".join('"v%d"' % i for i in range(16, 128)) + ", " + ", ".join('"a%d"' % i for i in range(128)) + ', "s60", "vcc", "scc", "memory"'
+    return """
+__global__ __launch_bounds__(512, 1) void %s(const u32x4* __restrict__ ops, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 32768 / 16; i += 512) ((u32x4*)smem)[i] = ops[i & 1023];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t kaddr = lane * 16, vaddr = (lane & 15) * 8 + (lane >> 4) * 128, goff = (threadIdx.x & 255) * 16;
+    float r;
+    asm volatile(
+%s
+        : "=v"(r) : "s"(iters), "s"(ops), "v"(kaddr), "v"(vaddr), "v"(goff)
+        : %s);
+    if (r == 12345.678f) out[blockIdx.x * 256 + (threadIdx.x & 255)] = r;
+}
+""" % (name, text, clob)
+
+
 HOST = r"""
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -196,7 +274,7 @@ int main() {
     CHECK(hipMalloc(&d_out, (size_t)n_cu * 256 * 4));
     CHECK(hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     const int iters = 128;      // tile bodies per workgroup and launch (config 2: 2 items x 64 tiles)
-    struct K { const char* name; kern_t fn; } ks[] = {NAMES};
+    struct K { const char* name; kern_t fn; int threads; } ks[] = {NAMES};
     const int nk = sizeof(ks) / sizeof(ks[0]);
     for (int i = 0; i < nk; ++i) CHECK(hipFuncSetAttribute((const void*)ks[i].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     hipEvent_t e0, e1;
@@ -204,15 +282,15 @@ int main() {
     float ms = 0.f;
     CHECK(hipEventRecord(e0));
     do {       // settle the clock
-        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(ks[0].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(ks[0].fn, dim3(n_cu), dim3(ks[0].threads), 65536, 0, d_ops, d_out, iters);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
     } while (ms < 400.f);
     std::vector<std::vector<double>> t(nk);
     for (int round = 0; round < 9; ++round)
         for (int i = 0; i < nk; ++i) {
-            for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+            for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(ks[i].threads), 65536, 0, d_ops, d_out, iters);
             CHECK(hipEventRecord(e0));
-            for (int w = 0; w < 100; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(256), 65536, 0, d_ops, d_out, iters);
+            for (int w = 0; w < 100; ++w) hipLaunchKernelGGL(ks[i].fn, dim3(n_cu), dim3(ks[i].threads), 65536, 0, d_ops, d_out, iters);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
             CHECK(hipGetLastError());
             t[i].push_back(ms / 100.0 * 1e3);
@@ -251,9 +329,20 @@ def main():
     variants += [("lm_cvt", 16, (), LM, None, "sum16", 128), ("lm_cvtrtz", 16, (), dict(LM, cvt=0, cvtrtz=32), None, "sum16", 128),
                  ("lm_perm", 16, (), dict(LM, cvt=0, perm=32), None, "sum16", 128), ("lm_cvtbf", 16, (), dict(LM, cvt=0, cvtbf=32), None, "sum16", 128),
                  ("lm_nocvt", 16, (), dict(LM, cvt=0), None, "sum16", 128)]
+    # round 6: the lm body without its 8 row-sum MFMAs (what dropping them could return at most), and the same work as two waves per SIMD (kernel_w2)
+    variants += [("lm_nosum", 16, (), LM, None, None, 128)]
+    # head dim 256 on the same structure: one wave per SIMD can keep O for 32 Q rows only (128 accumulator registers + 64 of Q
+    # fragments), so a wave-tile is 32 rows x 64 keys: the same FLOPs as the head-dim-128 body's 64 x 64, half the exp / pack work, but TWICE the
+    # fragment reads — a K or V^T fragment feeds two MFMAs instead of four (32 ds_read_b128 + 64 ds_read_b64_tr_b16 per wave-tile)
+    D256 = {"exp": 32, "cvt": 16, "kread": 32, "vread": 64}
+    variants += [("d256_rows32", 16, (), D256, None, "sum16h", 128), ("d256_rows32_nolds", 16, ("kread", "vread"), D256, None, "sum16h", 128)]
+    w2 = [("w2_lm", True), ("w2_nosum", False)]
     if len(sys.argv) > 2:
         variants = [v for v in variants if v[0] in sys.argv[2].split(",")]
-    src = HOST.replace("KERNELS", "\n".join(kernel(n, s, nf, fl, pv, ex, hd) for n, s, nf, fl, pv, ex, hd in variants)).replace("NAMES", ", ".join('{"%s", %s}' % (v[0], v[0]) for v in variants))
+        w2 = [v for v in w2 if v[0] in sys.argv[2].split(",")]
+    kernels = [kernel(n, s, nf, fl, pv, ex, hd) for n, s, nf, fl, pv, ex, hd in variants] + [kernel_w2(n, sm) for n, sm in w2]
+    names = ['{"%s", %s, 256}' % (v[0], v[0]) for v in variants] + ['{"%s", %s, 512}' % (n, n) for n, _ in w2]
+    src = HOST.replace("KERNELS", "\n".join(kernels)).replace("NAMES", ", ".join(names))
     path = os.path.join(HERE, "mfma_shape_probe.hip")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/ubench/mfma_shape_probe.py — do not edit.\n" + src)

@@ -109,9 +109,17 @@ def one_case(i, rng, gen, want_bwd, force=None):
     q = make((B, H, Nq, D), dtype, lq, rng, gen, dist)
     k = make((B, H, Nkv, D), dtype, lk, rng, gen, dist)
     v = make((B, H, Nkv, D), dtype, lv, rng, gen, dist)
-    desc = dict(i=i, B=B, H=H, Nq=Nq, Nkv=Nkv, D=D, dtype=str(dtype)[6:], causal=causal, scale=round(scale, 5), dist=dist,
+    # round 6: a third of the N(0,1) cases get logits of N(0, amp^2), amp 3 .. 8 — rows that outgrow the reference of their first tile by 16 octaves and
+    # more: the in-place repair of the lm forward bodies (csrc/gen/fwd_m16_gen.py: lm_repair), the reference moves of the max-first bodies behind it
+    amp = 1.0
+    if dist == "randn" and scale > 0 and rng.random() < 0.34:
+        amp = rng.choice([3.0, 4.0, 6.0, 8.0])
+        q = (q.float() * amp ** 0.5).to(dtype)
+        k = (k.float() * amp ** 0.5).to(dtype)
+    desc = dict(i=i, B=B, H=H, Nq=Nq, Nkv=Nkv, D=D, dtype=str(dtype)[6:], causal=causal, scale=round(scale, 5), dist=dist, amp=amp,
                 layouts=[lq, lk, lv], bwd=want_bwd)
     o_true, lse_true = dense64(q, k, v, causal, scale)
+    o_exact = o_true         # (a differentiated call never folds the scale: FA2_FLAG_EXACT_SCALE — its O is held to this one, whatever the plan below says)
     # Launches of the hand-scheduled bodies that fold scale * log2(e) into Q, rounded once to the I/O dtype (FA2_CONTRACT_PRESCALE_Q; the reference
     # oracle's contract, pure_torch_ver.py:61), are held to the truth that applies that rounding and nothing else — per head range, as fa2_fwd_plan
     # names the contract of the launch that served it (the plan is the one the library executes: include/fa2_gfx950.h).
@@ -152,6 +160,7 @@ def one_case(i, rng, gen, want_bwd, force=None):
             if err > 2 * lim:
                 fails.append("%s err %.3e > %.3e" % (name, err, 2 * lim))
         o = o.detach()
+        o_true = o_exact
         lse = flash_attn_wmma.forward(q, k, v, 64, 128, causal, scale, False)[5][:, :, :Nq]     # LSE is checked in backward cases too
     else:
         o = FlashAttentionFunction.apply(q, k, v, None, causal, scale)
@@ -178,7 +187,7 @@ def one_case(i, rng, gen, want_bwd, force=None):
             # launches did before): when one key dominates a row (large logits) the sum carries that single term's bf16 rounding, log2(1 + 2^-9) =
             # 2.8e-3, on top of the f32 bound (tests hold it to LSE_TOL_P16_BF16 against the oracle under the same contract; against float64 truth,
             # with logits scaled 3x: 4.4e-3 seen)
-            lim = max(lim, 2.8e-3 + lim, 5e-3)
+            lim = max(lim, 2.8e-3 + lim, 6e-3)          # (a dominant key whose P sits just above a power of two: log2(1 + 2^-8) = 5.6e-3; tests/conftest.py LSE_TOL_P16_BF16)
         elif p16:
             lim = max(lim, 3.6e-4 + lim)          # fp16: log2(1 + 2^-12)
         lerr = (lse.double() - lse_true).abs().max().item()

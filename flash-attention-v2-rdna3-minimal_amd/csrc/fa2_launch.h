@@ -18,7 +18,7 @@ namespace fa2 {
 // read once when the library is loaded).  They select between kernels that all satisfy the same contract.
 struct Options {
     std::atomic<int> rows{0};      // FA2_ROWS: 0 = heuristic, 128 | 256 = rows per forward workgroup
-    std::atomic<int> asm_mask{963};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 / 8 = the head-dim-128 forward / dQ-pass / dK-dV-pass
+    std::atomic<int> asm_mask{1987};     // FA2_ASM: bit 0 = hand-scheduled forward bodies, bit 1 = hand-scheduled backward bodies, bits 6 / 7 / 8 = the head-dim-128 forward / dQ-pass / dK-dV-pass
                                        // bodies built on v_mfma_f32_16x16x32 (round 5; off: the 32x32x16 bodies everywhere)
     std::atomic<int> persist{1};       // FA2_PERSIST: persistent workgroups of the hand-scheduled forward kernels
     std::atomic<int> bwd_parts{3};     // profiling only: bit 0 = run the dQ pass, bit 1 = run the dK / dV pass of fa2_bwd
@@ -110,6 +110,9 @@ inline int fwd_m16_mode(int asm_mask) { return (asm_mask & 64) ? ((asm_mask & 51
 // Does launch_fwd_asm(..., m16) run a body built on v_mfma_f32_16x16x32 (csrc/gen/fwd_m16_gen.py)?  ONE predicate: the launcher executes it, the plan
 // reports its contract (the folded 16 x 16 bodies add the ROUNDED P into the row sums: FA2_CONTRACT_LSUM_P16).  fwd_asm.cpp has the measurements.
 enum { kM16None = 0, kM16F32 = 1, kM16Fold = 2, kM16F32Lm = 3, kM16FoldNoLm = 4 };
+// hand-scheduled forward for head dim exactly 256 (round 6; fa2_fwd_d256.hip.h, csrc/gen/fwd_m16_d256_gen.py): 128-row workgroups, f32 scale,
+// row sums of the rounded P (FA2_CONTRACT_LSUM_P16); host.cpp: plan_range decides which calls it takes
+FA2_HIDDEN int launch_fwd_asm_d256(bool bf16, const FwdParams& p, bool causal, hipStream_t stream);
 inline int fwd_asm_m16_kind(int HD, bool bf16, const FwdParams& p, bool fold, int m16) {
     if (!m16) return kM16None;
     const bool lm = m16 == 2;

@@ -3,6 +3,7 @@
 #include "fa2_launch.h"
 
 #include "fa2_fwd_d128.hip.h"
+#include "fa2_fwd_d256.hip.h"
 #include "fa2_gfx950.h"
 
 namespace {
@@ -41,9 +42,27 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// head dim 256 (round 6): 128-row workgroups, one item each (fa2_fwd_d256.hip.h)
+template <bool BF16, bool CAUSAL>
+int launch_d256_t(const fa2::FwdParams& p0, hipStream_t stream) {
+    constexpr auto kern = fa2::fwd_asm_d256_kernel<BF16, CAUSAL>;
+    if (int rc = fa2::set_lds<kern>(fa2::kD256LdsBytes)) return rc;
+    fa2::FwdParams p = p0;
+    p.nqblk = (p.Nq + fa2::kD256Rows - 1) / fa2::kD256Rows;
+    const int64_t grid = (int64_t)p.nbh * p.nqblk;
+    if (grid > 0x7fffffffLL) return FA2_ERR_GRID;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), fa2::kD256LdsBytes, stream, p);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 namespace fa2 {
+
+int launch_fwd_asm_d256(bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
+    if (bf16) return causal ? launch_d256_t<true, true>(p, stream) : launch_d256_t<true, false>(p, stream);
+    return causal ? launch_d256_t<false, true>(p, stream) : launch_d256_t<false, false>(p, stream);
+}
 
 template <int HD, bool BF16>
 static int launch_asm_hd(const FwdParams& p, bool causal, bool fold, hipStream_t stream) {

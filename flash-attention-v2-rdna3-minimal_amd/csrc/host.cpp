@@ -165,7 +165,22 @@ bool asm_trimmed(int HD, bool bf16, const fa2::FwdParams& p, bool fold) {
     return p.D < HD && p.D >= (HD == 64 ? FA2_TRIM_MIN64 : fold ? FA2_TRIM_MIN128 : 104) && fa2::fwd_asm_m16_kind(HD, bf16, p, fold, m16_mode) != fa2::kM16None;
 }
 
+// Head dim exactly 256 (round 6): the hand-scheduled 128-row kernel (fa2_fwd_d256.hip.h; option "asm" bit 10).  It scales the f32 product and adds the
+// rounded P into the row sums on the matrix pipe (FA2_CONTRACT_LSUM_P16), so calls flagged FA2_FLAG_EXACT_SCALE keep the compiler-scheduled kernels;
+// its LDS-DMA pieces are derived from piece 0 by flipping offset bits: K / V row pitches must be multiples of one 512-byte tile row; Q and O are
+// addressed with 32-bit offsets from the head base; short KV sweeps stay on the 8-wave kernels (two waves per SIMD hide each other's prologue).
+bool asm_d256_ok(bool bf16, const fa2::FwdParams& p, bool causal) {
+    (void)bf16;
+    const int mask = fa2::options().asm_mask.load(std::memory_order_relaxed);
+    if (!(mask & 1) || !(mask & 1024) || p.D != 256 || p.negate_q || p.exact_scale || p.bias_kind != 0) return false;
+    if (p.ks[2] % 256 || p.vs[2] % 256) return false;
+    if (((int64_t)(p.Nq + 32) * p.qs[2] + 256) * 2 >= ((int64_t)1 << 32) || ((int64_t)(p.Nq + 32) * p.os[2] + 256) * 2 >= ((int64_t)1 << 32)) return false;
+    if (forced_rows() == 256) return false;              // (option rows = 256 pins the 256-row kernels: tests, A/B)
+    return (mask & 32) || p.Nkv >= (causal ? 1024 : 512);
+}
+
 RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
+    if (HD == 256 && asm_d256_ok(bf16, p, causal)) return {FA2_KERNEL_ASM, FA2_CONTRACT_LSUM_P16, 128, false};
     const int rows = pick_rows(p, causal);
     // Head dim exactly 128 with a positive scale: the hand-scheduled 4-wave kernel (256-row workgroups).  Head dim 64 has its generated
     // body too (same generator, half the MFMAs per tile for the same softmax work, row sums on the matrix pipe), but a lone wave per SIMD
@@ -196,6 +211,7 @@ RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
 int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStream_t stream) {
     const RangePlan r = plan_range(HD, bf16, p, causal);
     // option "asm" bit 6 (default): head dim 128 launches of whole items take the bodies built on v_mfma_f32_16x16x32 (round 5; fwd_asm.cpp)
+    if (r.kernel == FA2_KERNEL_ASM && HD == 256) return fa2::launch_fwd_asm_d256(bf16, p, causal, stream);
     if (r.kernel == FA2_KERNEL_ASM)
         return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, r.rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, r.rows, false, stream);

@@ -295,6 +295,10 @@ class Machine:
         w.n_issued += 1
         ops = ins.ops
         R = lambda i: self.resolve(w, ops[i])   # noqa: E731
+        if op.startswith("buffer_") and not 0 <= ins.mods.get("offset", 0) <= 0xfff:
+            raise EmuError("MUBUF offset does not fit 12 bits (the assembler truncates it silently): %s" % ins.text())
+        if op.startswith("ds_") and not 0 <= ins.mods.get("offset", 0) <= 0xffff:
+            raise EmuError("DS offset does not fit 16 bits: %s" % ins.text())
         if op.startswith("v_mfma_f32_16x16x32"):
             # A[m][k]: lane l holds m = l % 16, k = 8 (l / 16) .. + 7;  B[k][n]: n = l % 16, the same k;  D[m][n]: n = l % 16, m = 4 (l / 16) + i (4 registers)
             start = max(w.cycle, w.mfma_free)
@@ -738,6 +742,22 @@ class Machine:
                 for i in range(4):
                     rf[dst.idx + i] = data[:, i]
             w.vm.append(land)
+        elif op == "buffer_store_dwordx2":
+            # vdata[2], voffset, descriptor, soffset: 8 bytes per lane; a lane whose range leaves the descriptor stores nothing
+            assert ins.mods.get("offen")
+            src = R(0)
+            self.check_read(w, src.kind, src.idx, 2, "vmem")
+            voff = self.rd32(w, ops[1]).astype(np.int64)
+            rs = R(2)
+            base = int(rs[0]) | ((int(rs[1]) & 0xffff) << 32)
+            nrec = int(rs[2])
+            off = voff + self.rds(w, ops[3]) + ins.mods.get("offset", 0)
+            rf = self.regfile(w, src.kind)
+            for l in range(NLANE):
+                o = int(off[l]) & 0xffffffff
+                if o + 8 <= nrec:
+                    arr, at = self._gfind(base + o, 8)
+                    arr[at:at + 8] = np.array([rf[src.idx][l], rf[src.idx + 1][l]], dtype=np.uint32).view(np.uint8)
         elif op == "buffer_load_dwordx4":
             assert ins.mods.get("lds") and ins.mods.get("offen")
             if self.check and w.issue_idx - w.last_m0_write < 2:

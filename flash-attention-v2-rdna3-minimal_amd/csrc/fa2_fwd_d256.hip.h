@@ -7,7 +7,7 @@
 // the rounded P on the matrix pipe (FA2_CONTRACT_LSUM_P16).  The launcher (fwd_asm.cpp) hands over calls with D == 256, a positive scale, K / V row
 // pitches that are multiples of 512 bytes (the LDS-DMA pieces of a wave are derived from piece 0 by flipping offset bits) and Q / O spans below 4 GiB.
 #pragma once
-#include "fa2_fwd_kernel.hip.h"
+#include "fa2_fwd_d128.hip.h"
 
 namespace fa2 {
 
@@ -15,17 +15,13 @@ constexpr int kD256Rows = 128;                                   // Q rows per w
 constexpr int kD256TileB = 64 * 512;                             // one K or V tile image
 constexpr int kD256LdsBytes = 4 * kD256TileB + 16;
 
-#define FA2_D256_STR2(x) #x
-#define FA2_D256_STR(x) FA2_D256_STR2(x)
-#ifdef FA2_GEN_DIR
-#define FA2_D256_INC(name) FA2_D256_STR(FA2_GEN_DIR/name)
-#else
-#define FA2_D256_INC(name) FA2_D256_STR(name)
-#endif
+// (the generated bodies: FA2_D128_INC of fa2_fwd_d128.hip.h — tools/kbench.py points it at schedule variants)
+#define FA2_D256_INC(name) FA2_D128_INC(name)
 
 typedef uint32_t d256_u32x4s __attribute__((ext_vector_type(4)));
 
-template <bool BF16, bool CAUSAL>
+// TRIM: head dims 136 .. 248 on the same body (generator opt=trim): rows of p.D columns at any pitch, padded columns zero-filled by the loads themselves
+template <bool BF16, bool CAUSAL, bool TRIM>
 __global__ __launch_bounds__(256, 1) void fwd_asm_d256_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,23 +64,36 @@ __global__ __launch_bounds__(256, 1) void fwd_asm_d256_kernel(const FwdParams p)
     const uint64_t ka = (uint64_t)((const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1]);
     const uint64_t va = (uint64_t)((const uint16_t*)p.v + b * p.vs[0] + h * p.vs[1]);
     const uint64_t oa = (uint64_t)((uint16_t*)p.o + b * p.os[0] + h * p.os[1]);
-    const d256_u32x4s qrs = {(uint32_t)qa, (uint32_t)(qa >> 32) & 0xffffu, (uint32_t)(p.Nq - 1) * q_rowb + 512u, 0x00020000u};
+    const d256_u32x4s qrs = {(uint32_t)qa, (uint32_t)(qa >> 32) & 0xffffu, (uint32_t)(p.Nq - 1) * q_rowb + 2u * (uint32_t)p.D, 0x00020000u};
     const d256_u32x4s krs = {(uint32_t)ka, (uint32_t)(ka >> 32) & 0xffffu, p.k_bytes, 0x00020000u};
     const d256_u32x4s vrs = {(uint32_t)va, (uint32_t)(va >> 32) & 0xffffu, p.v_bytes, 0x00020000u};
-    const d256_u32x4s ors = {(uint32_t)oa, (uint32_t)(oa >> 32) & 0xffffu, (uint32_t)(p.Nq - 1) * o_rowb + 512u, 0x00020000u};
+    const d256_u32x4s ors = {(uint32_t)oa, (uint32_t)(oa >> 32) & 0xffffu, (uint32_t)(p.Nq - 1) * o_rowb + 2u * (uint32_t)p.D, 0x00020000u};
     const uint32_t qw = __builtin_amdgcn_readfirstlane((uint32_t)qw0 * q_rowb), ow = __builtin_amdgcn_readfirstlane((uint32_t)qw0 * o_rowb);
     const uint32_t k_tile = kKvTile * k_rowb, v_tile = kKvTile * v_rowb, k_row2 = 2u * k_rowb - 1024u, v_row2 = 2u * v_rowb - 1024u;
     const uint32_t ldsw = wave * (kD256TileB / 4);
     const uint32_t q_t16 = 16u * q_rowb, o_t16 = 16u * o_rowb;
     const float c = p.c;
+    const uint32_t ng = (uint32_t)p.D >> 3;
     float lse0, lse1;
 #define FA2_D256_OPERANDS                                                                                                     \
     : "=v"(lse0), "=v"(lse1)                                                                                                  \
     : "v"(q_off), "s"(qw), "s"(qrs), "s"(krs), "s"(vrs), "v"(kd0), "v"(vd0), "v"(kr0), "v"(vr0), "v"(lim0), "v"(lim1), "s"(c),   \
       "s"(ntw), "s"(ntiles), "s"(k_tile), "s"(v_tile), "s"(k_row2), "s"(v_row2), "s"(ldsw), "v"(o_off), "s"(ow), "s"(q_t16),     \
-      "s"(o_t16), "s"(ors)                                                                                                    \
+      "s"(o_t16), "s"(ors), "s"(ng)                                                                                           \
     :
-    if constexpr (BF16) {
+    if constexpr (BF16 && TRIM) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (TRIM) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16) {
         asm volatile(
 #include FA2_D256_INC(fa2_fwd_m16_d256_bf16.inc)
             FA2_D256_OPERANDS

@@ -43,9 +43,9 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
 }
 
 // head dim 256 (round 6): 128-row workgroups, one item each (fa2_fwd_d256.hip.h)
-template <bool BF16, bool CAUSAL>
+template <bool BF16, bool CAUSAL, bool TRIM>
 int launch_d256_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_asm_d256_kernel<BF16, CAUSAL>;
+    constexpr auto kern = fa2::fwd_asm_d256_kernel<BF16, CAUSAL, TRIM>;
     if (int rc = fa2::set_lds<kern>(fa2::kD256LdsBytes)) return rc;
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + fa2::kD256Rows - 1) / fa2::kD256Rows;
@@ -60,8 +60,12 @@ int launch_d256_t(const fa2::FwdParams& p0, hipStream_t stream) {
 namespace fa2 {
 
 int launch_fwd_asm_d256(bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
-    if (bf16) return causal ? launch_d256_t<true, true>(p, stream) : launch_d256_t<true, false>(p, stream);
-    return causal ? launch_d256_t<false, true>(p, stream) : launch_d256_t<false, false>(p, stream);
+    if (p.D < 256) {       // head dims 136 .. 248: the general form of the offsets, any row pitch
+        if (bf16) return causal ? launch_d256_t<true, true, true>(p, stream) : launch_d256_t<true, false, true>(p, stream);
+        return causal ? launch_d256_t<false, true, true>(p, stream) : launch_d256_t<false, false, true>(p, stream);
+    }
+    if (bf16) return causal ? launch_d256_t<true, true, false>(p, stream) : launch_d256_t<true, false, false>(p, stream);
+    return causal ? launch_d256_t<false, true, false>(p, stream) : launch_d256_t<false, false, false>(p, stream);
 }
 
 template <int HD, bool BF16>

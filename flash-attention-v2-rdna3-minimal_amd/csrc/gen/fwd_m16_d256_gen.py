@@ -17,8 +17,12 @@ Shape: workgroup = 4 waves = 128 Q rows, one wave per SIMD, wave = 32 rows = two
 Bodies are max-first only (the reference kernel's own recurrence, kernel_fp16.cu:434-490; deferred rescale at 2^14): at half the exp / pack work per
 MFMA the row-max stream costs half what it does at head dim 128, and the kernel carries no fast loop, no repair and no redo.  f32 scale (the reference
 kernel's contract), row sums of the rounded P on the matrix pipe (FA2_CONTRACT_LSUM_P16).  One item per workgroup (no seams): an item is 2 x the
-work per tile of a head-dim-128 one.  Head dims below 256 (136 .. 248): the descriptors' row length zero-fills nothing here — the host hands such
-calls to this kernel only when D == 256 (fa2_launch.h); trimmed forms are future work.
+work per tile of a head-dim-128 one.
+opt=trim: head dims 136 .. 248 on the same body (the reference zero-pads D on the host, kernel_fp16.cu:763-779).  The rows really have D columns at
+whatever pitch the caller's tensors have, so a piece's LDS-DMA source offset takes its general form — piece 0's + ((gl_i - gl_0) << 4) + i * (two rows),
+gl_i = the logical granule the lane's slot holds under the image's swizzle — and a granule the row does not have (gl_i >= D / 8) gets an offset beyond
+every descriptor: the load returns zeros, the image's padded columns are zero and nothing of a neighbouring row enters a product (fwd_m16_gen.py:
+trim_offsets has the argument).  Q fragments and O stores are masked the same way.  The body runs at D / 256 of its rate.
 """
 import os
 import sys
@@ -41,9 +45,11 @@ A_OO0 = Arg(21)                                    # per-lane byte offset into O
 A_OW = Arg(22, "s")                                # byte offset of the wave's first O row from the head base
 A_QT16, A_OT16 = Arg(23, "s"), Arg(24, "s")        # 16 * Q / O row bytes: the second q group
 A_ORS = Arg(25, "s", 4)                            # buffer descriptor of this head's O matrix (rows >= Nq are not stored)
-N_ARGS = 26
+A_NG = Arg(26, "s")                                # opt=trim (head dims 136 .. 248): the 16-byte granules a row really has (D / 8)
+N_ARGS = 27
 
 KD0, VD0, DT0, DT1 = V(220), V(221), V(222), V(223)   # LDS-DMA source offsets of piece 0 (K, V) and two scratch registers for the other pieces
+KG0, VG0, MARK, G4R = V(224), V(225), V(226), V(227)  # opt=trim: the logical granule this lane's slot holds in piece 0 of the K / V image; 0x80000000; lane / 16
 VRO = EPX                                          # read addresses of the odd d groups (the conflict-free V image: fwd_m16_gen.Gen16.stream_vread)
 ONES = [A(240 + 4 * qg, 4) for qg in range(2)]     # the constant A tuples of the row-sum links
 
@@ -82,6 +88,7 @@ class Gen256(m16.Gen16):
         user["opt"] = opt
         super().__init__(bf16, hd=128, **user)
         assert not self.ct, "the head-dim-256 bodies scale the f32 product"
+        self.trim = "trim" in self.opt
         self.g = Geo256()
         self.NKS16, self.NDG = 8, 16
         self.kf16, self.vf16, self.oacc16, self.qf16 = KF, VF, OACC, QF
@@ -162,20 +169,37 @@ class Gen256(m16.Gen16):
         skip = self.p.fresh("dma_skip")
         out = [mk("s_add_u32", S_TMP2, S_T, ahead, tag="salu"), mk("s_cmp_lt_i32", S_TMP2, A_NTWG, tag="salu"),
                mk("s_cbranch_scc0", Label(skip), tag="branch"),
-               mk("s_add_u32", M0, A_LDSW, lbase, tag="salu"), mk("s_mov_b32", S_TMP, soff, tag="salu")]
+               mk("s_add_u32", M0, A_LDSW, lbase, tag="salu"), mk("s_mov_b32", S_TMP, 0 if self.trim else soff, tag="salu")]
         for i in range(g.NP):
             flip = (32 * i) if which == "k" else (128 * (i & 1)) | (32 * ((i >> 1) & 1))
-            if i == 0:
+            if i == 0 and not self.trim:
                 reg = d0
             else:
                 reg = (DT0, DT1)[i & 1]
-                out.append(mk("s_add_u32", S_TMP, S_TMP, row2, tag="salu"))
+                if i:
+                    out.append(mk("s_add_u32", S_TMP, S_TMP, row2, tag="salu"))
                 if i == 4:      # a MUBUF instruction offset has 12 bits: the second half of the quarter through M0 and the scalar offset
                     out.append(mk("s_add_u32", M0, A_LDSW, lbase + 4096, tag="salu"))
                     out.append(mk("s_add_u32", S_TMP, S_TMP, 4096, tag="salu"))
-                out.append(mk("v_xor_b32", reg, flip, d0, tag="valu"))
+                if self.trim:
+                    # general form: gl_i = gl_0 ^ (flip >> 4);  offset = piece 0's + ((gl_i - gl_0) << 4), or beyond every descriptor if the row has no such granule
+                    g0 = KG0 if which == "k" else VG0
+                    out.append(mk("v_xor_b32", reg, flip >> 4, g0, tag="valu"))
+                    out.append(mk("s_nop", 0, tag="salu"))
+                    out.append(mk("v_cmp_gt_u32", m16.VCC, A_NG, reg, tag="valu"))
+                    out.append(mk("v_sub_u32", reg, reg, g0, tag="valu"))
+                    out.append(mk("s_nop", 0, tag="salu"))
+                    out.append(mk("v_lshl_add_u32", reg, reg, 4, d0, tag="valu"))
+                    out.append(mk("s_nop", 0, tag="salu"))
+                    # (the pieces' stride, 2 rows - 1024, is NEGATIVE for rows below 512 bytes: it goes into the per-lane offset, where offset +
+                    #  instruction offset wrap to the right sum — a scalar offset that has wrapped puts every lane out of range on the hardware)
+                    out.append(mk("v_add_u32", reg, S_TMP, reg, tag="valu"))
+                    out.append(mk("s_nop", 0, tag="salu"))
+                    out.append(mk("v_cndmask_b32", reg, MARK, reg, m16.VCC, tag="valu"))
+                else:
+                    out.append(mk("v_xor_b32", reg, flip, d0, tag="valu"))
                 out.append(mk("s_nop", 0, tag="salu"))
-            out.append(mk("buffer_load_dwordx4", reg, rs, S_TMP, tag="dma", offen=True, offset=1024 * (i & 3), lds=True))
+            out.append(mk("buffer_load_dwordx4", reg, rs, soff if self.trim else S_TMP, tag="dma", offen=True, offset=1024 * (i & 3), lds=True))
         out.append(Ins("label", (Label(skip),)))
         return [out]              # one atomic group: M0, the running scalar offset and the scratch registers belong to it
 
@@ -268,11 +292,33 @@ class Gen256(m16.Gen16):
         p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
         # Q fragments straight from memory, issued first: lane (n, g4) takes, of row 16 qg + n, the 16 bytes at column 64 ks + 16 g4
         p.emit("s_mov_b32", S_TMP, A_QW)
+        if self.trim:
+            p.emit("v_mbcnt_lo_u32_b32", TMP[7], -1, 0)
+            p.emit("v_mov_b32", MARK, 0x80000000)
+            p.emit("v_mbcnt_hi_u32_b32", TMP[7], -1, TMP[7])
+            p.emit("s_nop", 0)
+            p.emit("v_lshrrev_b32", G4R, 4, TMP[7])                         # g4 = lane / 16
+            # this lane's slot of piece 0 holds the logical granule ... of the K image (granule ^ (row & 15); row & 15 = lane / 32 in piece 0) ...
+            p.emit("v_and_b32", TMP[0], 31, TMP[7])
+            p.emit("v_lshrrev_b32", TMP[1], 5, TMP[7])
+            p.emit("s_nop", 0)
+            p.emit("v_xor_b32", KG0, TMP[0], TMP[1])
+            # ... and of the V image: chunk ^ (row & 3) -> granule bits 2 .. 3 ^ (lane / 32); no flipped half in piece 0 (rows 16 w, 16 w + 1: (row >> 2) & 1 = 0)
+            p.emit("v_lshlrev_b32", TMP[1], 2, TMP[1])
+            p.emit("s_nop", 0)
+            p.emit("v_xor_b32", VG0, TMP[0], TMP[1])
+            for ks in range(8):                                              # Q: granule 4 ks + g4 of the row
+                p.emit("v_add_u32", TMP[2], 4 * ks, G4R)
+                p.emit("s_nop", 0)
+                p.emit("v_cmp_gt_u32", m16.VCC, A_NG, TMP[2])
+                p.emit("s_nop", 0)
+                p.emit("v_cndmask_b32", V(16 + ks), MARK, A_Q0, m16.VCC)    # (the S banks are idle until H1: eight offset registers)
+            p.emit("s_nop", 0)
         for qg in range(2):
             if qg:
                 p.emit("s_add_u32", S_TMP, S_TMP, A_QT16)
             for ks in range(8):
-                p.emit("buffer_load_dwordx4", QF(qg, ks), A_Q0, A_QRS, S_TMP, offen=True, offset=64 * ks)
+                p.emit("buffer_load_dwordx4", QF(qg, ks), V(16 + ks) if self.trim else A_Q0, A_QRS, S_TMP, offen=True, offset=64 * ks)
         for ks in range(4):
             p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
         for j in range(4):
@@ -379,6 +425,8 @@ class Gen256(m16.Gen16):
             p.emit("v_add_f32", lse[h], MC[h][0], t)
         p.emit("s_nop", 0)
         p.emit("s_mov_b32", S_TMP, A_OW)
+        if self.trim:
+            p.emit("s_lshl_b32", S_D, A_NG, 1)      # D / 4
         for qg in range(2):
             if qg:
                 p.emit("s_add_u32", S_TMP, S_TMP, A_OT16)
@@ -396,7 +444,16 @@ class Gen256(m16.Gen16):
                 p.emit(self.cvt, src[1], src[2], src[3])
                 p.emit("s_nop", 0)
                 # 8 bytes: d = 16 dg + 4 g4 .. + 3 of row 16 qg + n
-                p.emit("buffer_store_dwordx2", V(src[0].idx, 2), A_OO0, A_ORS, S_TMP, offen=True, offset=32 * dg)
+                oo = A_OO0
+                if self.trim:                       # ... if the row has them: 4 dg + g4 < D / 4
+                    oo = src[2]
+                    p.emit("v_lshl_add_u32", src[3], dg, 2, G4R)
+                    p.emit("s_nop", 0)
+                    p.emit("v_cmp_gt_u32", m16.VCC, S_D, src[3])
+                    p.emit("s_nop", 0)
+                    p.emit("v_cndmask_b32", oo, MARK, A_OO0, m16.VCC)
+                    p.emit("s_nop", 0)
+                p.emit("buffer_store_dwordx2", V(src[0].idx, 2), oo, A_ORS, S_TMP, offen=True, offset=32 * dg)
         # the LSE leaves in ONE register: lane l = 16 g4 + n (l < 32) hands over row l of the wave
         p.emit("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
         p.emit("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
@@ -426,9 +483,11 @@ def main():
     cfg = base.parse_opts(a.opt)
     if base.is_probe(cfg) and not a.probe:
         sys.exit("fwd_m16_d256_gen.py: %r contains timing-probe options; they need --probe" % a.opt)
-    for bf16 in (False, True):
-        prog = Gen256(bf16, **cfg).build()
-        path = os.path.join(a.out, "fa2_fwd_m16_d256_%s.inc" % ("bf16" if bf16 else "f16"))
+    for bf16, trim in ((b, t) for b in (False, True) for t in (False, True)):
+        c = dict(cfg)
+        c["opt"] = tuple(o for o in cfg.get("opt", ()) if o != "trim") + (("trim",) if trim else ())
+        prog = Gen256(bf16, **c).build()
+        path = os.path.join(a.out, "fa2_fwd_m16_d256_%s%s.inc" % ("bf16" if bf16 else "f16", "_trim" if trim else ""))
         base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_d256_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
         print(path, len(prog.ins), "instructions")
 

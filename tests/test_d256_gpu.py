@@ -90,3 +90,36 @@ def test_head_dim_256_large_logits():
             o, lse = _cabi_forward(qq, kk, vv, causal)
             sl = (slice(0, 1), slice(3, 4))
             _assert_close_to_oracle(o[sl], lse[sl], qq[sl], kk[sl], vv[sl], dt, causal, plan=plan, head=3)
+
+
+@pytest.mark.parametrize("D", [176, 192, 200, 224, 248])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_head_dims_below_256_on_the_hand_scheduled_kernel(D, dt):
+    """Head dims 176 .. 248 run ON the head-dim-256 body (generator opt=trim; the reference zero-pads D on the host, kernel_fp16.cu:763-779): rows of D
+    columns at whatever pitch the tensors have, the padded columns of the Q / K / V images zero-filled by the loads themselves, D columns stored.  The
+    tensors are column slices of NaN-filled allocations with a row pitch of D + 24 .. 40 elements: a granule fetched from the gap, or a column stored
+    into it, would show."""
+    B, H, N, causal = 2, 5, 1100, (D % 16 == 0)
+    g = torch.Generator(device="cpu").manual_seed(D + dt)
+    pad = 24 + 8 * (D % 3)
+    big = {n: torch.full((B, H, N + 3, D + pad), float("nan"), dtype=TORCH_DT[dt], device=_dev()) for n in "qkv"}
+    for n in "qkv":
+        big[n][:, :, :N, :D] = torch.randn((B, H, N, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    q, k, v = (big[n][:, :, :N, :D] for n in "qkv")
+    plan = _plan(q, k, causal)
+    assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM and plan.rows == 128 and plan.contract == _fa2_lib.FA2_CONTRACT_LSUM_P16, plan.as_dict()
+    obig = torch.full((B, H, N + 3, D + pad), float("nan"), dtype=TORCH_DT[dt], device=_dev())
+    o = obig[:, :, :N, :D]
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=_dev())
+    lib = _fa2_lib.load(build_if_missing=False)
+    import ctypes
+    s3 = lambda t: _fa2_lib.strides3(t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    _fa2_lib.check(lib.fa2_fwd(dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, N, D, s3(q), s3(k), s3(v), s3(o),
+                               _fa2_lib.strides2(lse.stride(0), lse.stride(1)), float(D ** -0.5), int(causal), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert torch.isnan(obig[:, :, N:].float()).all() and torch.isnan(obig[:, :, :, D:].float()).all()      # nothing stored past Nq or past column D
+    qc, kc, vc = (t.contiguous() for t in (q, k, v))
+    for (b, h) in ((0, 0), (B - 1, H - 1)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _assert_close_to_oracle(o[sl].contiguous(), lse[sl], qc[sl], kc[sl], vc[sl], dt, causal, plan=plan, head=b * H + h)

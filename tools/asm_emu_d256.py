@@ -16,18 +16,23 @@ from isa import Reg  # noqa: E402
 LOG2E = 1.4426950408889634
 D = 256
 ROWS = 128               # Q rows per workgroup
+DTRIM = None             # a head dim below 256 (the trimmed body, opt=trim): rows of 2 * DTRIM bytes
 _PROGS = {}
 
 
 def program(bf16, **cfg):
+    if DTRIM is not None:
+        cfg = dict(cfg, opt=tuple(cfg.get("opt", ())) + ("trim",))
     key = (bf16, tuple(sorted(cfg.items())))
     if key not in _PROGS:
         _PROGS[key] = gen.Gen256(bf16, **cfg).build()
     return _PROGS[key]
 
 
-def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, o_base, pitch=2 * D):
+def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, o_base, pitch=None):
     g = gen.Geo256
+    d = D if DTRIM is None else DTRIM
+    pitch = 2 * d if pitch is None else pitch
     lane = np.arange(64)
     n16, g4 = lane & 15, lane >> 4
     q0 = qblk * ROWS
@@ -54,7 +59,7 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, o_base, p
     v[13] = (n16 * pitch + 8 * g4).astype(np.uint32)                                   # A_OO0
 
     def srd(base, rows):
-        return np.array([base & 0xffffffff, base >> 32, (rows - 1) * pitch + 2 * D, 0x00020000], dtype=np.uint32)
+        return np.array([base & 0xffffffff, base >> 32, (rows - 1) * pitch + 2 * d, 0x00020000], dtype=np.uint32)
 
     args = {0: Reg("v", 0), 1: Reg("v", 1), 2: Reg("v", 2), 3: qw0 * pitch, 4: srd(q_base, Nq), 5: srd(k_base, Nkv), 6: srd(v_base, Nkv)}
     for n in range(7, 13):
@@ -68,17 +73,19 @@ def wave_args(w, qblk, Nq, Nkv, causal, scale, q_base, k_base, v_base, o_base, p
     args[22] = qw0 * pitch
     args[23] = args[24] = 16 * pitch
     args[25] = srd(o_base, Nq)
+    args[26] = d // 8
     args["vregs"] = v
     return args
 
 
 def run_block(q, k, v, qblk, causal, scale=None, bf16=False, check_hazards=True, **cfg):
-    scale = D ** -0.5 if scale is None else scale
+    d = D if DTRIM is None else DTRIM
+    scale = d ** -0.5 if scale is None else scale
     Nq, Nkv = q.shape[0], k.shape[0]
     pad = np.full(4096, 0x7e00 if not bf16 else 0x7fc0, dtype=np.uint16)
     bufs, bases = [], []
     addr = 0x10000000
-    for t in (q, k, v, np.full((Nq, D), np.nan)):
+    for t in (q, k, v, np.full((Nq, d), np.nan)):
         arr = np.concatenate([pad, h128.to_bits(t, bf16).ravel(), pad]).view(np.uint8).copy()
         bufs.append((addr, arr))
         bases.append(addr + pad.size * 2)
@@ -89,7 +96,7 @@ def run_block(q, k, v, qblk, causal, scale=None, bf16=False, check_hazards=True,
         w.v[:16] = a["vregs"]
     m.run()
     rows = min(ROWS, Nq - qblk * ROWS)
-    o_bits = bufs[3][1].view(np.uint16)[pad.size:pad.size + Nq * D].reshape(Nq, D)[qblk * ROWS:qblk * ROWS + rows]
+    o_bits = bufs[3][1].view(np.uint16)[pad.size:pad.size + Nq * d].reshape(Nq, d)[qblk * ROWS:qblk * ROWS + rows]
     o = h128.from_bits(o_bits.copy(), bf16)
     lse = np.empty(ROWS, dtype=np.float32)
     for w in range(4):
@@ -98,17 +105,16 @@ def run_block(q, k, v, qblk, causal, scale=None, bf16=False, check_hazards=True,
     allbits = bufs[3][1].view(np.uint16)
     fill = h128.to_bits(np.array([np.nan]), bf16)[0]
     mask = np.ones(allbits.size, dtype=bool)
-    lo = pad.size + qblk * ROWS * D
-    mask[lo:lo + rows * D] = False
-    mask[:pad.size] = False
-    mask[pad.size + Nq * D:] = False
+    lo = pad.size + qblk * ROWS * d
+    mask[lo:lo + rows * d] = False
     assert (allbits[mask] == fill).all(), "a store outside the workgroup's rows"
     return o, lse[:rows].copy(), m
 
 
 def check(Nq, Nkv, qblk, causal, bf16=False, seed=0, amp=1.0, verbose=True, **cfg):
     rng = np.random.default_rng(seed)
-    q, k, v = rng.standard_normal((Nq, D)) * amp ** 0.5, rng.standard_normal((Nkv, D)) * amp ** 0.5, rng.standard_normal((Nkv, D))
+    d = D if DTRIM is None else DTRIM
+    q, k, v = rng.standard_normal((Nq, d)) * amp ** 0.5, rng.standard_normal((Nkv, d)) * amp ** 0.5, rng.standard_normal((Nkv, d))
     o, lse, m = run_block(q, k, v, qblk, causal, bf16=bf16, **cfg)
     r0 = qblk * ROWS
     h128_hd = h128.HD

@@ -20,8 +20,10 @@ def main():
     dev = torch.device("cuda", 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     full = lib.fa2_get_option(b"asm")
-    D = 256
-    for (B, H, N, Nkv, dt, causal) in SHAPES:
+    dims = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256]
+    for D in dims:
+      for (B, H, N, Nkv, dt, causal) in (SHAPES if D == 256 else SHAPES[:1] + SHAPES[3:5]):
+       if True:
         tdt = torch.float16 if dt == 0 else torch.bfloat16
         q, k, v = (torch.randn((B, H, n, D), device=dev).to(tdt) for n in (N, Nkv, Nkv))
         o = torch.empty_like(q)
@@ -50,8 +52,8 @@ def main():
         lib.fa2_set_option(b"asm", full)
         flops = 4.0 * B * H * N * Nkv * D * (0.5 if causal else 1.0)
         a, h_ = statistics.median(ts["asm"]), statistics.median(ts["hip"])
-        print("B%d H%d N%d D256 %s causal=%d: hand-scheduled %.1f us (%.0f TF, %.3f of peak), compiler-scheduled %.1f us (%.0f TF); %.2fx"
-              % (B, H, N, "f16" if dt == 0 else "bf16", causal, a, flops / a / 1e6, flops / a / 1e6 / 2500, h_, flops / h_ / 1e6, h_ / a))
+        print("B%d H%d N%d D%d %s causal=%d: hand-scheduled %.1f us (%.0f TF, %.3f of peak), compiler-scheduled %.1f us (%.0f TF); %.2fx"
+              % (B, H, N, D, "f16" if dt == 0 else "bf16", causal, a, flops / a / 1e6, flops / a / 1e6 / 2500, h_, flops / h_ / 1e6, h_ / a))
 
 
 if __name__ == "__main__":

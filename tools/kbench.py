@@ -35,6 +35,8 @@ CFGS = {
     "d64h": (1, 24, 5120, 64, "f16", False),
     "d256": (2, 16, 2048, 256, "f16", False),
     "d256c": (2, 16, 2048, 256, "bf16", True),
+    "d256h": (1, 24, 4096, 256, "f16", False),
+    "d256l": (2, 16, 4096, 256, "f16", True),
     "n2k": (4, 16, 2048, 128, "f16", False),
     "n1k": (8, 16, 1024, 128, "f16", False),
     "n512": (16, 16, 512, 128, "f16", False),
@@ -63,7 +65,7 @@ def build(specs):
     for s in specs:
         name, _, flags = s.partition(":")
         fl = [f for f in flags.split(",") if f]
-        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "m16gen=", "dq16gen=", "dkv16gen=", "only=", "opts="))]
+        extra = [f for f in fl if not f.startswith(("gen=", "bgen=", "m16gen=", "d256gen=", "dq16gen=", "dkv16gen=", "only=", "opts="))]
         only = None if extra else ["fwd_asm", "bwd_asm"]          # generator-only variants: recompile just the units that include the bodies
         for f in fl:
             if f.startswith("only="):                            # only=fwd_asm+host: -D flags that matter to these units alone
@@ -76,6 +78,8 @@ def build(specs):
                 opts["bwd_d128_gen.py"] = f[5:].replace(";", ",")
             if f.startswith("m16gen="):      # options of csrc/gen/fwd_m16_gen.py (the 16x16x32 body)
                 opts["fwd_m16_gen.py"] = f[7:].replace(";", ",")
+            if f.startswith("d256gen="):     # options of csrc/gen/fwd_m16_d256_gen.py (the head-dim-256 body)
+                opts["fwd_m16_d256_gen.py"] = f[8:].replace(";", ",")
             if f.startswith("dq16gen="):     # ... of the 16x16x32 backward passes (csrc/gen/bwd_dq_m16_gen.py, bwd_dkv_m16_gen.py; timed by tools/bwd_bench.py --libs)
                 opts["bwd_dq_m16_gen.py"] = f[8:].replace(";", ",")
             if f.startswith("dkv16gen="):

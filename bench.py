@@ -48,6 +48,9 @@ Rank 0 prints ONE JSON line.
                region (HIP events on the launch stream, one event between consecutive launches).
   steady       the same loop re-timed for --steady-launches launches AFTER the contractual region
                (extra evidence, not the metric): the rate the kernel sustains once the clock has settled.
+  sustained    (N = 1) the same loop for --sustain-seconds of GPU time (default 5): launches, mean launch time, first /
+               last / slowest chunk of 500 — long enough for an outside utilisation sampler to see the device busy
+               and for clock and temperature to reach their steady state (round 6; evidence, not the metric).
   roofline     prices the kernel against the 2.5 PFLOP/s dense fp16/bf16 MFMA peak
                (/opt/skills/guides/MI355X_MICROARCH.md) using the average launch duration of the timed
                region; `sustained_peak` / `frac_sustained` use the MFMA-only micro-benchmark measured on
@@ -163,6 +166,8 @@ def main():
                     help="default: c2 with one rank; c5 (+ the c2 weak-scaling figure under `weak_c2`) with --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-launches", type=int, default=400, help="launches of the post-region steady re-timing (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="GPU seconds of the same loop after the steady re-timing (evidence: utilisation samplers, thermal steady state; 0 = skip)")
     ap.add_argument("--collectives", action="store_true", help="also time scatter_batch / gather_batch (reported separately)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (dry run of the multi-rank path on one GPU)")
@@ -361,6 +366,24 @@ def main():
             steady_ms = s0.elapsed_time(s1) / args.steady_launches
             r["steady"] = {"launches": args.steady_launches, "kernel_ms": round(steady_ms, 5),
                            "tflops": round(attention_flops(B_local, H, N, N, D, causal) / (steady_ms * 1e-3) / 1e12, 2)}
+        # ---- sustained load (evidence, not the metric): the same loop for --sustain-seconds of GPU time, in chunks — long enough for an outside
+        #      utilisation sampler (rocm-smi every few seconds) to see the device busy, and for the clock / temperature to reach their steady state
+        r["sustained"] = None
+        if args.sustain_seconds > 0 and extras and world == 1:
+            chunk, chunks, total_ms = 500, [], 0.0
+            while total_ms < args.sustain_seconds * 1e3 and len(chunks) < 200:
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(chunk):
+                    o = attn(q, k, v, None, causal)
+                s1.record()
+                torch.cuda.synchronize()
+                chunks.append(s0.elapsed_time(s1) / chunk)
+                total_ms += chunks[-1] * chunk
+            mean_ms = total_ms / (chunk * len(chunks))
+            r["sustained"] = {"launches": chunk * len(chunks), "gpu_seconds": round(total_ms * 1e-3, 2), "kernel_ms": round(mean_ms, 5),
+                              "tflops": round(attention_flops(B_local, H, N, N, D, causal) / (mean_ms * 1e-3) / 1e12, 2),
+                              "first_chunk_ms": round(chunks[0], 5), "last_chunk_ms": round(chunks[-1], 5), "slowest_chunk_ms": round(max(chunks), 5)}
         return r
 
     m = measure(args.workload, True)
@@ -483,7 +506,7 @@ def main():
                                    % (args.workload, B_local, H, N, D, str(dtype)[6:], causal),
                        "global_batch": B_global, "parallelism": "batch-shard x%d (no data-path collective)" % world},
             "roofline": roof,
-            "sequence": ["parity_gate", "cold_warmup", "cold_timed", "settle", "warmup", "timed", "per_launch_events", "steady", "backward_info", "cpu_baseline"],
+            "sequence": ["parity_gate", "cold_warmup", "cold_timed", "settle", "warmup", "timed", "per_launch_events", "steady", "sustained", "backward_info", "cpu_baseline"],
             "settle": settle_info,
             "pct_of_mfma_roofline": round(100.0 * value / (MFMA_PEAK_TFLOPS * world), 2),
             "launch_ms": {"min": round(min(per_launch), 5), "median": round(statistics.median(per_launch), 5),
@@ -493,6 +516,8 @@ def main():
         }
         if steady is not None:
             line["steady"] = steady
+        if m.get("sustained") is not None:
+            line["sustained"] = m["sustained"]
         if weak is not None:
             line["weak_c2"] = weak
         if rank_info is not None:

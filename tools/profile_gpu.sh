@@ -9,11 +9,11 @@ WL=${2:-c2}
 OUT=gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 50 --warmup 10 --workload $WL --no-cpu-baseline"
+CMD="python bench.py --steps 50 --warmup 10 --workload $WL --no-cpu-baseline --sustain-seconds 0"
 python bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
 # the trace pass runs bench.py's default step counts so that its per-kernel average is the same mix of warm-up and
 # steady launches the bench line is measured on
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --workload $WL --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --workload $WL --no-cpu-baseline --sustain-seconds 0 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES -d $OUT/pmc_mfma -o pmc -- $CMD > $OUT/pmc_mfma.log 2>&1

@@ -21,7 +21,9 @@ constexpr int kD256LdsBytes = 4 * kD256TileB + 16;
 typedef uint32_t d256_u32x4s __attribute__((ext_vector_type(4)));
 
 // TRIM: head dims 136 .. 248 on the same body (generator opt=trim): rows of p.D columns at any pitch, padded columns zero-filled by the loads themselves
-template <bool BF16, bool CAUSAL, bool TRIM>
+// KS (TRIM only): the 32-column k-steps of Q.K^T the body runs, 5 .. 8 for head dims <= 160 / 192 / 224 / 256 (d groups of O: 2 KS) — k-steps and d groups
+// without a real column are not in the instruction stream at all: 84 / 100 / 116 / 132 MFMAs per tile
+template <bool BF16, bool CAUSAL, bool TRIM, int KS = 8>
 __global__ __launch_bounds__(256, 1) void fwd_asm_d256_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -81,15 +83,51 @@ __global__ __launch_bounds__(256, 1) void fwd_asm_d256_kernel(const FwdParams p)
       "s"(ntw), "s"(ntiles), "s"(k_tile), "s"(v_tile), "s"(k_row2), "s"(v_row2), "s"(ldsw), "v"(o_off), "s"(ow), "s"(q_t16),     \
       "s"(o_t16), "s"(ors), "s"(ng)                                                                                           \
     :
-    if constexpr (BF16 && TRIM) {
+    if constexpr (BF16 && TRIM && KS == 5) {
         asm volatile(
-#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim.inc)
+#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim5.inc)
             FA2_D256_OPERANDS
 #include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
         );
-    } else if constexpr (TRIM) {
+    } else if constexpr (BF16 && TRIM && KS == 6) {
         asm volatile(
-#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim.inc)
+#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim6.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16 && TRIM && KS == 7) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim7.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (BF16 && TRIM && KS == 8) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_bf16_trim8.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (!BF16 && TRIM && KS == 5) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim5.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (!BF16 && TRIM && KS == 6) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim6.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (!BF16 && TRIM && KS == 7) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim7.inc)
+            FA2_D256_OPERANDS
+#include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
+        );
+    } else if constexpr (!BF16 && TRIM && KS == 8) {
+        asm volatile(
+#include FA2_D256_INC(fa2_fwd_m16_d256_f16_trim8.inc)
             FA2_D256_OPERANDS
 #include FA2_D256_INC(fa2_fwd_d128_clobbers.inc)
         );

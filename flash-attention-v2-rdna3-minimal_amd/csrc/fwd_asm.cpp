@@ -43,9 +43,9 @@ int launch_asm_t(const fa2::FwdParams& p0, hipStream_t stream) {
 }
 
 // head dim 256 (round 6): 128-row workgroups, one item each (fa2_fwd_d256.hip.h)
-template <bool BF16, bool CAUSAL, bool TRIM>
+template <bool BF16, bool CAUSAL, bool TRIM, int KS = 8>
 int launch_d256_t(const fa2::FwdParams& p0, hipStream_t stream) {
-    constexpr auto kern = fa2::fwd_asm_d256_kernel<BF16, CAUSAL, TRIM>;
+    constexpr auto kern = fa2::fwd_asm_d256_kernel<BF16, CAUSAL, TRIM, KS>;
     if (int rc = fa2::set_lds<kern>(fa2::kD256LdsBytes)) return rc;
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + fa2::kD256Rows - 1) / fa2::kD256Rows;
@@ -60,9 +60,16 @@ int launch_d256_t(const fa2::FwdParams& p0, hipStream_t stream) {
 namespace fa2 {
 
 int launch_fwd_asm_d256(bool bf16, const FwdParams& p, bool causal, hipStream_t stream) {
-    if (p.D < 256) {       // head dims 136 .. 248: the general form of the offsets, any row pitch
-        if (bf16) return causal ? launch_d256_t<true, true, true>(p, stream) : launch_d256_t<true, false, true>(p, stream);
-        return causal ? launch_d256_t<false, true, true>(p, stream) : launch_d256_t<false, false, true>(p, stream);
+    if (p.D < 256) {       // head dims 136 .. 248: the general form of the offsets, any row pitch; the body runs ceil(D / 32) k-steps
+        const int ks = (p.D + 31) / 32;
+#define FA2_D256_TRIM_CASE(K)                                                                                                              \
+        if (ks == K) {                                                                                                                 \
+            if (bf16) return causal ? launch_d256_t<true, true, true, K>(p, stream) : launch_d256_t<true, false, true, K>(p, stream);   \
+            return causal ? launch_d256_t<false, true, true, K>(p, stream) : launch_d256_t<false, false, true, K>(p, stream);           \
+        }
+        FA2_D256_TRIM_CASE(5) FA2_D256_TRIM_CASE(6) FA2_D256_TRIM_CASE(7) FA2_D256_TRIM_CASE(8)
+#undef FA2_D256_TRIM_CASE
+        return FA2_ERR_HEAD_DIM;
     }
     if (bf16) return causal ? launch_d256_t<true, true, false>(p, stream) : launch_d256_t<true, false, false>(p, stream);
     return causal ? launch_d256_t<false, true, false>(p, stream) : launch_d256_t<false, false, false>(p, stream);

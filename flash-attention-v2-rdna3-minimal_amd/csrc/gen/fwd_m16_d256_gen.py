@@ -80,24 +80,28 @@ def VF(dg, kvs):
 
 
 class Gen256(m16.Gen16):
-    WINDOWS = {"m": (4.0, 24.0), "mmask": (4.0, 40.0), "e": (24.0, 112.0), "vread": (66.0, 130.0), "kread_ct": (8.0, 60.0), "dma": (2.0, 64.0)}
-
-    def __init__(self, bf16=False, **cfg):
+    def __init__(self, bf16=False, nks=8, **cfg):
+        """nks: 32-column k-steps of Q.K^T the body really runs (opt=trim: 5 .. 8 for head dims <= 160 / 192 / 224 / 256; the d groups of O follow: 2 nks).
+        The images, rings and the LDS-DMA are the head-dim-256 ones whatever nks is; k-steps and d groups that hold no real column — their MFMAs, their
+        fragment reads — are simply not there: 84 / 100 / 116 / 132 MFMAs per tile."""
         opt = tuple(o for o in cfg.get("opt", ()) if o != "lm") + ("lm",)
         user = dict(cfg)
         user["opt"] = opt
         super().__init__(bf16, hd=128, **user)
         assert not self.ct, "the head-dim-256 bodies scale the f32 product"
         self.trim = "trim" in self.opt
+        assert 5 <= nks <= 8 and (nks == 8 or self.trim)
         self.g = Geo256()
-        self.NKS16, self.NDG = 8, 16
+        self.NKS16, self.NDG = nks, 2 * nks
         self.kf16, self.vf16, self.oacc16, self.qf16 = KF, VF, OACC, QF
         self.ones16 = ONES
         self.pool = True
         self.vflip, self.vro = True, VRO
         self.npv, self.nqk = 4 * self.NDG, 8 * self.NKS16 + 4
         self.ng = self.npv + self.nqk
-        for k, w in self.WINDOWS.items():
+        npv, ng = float(self.npv), float(self.ng)
+        windows = {"m": (4.0, 24.0), "mmask": (4.0, 40.0), "e": (24.0, ng - 20.0), "vread": (npv + 2.0, ng - 2.0), "kread_ct": (8.0, npv - 4.0), "dma": (2.0, npv)}
+        for k, w in windows.items():
             if k not in cfg:
                 self.cfg[k] = w
 
@@ -307,7 +311,7 @@ class Gen256(m16.Gen16):
             p.emit("v_lshlrev_b32", TMP[1], 2, TMP[1])
             p.emit("s_nop", 0)
             p.emit("v_xor_b32", VG0, TMP[0], TMP[1])
-            for ks in range(8):                                              # Q: granule 4 ks + g4 of the row
+            for ks in range(self.NKS16):                                     # Q: granule 4 ks + g4 of the row
                 p.emit("v_add_u32", TMP[2], 4 * ks, G4R)
                 p.emit("s_nop", 0)
                 p.emit("v_cmp_gt_u32", m16.VCC, A_NG, TMP[2])
@@ -317,7 +321,7 @@ class Gen256(m16.Gen16):
         for qg in range(2):
             if qg:
                 p.emit("s_add_u32", S_TMP, S_TMP, A_QT16)
-            for ks in range(8):
+            for ks in range(self.NKS16):
                 p.emit("buffer_load_dwordx4", QF(qg, ks), V(16 + ks) if self.trim else A_Q0, A_QRS, S_TMP, offen=True, offset=64 * ks)
         for ks in range(4):
             p.emit("v_xor_b32", KR[ks], ks << 6, A_KR0)
@@ -483,11 +487,11 @@ def main():
     cfg = base.parse_opts(a.opt)
     if base.is_probe(cfg) and not a.probe:
         sys.exit("fwd_m16_d256_gen.py: %r contains timing-probe options; they need --probe" % a.opt)
-    for bf16, trim in ((b, t) for b in (False, True) for t in (False, True)):
+    for bf16, trim, nks in ((b, t, n) for b in (False, True) for (t, n) in ((False, 8), (True, 8), (True, 7), (True, 6), (True, 5))):
         c = dict(cfg)
         c["opt"] = tuple(o for o in cfg.get("opt", ()) if o != "trim") + (("trim",) if trim else ())
-        prog = Gen256(bf16, **c).build()
-        path = os.path.join(a.out, "fa2_fwd_m16_d256_%s%s.inc" % ("bf16" if bf16 else "f16", "_trim" if trim else ""))
+        prog = Gen256(bf16, nks=nks, **c).build()
+        path = os.path.join(a.out, "fa2_fwd_m16_d256_%s%s.inc" % ("bf16" if bf16 else "f16", ("_trim%d" % nks) if trim else ""))
         base.write_atomic(path, "// GENERATED by csrc/gen/fwd_m16_d256_gen.py %s — do not edit.  %d instructions.\n" % (a.opt, len(prog.ins)) + base.render_inline(prog))
         print(path, len(prog.ins), "instructions")
 

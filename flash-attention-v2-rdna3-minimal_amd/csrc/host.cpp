@@ -173,11 +173,15 @@ bool asm_d256_ok(bool bf16, const fa2::FwdParams& p, bool causal) {
     (void)bf16;
     const int mask = fa2::options().asm_mask.load(std::memory_order_relaxed);
 #ifndef FA2_D256_TRIM_MIN      // (developer A/B: tools/kbench.py build NAME:-DFA2_D256_TRIM_MIN=144,only=host)
-#define FA2_D256_TRIM_MIN 176
+#define FA2_D256_TRIM_MIN 136
 #endif
     if (!(mask & 1) || !(mask & 1024) || p.D > 256 || p.D < FA2_D256_TRIM_MIN || p.negate_q || p.exact_scale || p.bias_kind != 0) return false;
+    // Head dims below 256 run ceil(D / 32) k-steps of the body (fwd_asm.cpp).  tools/d256_ab.py, one box (profiles/r21_d256_ab.txt), against the trimmed
+    // compiler-scheduled kernels: D 176 .. 248 1.25 .. 1.51x, causal or not; D 136 .. 160 (the 8-wave kernel runs those in ONE pass over all columns)
+    // non-causal 1.03 .. 1.05x, causal 0.86x at N = 4096: those keep the 8-wave kernel when causal.
+    if (p.D < 176 && causal) return false;
     // D == 256: the pieces of a wave's LDS-DMA share are derived from piece 0 by flipping offset bits — row pitches that are multiples of one 512-byte
-    // tile row; below (the body runs at D / 256 of its rate: from 176 on it beats the trimmed compiler-scheduled kernels) the general form, any pitch
+    // tile row; below, the general form of the offsets: any pitch
     if (p.D == 256 && (p.ks[2] % 256 || p.vs[2] % 256)) return false;
     if (((int64_t)(p.Nq + 32) * p.qs[2] + 256) * 2 >= ((int64_t)1 << 32) || ((int64_t)(p.Nq + 32) * p.os[2] + 256) * 2 >= ((int64_t)1 << 32)) return false;
     if (forced_rows() == 256) return false;              // (option rows = 256 pins the 256-row kernels: tests, A/B)

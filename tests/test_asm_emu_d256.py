@@ -57,6 +57,32 @@ def test_head_dims_below_256_on_the_same_body(d):
         harness._PROGS.clear()
 
 
+def test_trimmed_bodies_leave_out_the_k_steps_without_a_real_column():
+    """ceil(D / 32) k-steps of Q.K^T and twice as many d groups of O: 84 / 100 / 116 / 132 MFMAs per tile for head dims <= 160 / 192 / 224 / 256 (the
+    launcher picks the body, fwd_asm.cpp); a larger body than needed gives the same result (its extra k-steps multiply zero-filled columns)."""
+    import fwd_m16_d256_gen as gen
+    for nks, want in ((5, 84), (6, 100), (7, 116), (8, 132)):
+        prog = gen.Gen256(False, nks=nks, opt=("trim",)).build()
+        names = [i.ops[0].name if i.op == "label" else None for i in prog.ins]
+        ops = [i.op for i in prog.ins[names.index("ta_e"):names.index("tb_e")]]
+        assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == want
+    saved = harness.DTRIM, harness.NKS
+    try:
+        outs = []
+        for nks in (5, 7):
+            harness.DTRIM, harness.NKS = 152, nks
+            harness._PROGS.clear()
+            rng = np.random.default_rng(3)
+            q, k, v = rng.standard_normal((128, 152)), rng.standard_normal((200, 152)), rng.standard_normal((200, 152))
+            o, lse, m = harness.run_block(q, k, v, 0, False)
+            assert not m.errors
+            outs.append((o, lse))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    finally:
+        harness.DTRIM, harness.NKS = saved
+        harness._PROGS.clear()
+
+
 def test_d256_body_is_max_first_and_fits_the_instruction_formats():
     """132 MFMAs per full body (64 P.V + 64 Q.K^T + 4 row-sum links), every DS offset inside 16 bits and every MUBUF offset inside 12 (the assembler
     truncates the latter silently — the first GPU run of this kernel raced because of it; tools/asm_emu.py refuses both now), no fast loop."""
@@ -81,8 +107,8 @@ def test_d256_text_assembles_for_gfx950(tmp_path):
     llvm_mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
     if not os.path.exists(llvm_mc):
         pytest.skip("llvm-mc not installed")
-    for bf16, opt in ((False, ()), (True, ()), (False, ("trim",))):
-        prog = gen.Gen256(bf16, opt=opt).build()
+    for bf16, opt, nks in ((False, (), 8), (True, (), 8), (False, ("trim",), 8), (True, ("trim",), 5), (False, ("trim",), 6), (False, ("trim",), 7)):
+        prog = gen.Gen256(bf16, nks=nks, opt=opt).build()
         text = "\n".join(prog.text_lines())
         # inline-asm operands -> plain registers of the right width (the assembler checks syntax, operand classes and encodings)
         wide = {4: "s[8:11]", 5: "s[12:15]", 6: "s[16:19]", 25: "s[20:23]"}
@@ -91,7 +117,7 @@ def test_d256_text_assembles_for_gfx950(tmp_path):
             rep = wide.get(n) or sregs.get(n) or "v%d" % (n if n < 16 else n - 12)
             text = text.replace("%%%d" % n, rep)
         text = text.replace("%=", "0")
-        path = tmp_path / ("d256_%d_%d.s" % (bf16, len(opt)))
+        path = tmp_path / ("d256_%d_%d_%d.s" % (bf16, len(opt), nks))
         path.write_text(text + "\n")
         res = subprocess.run([llvm_mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, str(path)], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[-2000:]

@@ -237,17 +237,17 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     assert (p.kernel, p.contract) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16)
     with _fa2_lib.options(asm=451):
         assert (_meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16).kernel, _meta_plan(2, 16, 4096, 4096, 64, dt=torch.bfloat16, causal=True).contract) == (K.FA2_KERNEL_HIP_256, 0)
-    # head dims 176 .. 256 (round 6): the hand-scheduled 128-row kernel, f32 scale, row sums of the rounded P — from 512 keys on (causal: 1024), D = 256 with
-    # K row pitches that are multiples of 512 bytes; differentiated calls, short sweeps, padded K at D = 256, head dims below 176 and option "asm" bit 10
+    # head dims 136 .. 256 (round 6): the hand-scheduled 128-row kernel, f32 scale, row sums of the rounded P — from 512 keys on (causal: 1024), D = 256 with
+    # K row pitches that are multiples of 512 bytes; differentiated calls, short sweeps, padded K at D = 256 and option "asm" bit 10
     # clear keep the compiler-scheduled kernels
-    for D in (176, 224, 256):
+    for D in (136, 160, 176, 224, 256):
         p = _meta_plan(1, 24, 4096, 4096, D)
         assert (p.kernel, p.contract, p.rows, p.heads_main) == (K.FA2_KERNEL_ASM, C.FA2_CONTRACT_LSUM_P16, 128, 24), (D, p.as_dict())
     assert _meta_plan(2, 16, 2048, 2048, 256, dt=torch.bfloat16, causal=True).kernel == K.FA2_KERNEL_ASM
     assert _meta_plan(1, 24, 4096, 4096, 256, causal=_fa2_lib.FA2_FLAG_EXACT_SCALE).kernel != K.FA2_KERNEL_ASM
     assert _meta_plan(1, 24, 4096, 256, 256).kernel != K.FA2_KERNEL_ASM and _meta_plan(2, 16, 512, 512, 256, causal=True).kernel != K.FA2_KERNEL_ASM
     assert _meta_plan(1, 24, 4096, 4096, 256, kpad=8).kernel != K.FA2_KERNEL_ASM and _meta_plan(1, 24, 4096, 4096, 224, kpad=8).kernel == K.FA2_KERNEL_ASM
-    assert _meta_plan(1, 24, 4096, 4096, 160).kernel != K.FA2_KERNEL_ASM
+    assert _meta_plan(1, 24, 4096, 4096, 128 + 8).kernel == K.FA2_KERNEL_ASM and _meta_plan(1, 24, 4096, 4096, 264).kernel != K.FA2_KERNEL_ASM
     with _fa2_lib.options(asm=963):
         assert _meta_plan(1, 24, 4096, 4096, 256).kernel != K.FA2_KERNEL_ASM
     # two launches: 544 workgroups = two full rounds of the body + the last two heads as 128-row workgroups of the HIP kernel

@@ -92,14 +92,15 @@ def test_head_dim_256_large_logits():
             _assert_close_to_oracle(o[sl], lse[sl], qq[sl], kk[sl], vv[sl], dt, causal, plan=plan, head=3)
 
 
-@pytest.mark.parametrize("D", [176, 192, 200, 224, 248])
+@pytest.mark.parametrize("D", [136, 152, 160, 176, 192, 200, 224, 248])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_head_dims_below_256_on_the_hand_scheduled_kernel(D, dt):
-    """Head dims 176 .. 248 run ON the head-dim-256 body (generator opt=trim; the reference zero-pads D on the host, kernel_fp16.cu:763-779): rows of D
+    """Head dims 136 .. 248 run ON the head-dim-256 body — with the k-steps and d groups that hold no real column left out of the instruction stream
+    (ceil(D / 32) k-steps: 5 .. 8) — (generator opt=trim; the reference zero-pads D on the host, kernel_fp16.cu:763-779): rows of D
     columns at whatever pitch the tensors have, the padded columns of the Q / K / V images zero-filled by the loads themselves, D columns stored.  The
     tensors are column slices of NaN-filled allocations with a row pitch of D + 24 .. 40 elements: a granule fetched from the gap, or a column stored
     into it, would show."""
-    B, H, N, causal = 2, 5, 1100, (D % 16 == 0)
+    B, H, N, causal = 2, 5, 1100, (D % 16 == 0 and D >= 176)
     g = torch.Generator(device="cpu").manual_seed(D + dt)
     pad = 24 + 8 * (D % 3)
     big = {n: torch.full((B, H, N + 3, D + pad), float("nan"), dtype=TORCH_DT[dt], device=_dev()) for n in "qkv"}

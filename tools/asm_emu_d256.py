@@ -17,12 +17,13 @@ LOG2E = 1.4426950408889634
 D = 256
 ROWS = 128               # Q rows per workgroup
 DTRIM = None             # a head dim below 256 (the trimmed body, opt=trim): rows of 2 * DTRIM bytes
+NKS = None               # ... and the k-steps its body runs (default: ceil(DTRIM / 32), what the launcher picks)
 _PROGS = {}
 
 
 def program(bf16, **cfg):
     if DTRIM is not None:
-        cfg = dict(cfg, opt=tuple(cfg.get("opt", ())) + ("trim",))
+        cfg = dict(cfg, opt=tuple(cfg.get("opt", ())) + ("trim",), nks=NKS or (DTRIM + 31) // 32)
     key = (bf16, tuple(sorted(cfg.items())))
     if key not in _PROGS:
         _PROGS[key] = gen.Gen256(bf16, **cfg).build()

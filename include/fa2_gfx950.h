@@ -284,7 +284,7 @@ int fa2_tile_rows(int D, int* q_rows_per_block, int* kv_rows_per_tile);
  *   FA2_KERNEL_HIP_256 / _128     compiler-scheduled HIP kernel, 8-wave 256-row / 4-wave 128-row workgroups (csrc/fa2_fwd_kernel.hip.h)
  *   FA2_KERNEL_ASM                hand-scheduled 4-wave 256-row body (csrc/gen/fwd_d128_gen.py, fwd_m16_gen.py): head dims 64 and 128, and — on the
  *                                 16x16x32 bodies, padded columns zero-filled by the LDS-DMA — 40 .. 56 and 88 .. 120 (f32-scale kinds from 104);
- *                                 round 6: head dims 176 .. 256 on a 4-wave 128-row body (`rows` = 128; csrc/gen/fwd_m16_d256_gen.py: f32 scale,
+ *                                 round 6: head dims 136 .. 256 (below 176: non-causal calls) on a 4-wave 128-row body (`rows` = 128; csrc/gen/fwd_m16_d256_gen.py: f32 scale,
  *                                 FA2_CONTRACT_LSUM_P16; calls flagged FA2_FLAG_EXACT_SCALE keep the compiler-scheduled kernels)
  *   FA2_KERNEL_HIP_BIAS           the BIAS forms of the HIP kernel (fa2_fwd_bias); `rows` is reported as 0 = unspecified for it: the load form, and with it
  *                                 128- or 256-row workgroups, depends on the bias strides and alignment, which this query does not take
@@ -331,8 +331,9 @@ int fa2_fwd_prescales_q(int D, float scale);
  *                              round 6 a tile in which a P leaves the 16-bit range (fp16: a score 16 octaves above its row's reference) is formed again
  *                              in place and the wave finishes its sweep on the max-first bodies — <= 1.09x the sum-check bodies (bit 9 clear) on
  *                              N(0, amp^2) logits for every amp, 0.97x on benign data (profiles/r20_growth_cliff.txt; round 5 redid the item: 1.3 ..
- *                              1.7x); bit 10: head dims 176 .. 256 (D = 256: K / V row pitches that are multiples of 512 bytes) on the hand-scheduled
- *                              128-row kernel — 1.13 .. 1.6x the compiler-scheduled kernels from 512 keys (causal: 1024) on, profiles/r21_d256_ab.txt.
+ *                              1.7x); bit 10: head dims 136 .. 256 (D = 256: K / V row pitches that are multiples of 512 bytes; below 176: non-causal) on the
+ *                              hand-scheduled 128-row kernel — 1.25 .. 1.6x the compiler-scheduled kernels at D >= 176, from 512 keys (causal: 1024) on,
+ *                              profiles/r21_d256_ab.txt.
  *                              Default 1987.
  *                              0 = compiler-scheduled HIP kernels everywhere
  *   "persist"   FA2_PERSIST    1 (default) | 0 — persistent workgroups of the hand-scheduled forward kernels

@@ -31,6 +31,11 @@
  *   FA2_ORACLE_BF16_TRUNC  bf16 conversions truncate instead of RNE (kernel_bf16.cu:62-72)
  *   FA2_ORACLE_LSUM_P16    the row sum l adds the ROUNDED P (the values the P.V product consumes) instead of the f32 P: the
  *                          contract of the gfx950 head-dim-64 body, whose row sums ride the matrix pipe (csrc/gen/fwd_d128_gen.py "lmfma")
+ *   FA2_ORACLE_PRESCALE_FUSED  (with PRESCALE_Q, fp16 only) the product Q * scale*log2(e) is rounded to fp16 ONCE, from the exact
+ *                          product, as the gfx950 fp16 kernels' v_fma_mixlo_f16 does.  pure_torch_ver.py:61 (and PRESCALE_Q alone)
+ *                          rounds it to f32 first and to fp16 after: the two differ by one fp16 ulp on the rare products whose f32
+ *                          rounding lands on an fp16 tie — how rare depends on the bit pattern of scale*log2(e): D = 112 and 56
+ *                          are unlucky (found on the GPU in round 6: 17 rows of 1024 off by > 5e-4 of LSE on N(0, 6^2) logits)
  *   FA2_ORACLE_PRESCALE_Q  Q is multiplied by scale*log2(e) and rounded back to the I/O dtype BEFORE the
  *                          product, as pure_torch_ver.py:61 does (`scale * q_frags[Tr_i]`); S = Q' K^T is then
  *                          not scaled again.  The gfx950 kernels use this contract where
@@ -53,6 +58,7 @@
 #define FA2_ORACLE_BF16_TRUNC 4
 #define FA2_ORACLE_PRESCALE_Q 8
 #define FA2_ORACLE_LSUM_P16 16
+#define FA2_ORACLE_PRESCALE_FUSED 32
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -108,6 +114,19 @@ typedef struct {
     int dtype, trunc;
 } cvt_t;
 
+/* exact double -> nearest fp16 value (ties to even), returned as float: the single rounding of a fused multiply-to-half */
+static float f16_round_double(double p) {
+    if (!(p == p) || p == 0.0 || isinf(p)) return (float)p;
+    int e;
+    (void)frexp(p, &e);                 /* |p| = f * 2^e, f in [0.5, 1) -> exponent of the leading bit: e - 1 */
+    int lead = e - 1;
+    if (lead < -14) lead = -14;         /* subnormal halves share the exponent -14 */
+    const double r = nearbyint(ldexp(p, 10 - lead));        /* 11 significant bits (fewer below 2^-14), round-to-nearest-even */
+    const double v = ldexp(r, lead - 10);
+    if (fabs(v) >= 65520.0) return (float)(p < 0 ? -INFINITY : INFINITY);
+    return (float)v;                    /* exactly representable in fp16, hence in f32 */
+}
+
 static inline float load16(cvt_t c, uint16_t h) { return c.dtype == FA2_ORACLE_DTYPE_F16 ? f16_to_f32(h) : bf16_to_f32(h); }
 static inline uint16_t store16(cvt_t c, float f) { return c.dtype == FA2_ORACLE_DTYPE_F16 ? f32_to_f16(f) : f32_to_bf16(f, c.trunc); }
 static inline float round16(cvt_t c, float f) { return load16(c, store16(c, f)); }
@@ -136,7 +155,7 @@ static int fwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint1
     const float c = scale * 1.4426950408889634f; /* kernel_fp16.cu:827 */
     const int Tr = (Nq + Br - 1) / Br, Tc = (Nkv + Bc - 1) / Bc;
     const int round_s = flags & FA2_ORACLE_ROUND_S, round_o = flags & FA2_ORACLE_ROUND_O;
-    const int prescale = flags & FA2_ORACLE_PRESCALE_Q, lsum16 = flags & FA2_ORACLE_LSUM_P16;
+    const int prescale = flags & FA2_ORACLE_PRESCALE_Q, lsum16 = flags & FA2_ORACLE_LSUM_P16, fused = flags & FA2_ORACLE_PRESCALE_FUSED;
     const float cs = prescale ? 1.f : c; /* factor applied to the f32 dot product */
     int failed = 0;
 #ifdef _OPENMP
@@ -184,7 +203,8 @@ static int fwd_impl(int dtype, const uint16_t* q, const uint16_t* k, const uint1
                     for (int i = 0; i < rows; ++i) {
                         for (int d = 0; d < D; ++d) {
                             float x = load16(cv, qb[(int64_t)(r0 + i) * qs[2] + d]);
-                            if (prescale) x = round16(cv, x * c); /* pure_torch_ver.py:61 */
+                            if (prescale && fused && dtype == FA2_ORACLE_DTYPE_F16) x = f16_round_double((double)x * (double)c);
+                            else if (prescale) x = round16(cv, x * c); /* pure_torch_ver.py:61 */
                             qf[(size_t)i * D + d] = x;
                         }
                         m[i] = -INFINITY;

@@ -32,6 +32,7 @@ ROUND_S = 1
 ROUND_O = 2
 BF16_TRUNC = 4
 PRESCALE_Q = 8      # scale*log2e folded into Q in the I/O dtype (pure_torch_ver.py:61)
+PRESCALE_FUSED = 32  # with PRESCALE_Q, fp16: the product is rounded to fp16 ONCE from the exact product (v_fma_mixlo_f16), not via f32 (pure_torch_ver.py:61)
 LSUM_P16 = 16       # the row sum adds the rounded P (what the P.V product consumes): the head-dim-64 asm body's row sums ride the matrix pipe
 LOG2E = 1.4426950408889634
 

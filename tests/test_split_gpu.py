@@ -70,6 +70,8 @@ def _check_heads(o, lse, q, k, v, dt, heads, bnhd=False, plan=None):
     one contract per call; `plan` = _plan_ws(...) of the call that produced o)."""
     assert plan is not None and plan.kernel_tail == 0
     flags = (fo.PRESCALE_Q if plan.contract & _fa2_lib.FA2_CONTRACT_PRESCALE_Q else 0) | (fo.LSUM_P16 if plan.contract & _fa2_lib.FA2_CONTRACT_LSUM_P16 else 0)
+    if dt == 0 and flags & fo.PRESCALE_Q:
+        flags |= fo.PRESCALE_FUSED              # (the fp16 kernels round Q * c once, from the exact product: v_fma_mixlo_f16)
     for (b, h) in heads:
         if bnhd:
             sl = lambda t: t[b:b + 1, :, h:h + 1].transpose(1, 2).contiguous()  # noqa: E731

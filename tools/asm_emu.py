@@ -464,12 +464,13 @@ class Machine:
             with np.errstate(invalid="ignore", over="ignore"):
                 self.wr32(w, ops[0], (x.astype(np.float64) * self.rdf(w, ops[2]).astype(np.float64)).astype(np.float32))
         elif op in ("v_fma_mixlo_f16", "v_fma_mixhi_f16"):
-            # f16 half of src0 (op_sel) x f32 src1 + 0, computed in f32 and rounded once more to f16 into the low / high half of the destination
+            # f16 half of src0 (op_sel) x f32 src1 + 0: the exact product (11 x 24 bits fit a double) rounded ONCE to f16 — a fused operation on the hardware
+            # (round 6: the emulator rounded via f32 until the GPU disagreed with it by one ulp on rare elements at unlucky scales)
             assert ins.mods.get("op_sel_hi") == "[1,0,0]" and isinstance(ops[3], int) and ops[3] == 0
             half = 16 if ins.mods.get("op_sel") == "[1,0,0]" else 0
             x = f16_to_f32(((self.rd32(w, ops[1]) >> half) & 0xffff).astype(np.uint16))
             with np.errstate(invalid="ignore", over="ignore"):
-                r = f32_to_f16_bits((x.astype(np.float64) * self.rdf(w, ops[2]).astype(np.float64)).astype(np.float32))
+                r = (x.astype(np.float64) * self.rdf(w, ops[2]).astype(np.float64)).astype(np.float16).view(np.uint16).astype(np.uint32)
             old = self.rd32(w, ops[0])
             self.wr32(w, ops[0], ((old & np.uint32(0xffff0000)) | r) if op == "v_fma_mixlo_f16" else ((old & np.uint32(0x0000ffff)) | (r << 16)))
         elif op == "v_add_u32":

@@ -100,10 +100,12 @@ class Gen256(m16.Gen16):
         self.npv, self.nqk = 4 * self.NDG, 8 * self.NKS16 + 4
         self.ng = self.npv + self.nqk
         npv, ng = float(self.npv), float(self.ng)
-        windows = {"m": (4.0, 24.0), "mmask": (4.0, 40.0), "e": (24.0, ng - 20.0), "vread": (npv + 2.0, ng - 2.0), "kread_ct": (8.0, npv - 4.0), "dma": (2.0, npv)}
+        windows = {"m": (4.0, 24.0), "mmask": (4.0, 40.0), "e": (24.0, ng - 20.0), "vread": (npv + 2.0, ng - 2.0), "kread_ct": (8.0, npv - 4.0), "dma": (2.0, npv), "dmaf": (2.0, ng - 24.0)}
         for k, w in windows.items():
             if k not in cfg:
                 self.cfg[k] = w
+            elif nks != 8:                   # a window given for the 132-gap body (tools/kbench.py sweeps): the shorter bodies take it to scale
+                self.cfg[k] = (cfg[k][0] * ng / 132.0, cfg[k][1] * ng / 132.0)
 
     # ------------------------------------------------------------------ MFMA lists (one q block)
     def qk_mfmas(self, par):
@@ -170,14 +172,13 @@ class Gen256(m16.Gen16):
         g = self.g
         rs, d0, soff, row2 = (A_KRS, KD0, S_KOFF, A_KROW2) if which == "k" else (A_VRS, VD0, S_VOFF, A_VROW2)
         lbase = (g.K_SLOT if which == "k" else g.V_BASE) + slot_par * g.SLOT_B
-        skip = self.p.fresh("dma_skip")
-        out = [mk("s_add_u32", S_TMP2, S_T, ahead, tag="salu"), mk("s_cmp_lt_i32", S_TMP2, A_NTWG, tag="salu"),
-               mk("s_cbranch_scc0", Label(skip), tag="branch"),
-               mk("s_add_u32", M0, A_LDSW, lbase, tag="salu"), mk("s_mov_b32", S_TMP, 0 if self.trim else soff, tag="salu")]
+        groups = [[mk("s_add_u32", M0, A_LDSW, lbase, tag="salu"), mk("s_mov_b32", S_TMP, 0 if self.trim else soff, tag="salu")]]
         for i in range(g.NP):
+            out = []
             flip = (32 * i) if which == "k" else (128 * (i & 1)) | (32 * ((i >> 1) & 1))
             if i == 0 and not self.trim:
                 reg = d0
+                out.append(mk("s_nop", 0, tag="salu"))
             else:
                 reg = (DT0, DT1)[i & 1]
                 if i:
@@ -204,8 +205,19 @@ class Gen256(m16.Gen16):
                     out.append(mk("v_xor_b32", reg, flip, d0, tag="valu"))
                 out.append(mk("s_nop", 0, tag="salu"))
             out.append(mk("buffer_load_dwordx4", reg, rs, soff if self.trim else S_TMP, tag="dma", offen=True, offset=1024 * (i & 3), lds=True))
-        out.append(Ins("label", (Label(skip),)))
-        return [out]              # one atomic group: M0, the running scalar offset and the scratch registers belong to it
+            groups.append(out)
+        if not guarded:
+            # main-loop bodies (tile t + ahead exists): one group per piece, in this order — M0, the running scalar offset, the two scratch registers and
+            # VCC (trim) belong to the ONE stream the K and V groups of a body form; eight 1 KiB pieces back to back hold up the wave's issue (round 6:
+            # the staging instructions as two blocks cost 14.5 % of the launch, profiles/r22_d256_body_ablation.txt)
+            return groups
+        skip = self.p.fresh("dma_skip")
+        flat = [mk("s_add_u32", S_TMP2, S_T, ahead, tag="salu"), mk("s_cmp_lt_i32", S_TMP2, A_NTWG, tag="salu"),
+                mk("s_cbranch_scc0", Label(skip), tag="branch")]
+        for grp in groups:
+            flat.extend(grp)
+        flat.append(Ins("label", (Label(skip),)))
+        return [flat]             # one atomic group: the guard's SCC and branch must not be interleaved with other streams
 
     def rare_rescale(self, lab):
         r = [Ins("label", (Label(lab),))]
@@ -232,22 +244,27 @@ class Gen256(m16.Gen16):
     def body(self, par, pv=True, s1=True, s2=True, masked=False, guarded=True, name="body", first=False, dma=True, **kw):
         p, cfg, ng = self.p, self.cfg, self.ng
         start = len(p.ins)
+        abl = set(cfg["abl"]) if name.startswith(("TA", "TF")) else set()       # timing-only ablations of the main-loop bodies (tools/kbench.py d256gen=abl=...)
         mf = (self.pv_mfmas(par, 0) if pv else [None] * self.npv) + self.qk_phase(par, s1, s2)
         assert len(mf) == ng
+        if "mfma" in abl:
+            mf = [None] * ng
         if not pv:
             p.emit("s_nop", 15)
             p.emit("s_nop", 15)
         load = [0.0] * ng
         slots = [[] for _ in range(ng)]
-        if s1:
+        if s1 and "max" not in abl:
             mw = cfg["mmask"] if masked else cfg["m"]
             self.place(load, slots, self.stream_max(0, par ^ 1, masked, first), mw[0], mw[1], 0)
-        if dma:
-            self.place(load, slots, self.dma_group("k", par ^ 1, True, 3) + self.dma_group("v", par, True, 2), cfg["dma"][0], cfg["dma"][1], 2)
-        if s2:
+        if dma and "dma" not in abl:
+            dw = cfg["dma"] if guarded else cfg["dmaf"]
+            self.place(load, slots, self.dma_group("k", par ^ 1, guarded, 3) + self.dma_group("v", par, guarded, 2), dw[0], dw[1], 2)
+        if s2 and "kread" not in abl:
             self.place_pool_kreads(load, slots, par)
-        if s1:
+        if s1 and "vread" not in abl:
             self.place(load, slots, self.stream_vread(par ^ 1), cfg["vread"][0], cfg["vread"][1], 4)
+        if s1 and "exp" not in abl:
             self.place(load, slots, self.stream_exp(0, par ^ 1), (cfg["mmask"] if masked else cfg["m"])[1], cfg["e"][1], 5)
         self.last_load = load
         for g in range(ng):
@@ -268,8 +285,12 @@ class Gen256(m16.Gen16):
         p.emit("s_add_u32", S_T, S_T, 1)
         p.emit("s_add_u32", S_KOFF, S_KOFF, A_KTILE)
         p.emit("s_add_u32", S_VOFF, S_VOFF, A_VTILE)
-        p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
-        p.emit("s_barrier")
+        if "vmwait" in abl:
+            p.emit("s_waitcnt", lgkmcnt=0)
+        else:
+            p.emit("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        if "bar" not in abl:
+            p.emit("s_barrier")
         # legality (Gen16.body): no V^T read ahead of the last P.V MFMA that takes its registers, no link ahead of a pack of its registers
         ins = [x for x in p.ins[start:] if x.op != "label"]
         last = {}
@@ -391,6 +412,8 @@ class Gen256(m16.Gen16):
         for par, suffix in ((0, "e"), (1, "o")):
             if par == 1:
                 p.label("disp_odd")
+            p.emit("s_cmp_ge_i32", S_D, 4)           # t + 3 < ntw <= ntwg: the tiles this body stages exist, its staging needs no guard
+            p.emit("s_cbranch_scc1", Label("tf_" + suffix))
             p.emit("s_cmp_ge_i32", S_D, 3)
             p.emit("s_cbranch_scc1", Label("ta_" + suffix))
             p.emit("s_cmp_eq_u32", S_D, 2)
@@ -398,6 +421,9 @@ class Gen256(m16.Gen16):
             p.emit("s_cmp_eq_u32", S_D, 1)
             p.emit("s_cbranch_scc1", Label("tc_" + suffix))
             self.body(par, pv=False, s1=False, s2=False, name="ST%d" % par)
+            p.emit("s_branch", Label("dispatch"))
+            p.label("tf_" + suffix)
+            self.body(par, name="TF%d" % par, guarded=False)
             p.emit("s_branch", Label("dispatch"))
             p.label("ta_" + suffix)
             self.body(par, name="TA%d" % par)

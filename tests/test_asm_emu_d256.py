@@ -18,8 +18,8 @@ CASES = [
     # Nq, Nkv, q block, causal, bf16, amp
     (128, 64, 0, False, False, 1.0),          # one tile: H1, H2b, TC
     (128, 128, 0, False, True, 1.0),
-    (128, 192, 0, False, False, 1.0),         # first TA body
-    (128, 640, 0, False, False, 1.0),
+    (128, 192, 0, False, False, 1.0),         # first TA body (guarded staging)
+    (128, 640, 0, False, False, 1.0),         # TF bodies: staging piece by piece between the other streams
     (100, 333, 0, False, False, 1.0),         # ragged Nq (rows >= Nq are neither loaded nor stored) and Nkv (masked last tile)
     (128, 77, 0, True, False, 1.0),
     (256, 256, 1, True, False, 1.0),          # causal: waves 0 / 1 finish a tile ahead of 2 / 3 (stage-only bodies)

@@ -57,7 +57,8 @@ def make(shape_bhnd, dtype, layout, rng, gen, dist):
 
 
 def one_case(i, rng, gen, want_bwd, force=None):
-    """force: None (draw everything) | 'wide' (a grid of more 256-row workgroups than CUs) | 'longcausal' (persistent causal pair units)."""
+    """force: None (draw everything) | 'wide' (a grid of more 256-row workgroups than CUs) | 'longcausal' (persistent causal pair units) | 'd256' (head dims 136 .. 256 on the
+    32-rows-per-wave kernel)."""
     dtype = rng.choice([torch.float16, torch.bfloat16])
     dmax = 512
     D = rng.choice([8, 16, 24, 32, 40, 48, 64, 72, 80, 96, 104, 112, 120, 128, 128, 128, 136, 144, 160, 176, 192, 208, 224, 232, 256, 320, 328, 384, 448, 512])
@@ -97,6 +98,16 @@ def one_case(i, rng, gen, want_bwd, force=None):
             B = rng.choice([b for b in (1, 2) if heads % b == 0])
             H = heads // B
         causal = True
+    elif force == "d256" or (force is None and rng.random() < 0.08):
+        # head dims 136 .. 256 over sweeps long enough for the hand-scheduled 32-rows-per-wave kernel (csrc/gen/fwd_m16_d256_gen.py: >= 512 keys, causal
+        # 1024) and its unguarded main-loop bodies
+        D = rng.choice([136, 144, 152, 160, 176, 192, 200, 224, 240, 248, 256, 256, 256])
+        Nq = rng.choice([128, 256, 640, 1024]) - rng.choice([0, 0, 5, 77]) if rng.random() < 0.5 else rng.randint(1, 1500)
+        Nkv = Nq if rng.random() < 0.4 and Nq >= 512 else rng.randint(512, 2600)
+        B, H = rng.randint(1, 2), rng.randint(1, 3)
+        causal = rng.random() < 0.3
+        if causal:
+            Nq = Nkv = max(Nq, Nkv, 1024)
     dist = rng.choice(["rand", "randn"])
     scale = D ** -0.5
     r = rng.random()
@@ -204,6 +215,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--bwd-every", type=int, default=3, help="every n-th case also runs the backward (0 = never)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--force", default=None, choices=["wide", "longcausal", "d256"], help="every case of one family (one_case)")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     gen = torch.Generator(device="cuda").manual_seed(args.seed)
@@ -211,7 +223,7 @@ def main():
     for i in range(args.cases):
         want_bwd = args.bwd_every > 0 and i % args.bwd_every == 0
         try:
-            d = one_case(i, rng, gen, want_bwd)
+            d = one_case(i, rng, gen, want_bwd, force=args.force)
         except Exception as e:                      # a refused shape or a launch error is a finding too
             d = dict(i=i, fails=["exception: %r" % (e,)])
         n_bwd += int(want_bwd)

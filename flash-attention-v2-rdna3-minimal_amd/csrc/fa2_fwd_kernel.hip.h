@@ -250,8 +250,14 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // BIAS = 2 (round 3): the bias tile of a step goes global -> LDS by LDS-DMA, swizzled like a K tile, into a wave-private image and is decoded
 // group by group straight into the score registers — no 32 raw registers, so the 8-wave, 256-row shape (two waves per SIMD, 256 registers)
 // carries a dense per-row bias too.  Geometry: the "tile" form's (pointer, strides and Nkv multiples of 16 bytes), head dims <= 128.
+#ifndef FA2_OCC64
+#define FA2_OCC64 2
+#endif
+#ifndef FA2_OCC128
+#define FA2_OCC128 2
+#endif
 template <int HD, int NW, int QB, int BIAS>
-constexpr int fwd_min_waves_per_simd() { return (NW == 4 && !BIAS && QB == 1 && HD <= 128) ? 2 : (NW + 3) / 4; }
+constexpr int fwd_min_waves_per_simd() { return (NW == 4 && !BIAS && QB == 1 && HD <= 128) ? (HD <= 64 ? FA2_OCC64 : FA2_OCC128) : (NW + 3) / 4; }
 
 //
 // KSQ / DTN / RTD (round 3, "trimmed" instantiations, fwd_hip.cpp): a head dim D below the kernel's HD keeps the LDS images and

@@ -26,6 +26,7 @@ struct Options {
     std::atomic<int> epoch{0};         // bumped by every fa2_set_option: callers that cache a plan (the compiled front end) key it on this
     std::atomic<int> fold{1};          // FA2_FOLD: 0 = the hand-scheduled forward bodies scale the f32 product, 1 = fp16 launches fold the scale into Q, 2 = bf16 too
                                        // (never for calls flagged FA2_FLAG_EXACT_SCALE: the forward of a call that will be differentiated)
+    std::atomic<int> short_kv{1};      // FA2_SHORT: 1 = non-causal sweeps of at most two KV tiles (cross-attention) run the single-pass kernel (fa2_fwd_short.hip.h)
     std::atomic<int> kfold{0};         // FA2_KFOLD: 1 = the hand-scheduled dK / dV pass folds the scale into its K fragments where `fold` would fold a forward of that
                                        // dtype (round 4's default; off since round 5: profiles/r16_fold_evidence.txt, tests/test_backward_gpu.py large-logit case)
 };
@@ -95,6 +96,9 @@ int set_lds(int bytes) {
 // generic HIP forward (fwd_hip.cpp): rows = 256 (8 waves) or 128 (4 waves) per workgroup; bias: the BIAS kernels (always 128 rows)
 FA2_HIDDEN int launch_fwd_hip_f16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_hip_bf16(int HD, const FwdParams& p, bool causal, int rows, bool bias, hipStream_t stream);
+// KV sweeps of at most two tiles, non-causal, no bias, head dims <= 128 (fa2_fwd_short.hip.h; round 6): 128-row workgroups, one memory round trip
+FA2_HIDDEN int launch_fwd_short_f16(int HD, const FwdParams& p, hipStream_t stream);
+FA2_HIDDEN int launch_fwd_short_bf16(int HD, const FwdParams& p, hipStream_t stream);
 // trimmed instantiations of the same kernels for head dims well below HD (fwd_hip.cpp compiled with -DFA2_TU_TRIM=1); -1 = none for this p.D
 FA2_HIDDEN int launch_fwd_hip_trim_f16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream);
 FA2_HIDDEN int launch_fwd_hip_trim_bf16(int HD, const FwdParams& p, bool causal, int rows, hipStream_t stream);

@@ -3,6 +3,7 @@
 // Reference counterpart: the template dispatch at the end of forward_fp16 / forward_bf16 (kernel_fp16.cu:841-851).
 #include "fa2_launch.h"
 
+#include "fa2_fwd_short.hip.h"
 #include "fa2_gfx950.h"
 
 #ifndef FA2_TU_BF16
@@ -149,6 +150,21 @@ int launch_hd(const fa2::FwdParams& p, bool causal, int rows, bool bias, hipStre
     return causal ? launch_t<HD, true>(p, rows, bias, stream) : launch_t<HD, false>(p, rows, bias, stream);
 }
 
+// KV sweeps of at most two tiles (fa2_fwd_short.hip.h): 128-row workgroups, LDS sized by the tiles there are
+template <int HD>
+int launch_short(const fa2::FwdParams& p0, hipStream_t stream) {
+    fa2::FwdParams p = p0;
+    p.nqblk = (p.Nq + fa2::kShortRows - 1) / fa2::kShortRows;
+    if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
+    p.nsplit = 0;
+    const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
+    if (nt < 1 || nt > 2) return FA2_ERR_BAD_SHAPE;
+    constexpr auto kern = fa2::fwd_short_kernel<HD, kBF16>;
+    if (int rc = fa2::set_lds<kern>(fa2::short_lds_bytes<HD>(2))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(256), fa2::short_lds_bytes<HD>(nt), stream, p);
+    return (int)hipGetLastError();
+}
+
 template <int HD>
 int launch_combine(const fa2::FwdParams& p, hipStream_t stream) {
     const int64_t threads = (int64_t)p.split_items * fa2::kSplitRows * (HD / 8);
@@ -167,6 +183,14 @@ int launch_fwd_combine_bf16(int HD, const FwdParams& p, hipStream_t stream) {
 int launch_fwd_combine_f16(int HD, const FwdParams& p, hipStream_t stream) {
 #endif
     return HD == 64 ? launch_combine<64>(p, stream) : HD == 128 ? launch_combine<128>(p, stream) : FA2_ERR_HEAD_DIM;
+}
+
+#if FA2_TU_BF16
+int launch_fwd_short_bf16(int HD, const FwdParams& p, hipStream_t stream) {
+#else
+int launch_fwd_short_f16(int HD, const FwdParams& p, hipStream_t stream) {
+#endif
+    return HD == 64 ? launch_short<64>(p, stream) : HD == 128 ? launch_short<128>(p, stream) : FA2_ERR_HEAD_DIM;
 }
 
 #if FA2_TU_BF16

@@ -34,6 +34,7 @@ Options& options() {
         if (const char* e = std::getenv("FA2_SPLIT")) o.split = std::atoi(e) != 0;
         if (const char* e = std::getenv("FA2_FOLD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) o.fold = v; }
         if (const char* e = std::getenv("FA2_KFOLD")) o.kfold = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FA2_SHORT")) o.short_kv = std::atoi(e) != 0;
         return true;
     }();
     (void)init;
@@ -151,7 +152,14 @@ bool asm_folds(bool bf16, const fa2::FwdParams& p) {
 }
 
 // What one launch over the heads [p.bh0, p.bh0 + p.nbh) runs: the ONE place that decides it (launch_range executes the plan, fa2_fwd_plan reports it).
-struct RangePlan { int kernel, contract; int rows; bool fold; };
+struct RangePlan { int kernel, contract; int rows; bool fold; bool short_kv = false; };
+
+// Non-causal sweeps of at most two KV tiles without a bias (cross-attention on a text prompt: Nkv = 77) at head dims <= 128: the single-pass kernel
+// (fa2_fwd_short.hip.h; option "short").  Option "rows" pins the streaming kernels (tests, A/B).
+bool short_kv_ok(int HD, const fa2::FwdParams& p, bool causal) {
+    return !causal && HD <= 128 && p.Nkv <= 2 * fa2::kKvTile && p.bias_kind == FA2_BIAS_NONE && forced_rows() == 0 &&
+           fa2::options().short_kv.load(std::memory_order_relaxed) != 0;
+}
 
 // A head dim below the body's that the 16x16x32 bodies take (see plan_range)
 bool asm_trimmed(int HD, bool bf16, const fa2::FwdParams& p, bool fold) {
@@ -190,6 +198,7 @@ bool asm_d256_ok(bool bf16, const fa2::FwdParams& p, bool causal) {
 
 RangePlan plan_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal) {
     if (HD == 256 && asm_d256_ok(bf16, p, causal)) return {FA2_KERNEL_ASM, FA2_CONTRACT_LSUM_P16, 128, false};
+    if (short_kv_ok(HD, p, causal)) return {FA2_KERNEL_HIP_128, 0, 128, false, true};
     const int rows = pick_rows(p, causal);
     // Head dim exactly 128 with a positive scale: the hand-scheduled 4-wave kernel (256-row workgroups).  Head dim 64 has its generated
     // body too (same generator, half the MFMAs per tile for the same softmax work, row sums on the matrix pipe), but a lone wave per SIMD
@@ -223,6 +232,7 @@ int launch_range(int HD, bool bf16, const fa2::FwdParams& p, bool causal, hipStr
     if (r.kernel == FA2_KERNEL_ASM && HD == 256) return fa2::launch_fwd_asm_d256(bf16, p, causal, stream);
     if (r.kernel == FA2_KERNEL_ASM)
         return fa2::launch_fwd_asm(HD, bf16, p, causal, r.fold, stream, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
+    if (r.short_kv) return bf16 ? fa2::launch_fwd_short_bf16(HD, p, stream) : fa2::launch_fwd_short_f16(HD, p, stream);
     return bf16 ? fa2::launch_fwd_hip_bf16(HD, p, causal, r.rows, false, stream) : fa2::launch_fwd_hip_f16(HD, p, causal, r.rows, false, stream);
 }
 
@@ -247,6 +257,7 @@ bool asm_noncausal_ok(int HD, bool bf16, const fa2::FwdParams& p) {
 fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causal) {
     fa2::SplitPlan none;
     if (causal || p.bias_kind != FA2_BIAS_NONE || HD > 128 || !fa2::options().split.load(std::memory_order_relaxed)) return none;
+    if (short_kv_ok(HD, p, causal)) return none;
     const int f = forced_rows();
     if (f == 128 || p.rows_hint == 128) return none;
     const int64_t items = (int64_t)p.nbh * ((p.Nq + kFwdRows - 1) / kFwdRows);
@@ -407,6 +418,7 @@ int fa2_set_option(const char* name, int value) {
     else if (!std::strcmp(name, "fold")) { if (value < 0 || value > 2) return FA2_ERR_BAD_SHAPE; o.fold = value; }
     else if (!std::strcmp(name, "bwd_parts")) { if (value < 1 || value > 3) return FA2_ERR_BAD_SHAPE; o.bwd_parts = value; }
     else if (!std::strcmp(name, "kfold")) o.kfold = value != 0;
+    else if (!std::strcmp(name, "short")) o.short_kv = value != 0;
     else return FA2_ERR_BAD_SHAPE;
     o.epoch.fetch_add(1, std::memory_order_relaxed);
     return FA2_OK;
@@ -423,6 +435,7 @@ int fa2_get_option(const char* name) {
     if (!std::strcmp(name, "epoch")) return o.epoch.load() & 0x3fffffff;
     if (!std::strcmp(name, "bwd_parts")) return o.bwd_parts.load();
     if (!std::strcmp(name, "kfold")) return o.kfold.load();
+    if (!std::strcmp(name, "short")) return o.short_kv.load();
     return FA2_ERR_BAD_SHAPE;
 }
 

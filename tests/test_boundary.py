@@ -262,7 +262,14 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
         assert _meta_plan(2, 16, 4096, 4096, D, dt=dt).kernel == want, (D, dt)
     with _fa2_lib.options(asm=_fa2_lib.load(build_if_missing=False).fa2_get_option(b"asm") & ~64):
         assert _meta_plan(2, 16, 4096, 4096, 96).kernel == K.FA2_KERNEL_HIP_256
-    assert _meta_plan(2, 16, 4096, 77, 128).kernel == K.FA2_KERNEL_HIP_256
+    # (round 6) non-causal sweeps of at most two KV tiles, no bias, head dims <= 128: the single-pass 128-row kernel (csrc/fa2_fwd_short.hip.h), f32 scale;
+    # option "short" = 0 and option "rows" keep the streaming kernels
+    for (nkv, D, dt) in ((77, 128, torch.float16), (77, 64, torch.float16), (128, 40, torch.bfloat16), (1, 80, torch.float16)):
+        p = _meta_plan(2, 16, 4096, nkv, D, dt=dt)
+        assert (p.kernel, p.contract, p.rows, p.nsplit, p.kernel_tail) == (K.FA2_KERNEL_HIP_128, 0, 128, 0, 0), (nkv, D, p.as_dict())
+    assert _meta_plan(2, 16, 4096, 129, 64).kernel != K.FA2_KERNEL_HIP_128 and _meta_plan(2, 16, 4096, 77, 160).kernel != K.FA2_KERNEL_HIP_128
+    with _fa2_lib.options(short=0):
+        assert _meta_plan(2, 16, 4096, 77, 128).kernel == K.FA2_KERNEL_HIP_256
     assert _meta_plan(2, 16, 2048, 2048, 128, kpad=8).kernel == K.FA2_KERNEL_HIP_256
     assert _meta_plan(2, 16, 4096, 4096, 128, scale=-0.1).kernel == K.FA2_KERNEL_HIP_256
     # the fold needs scale * log2(e) <= 1 (the prescaled Q must stay inside fp16's range): a larger scale runs the f32-scale body of the same schedule

@@ -1,0 +1,141 @@
+"""GPU parity tests of the single-pass forward for KV sweeps of at most two tiles (round 6: csrc/fa2_fwd_short.hip.h; option "short") — the
+cross-attention calls of the reference's own use case (Nkv = 77, reference README.md:35-37; precision_test.py:34-35 exercises unaligned shapes):
+through the C-ABI against the C oracle, float64 attention, the streaming kernel of the same call (option "short" = 0), NaN-poisoned memory around
+ragged shapes and strided layouts."""
+import ctypes
+
+import pytest
+import torch
+
+from rocwmma_fattn import _fa2_lib
+from rocwmma_fattn.FlashAttn import FlashAttentionFunction
+from test_parity_gpu import TORCH_DT, _assert_close_to_oracle, _cabi_forward, _dev, _plan
+
+pytestmark = pytest.mark.gpu
+
+LOG2E = 1.4426950408889634
+
+
+def _dense64(q, k, v, scale):
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * scale
+    return torch.matmul(torch.softmax(s, -1), v.double()), torch.logsumexp(s, -1) * LOG2E
+
+
+def _is_short(plan, heads):
+    return (plan.kernel, plan.contract, plan.rows, plan.heads_main, plan.nsplit) == (_fa2_lib.FA2_KERNEL_HIP_128, 0, 128, heads, 0)
+
+
+SHAPES = [
+    # B, H, Nq, Nkv, D
+    (2, 10, 4096, 77, 64),          # SDXL cross-attention, 64 x 64 latent
+    (2, 20, 1024, 77, 64),          # ... 32 x 32
+    (2, 8, 4096, 77, 40),           # SD 1.5 cross-attention (head dim 40: padded columns zero-filled by the loads)
+    (2, 8, 1024, 77, 80),           # ... head dim 80 on the 128 kernel
+    (1, 3, 100, 1, 64),             # one key: softmax of one score
+    (1, 2, 333, 13, 8),
+    (3, 5, 129, 63, 128),
+    (1, 7, 1000, 64, 128),          # exactly one tile
+    (2, 3, 257, 65, 96),            # the second tile holds one key
+    (1, 4, 2050, 127, 64),
+    (1, 9, 511, 128, 128),          # two full tiles
+    (1, 1, 1, 128, 16),             # one query row
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dt", [0, 1])
+def test_short_sweeps_on_the_single_pass_kernel(shape, dt):
+    B, H, Nq, Nkv, D = shape
+    g = torch.Generator(device="cpu").manual_seed(77 + Nq + Nkv + D + dt)
+    q = torch.randn((B, H, Nq, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    k = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    v = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+    plan = _plan(q, k, False)
+    assert _is_short(plan, B * H), plan.as_dict()
+    o, lse = _cabi_forward(q, k, v, False)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    o2, lse2 = _cabi_forward(q, k, v, False)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    # float64 attention
+    o_ref, lse_ref = _dense64(q, k, v, D ** -0.5)
+    tol = 1e-3 if dt == 0 else 8e-3
+    assert float((o.double() - o_ref).abs().max()) <= tol * max(1.0, float(o_ref.abs().max()))
+    assert float((lse.double() - lse_ref).abs().max()) <= 1e-3
+    # the streaming kernel of the same call: same contract (f32 scale, f32 row sums), same answer to rounding
+    with _fa2_lib.options(short=0):
+        o_st, lse_st = _cabi_forward(q, k, v, False)
+    ulp = 2.0 ** -10 if dt == 0 else 2.0 ** -7
+    assert float((o.float() - o_st.float()).abs().max()) <= 2 * ulp * max(1.0, float(o_st.float().abs().max()))
+    assert float((lse - lse_st).abs().max()) <= 2e-5 * max(1.0, float(lse_st.abs().max()))
+    # the C oracle on the first and the last head
+    for (b, h) in ((0, 0), (B - 1, H - 1)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        _assert_close_to_oracle(o[sl], lse[sl], q[sl], k[sl], v[sl], dt, False, plan=plan, head=b * H + h)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_short_sweeps_strided_layouts_and_memory_past_the_tails(dt):
+    """Column slices of NaN-filled allocations (row pitch D + 24, rows past Nq / Nkv hold NaNs), a BNHD view through the operator, and O written into a
+    NaN-filled allocation: nothing outside the call's rows and columns may enter a result or be written."""
+    B, H, Nq, Nkv, D = 2, 5, 300, 77, 40
+    g = torch.Generator(device="cpu").manual_seed(5 + dt)
+    T = TORCH_DT[dt]
+    big = {n: torch.full((B, H, (Nq if n == "q" else Nkv) + 5, D + 24), float("nan"), dtype=T, device=_dev()) for n in "qkv"}
+    for n in "qkv":
+        rows = Nq if n == "q" else Nkv
+        big[n][:, :, :rows, :D] = torch.randn((B, H, rows, D), generator=g).to(T).to(_dev())
+    q, k, v = big["q"][:, :, :Nq, :D], big["k"][:, :, :Nkv, :D], big["v"][:, :, :Nkv, :D]
+    assert _is_short(_plan(q, k, False), B * H)
+    obig = torch.full((B, H, Nq + 5, D + 24), float("nan"), dtype=T, device=_dev())
+    o = obig[:, :, :Nq, :D]
+    lse = torch.full((B, H, Nq + 3), float("nan"), dtype=torch.float32, device=_dev())
+    lib = _fa2_lib.load(build_if_missing=False)
+    s3 = lambda t: _fa2_lib.strides3(t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    _fa2_lib.check(lib.fa2_fwd(dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nkv, D, s3(q), s3(k), s3(v), s3(o),
+                               _fa2_lib.strides2(lse.stride(0), lse.stride(1)), float(D ** -0.5), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse[:, :, :Nq]).all()
+    assert torch.isnan(obig[:, :, Nq:]).all() and torch.isnan(obig[:, :, :, D:]).all() and torch.isnan(lse[:, :, Nq:]).all()
+    o_ref, lse_ref = _dense64(q, k, v, D ** -0.5)
+    assert float((o.double() - o_ref).abs().max()) <= (1e-3 if dt == 0 else 8e-3)
+    assert float((lse[:, :, :Nq].double() - lse_ref).abs().max()) <= 1e-3
+    # BNHD through the operator (the reference's permute_NH flag, FlashAttn.py:47-76), a negative and a large scale
+    qb, kb, vb = (t.transpose(1, 2).contiguous() for t in (q, k, v))                     # [B, N, H, D]
+    for scale in (None, -0.3, 1.7):
+        ob = FlashAttentionFunction.apply(qb, kb, vb, None, False, scale, True)
+        torch.cuda.synchronize()
+        ref, _ = _dense64(q, k, v, D ** -0.5 if scale is None else scale)
+        assert float((ob.transpose(1, 2).double() - ref).abs().max()) <= (2e-3 if dt == 0 else 1.6e-2), scale
+
+
+def test_short_sweeps_large_logits_and_the_switches():
+    """N(0, 8^2) logits (the exact row max is taken before anything is exponentiated: there is no reference to outgrow); option "rows" pins the
+    streaming kernels, option "short" = 0 hands the call back to them, and a key-padding mask (the bias kernels) agrees with the single-pass kernel
+    when it masks nothing."""
+    B, H, Nq, Nkv, D = 1, 6, 700, 100, 64
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for dt in (0, 1):
+        q = (8.0 ** 0.5 * torch.randn((B, H, Nq, D), generator=g)).to(TORCH_DT[dt]).to(_dev())
+        k = (8.0 ** 0.5 * torch.randn((B, H, Nkv, D), generator=g)).to(TORCH_DT[dt]).to(_dev())
+        v = torch.randn((B, H, Nkv, D), generator=g).to(TORCH_DT[dt]).to(_dev())
+        plan = _plan(q, k, False)
+        assert _is_short(plan, B * H)
+        o, lse = _cabi_forward(q, k, v, False)
+        _assert_close_to_oracle(o[:, 2:3], lse[:, 2:3], q[:, 2:3], k[:, 2:3], v[:, 2:3], dt, False, plan=plan, head=2)
+        o_ref, lse_ref = _dense64(q, k, v, D ** -0.5)
+        assert float((o.double() - o_ref).abs().max()) <= (2e-3 if dt == 0 else 1.6e-2)
+        assert float((lse.double() - lse_ref).abs().max()) <= 2e-3
+    q = torch.randn((2, 16, 4096, 64), device=_dev()).half()
+    k = torch.randn((2, 16, 77, 64), device=_dev()).half()
+    v = torch.randn_like(k)
+    assert _is_short(_plan(q, k, False), 32)
+    with _fa2_lib.options(short=0):
+        assert _plan(q, k, False).rows == 256          # (512 workgroups of 256 rows: the 8-wave streaming kernel)
+    with _fa2_lib.options(rows=256):
+        assert _plan(q, k, False).rows == 256
+    from rocwmma_fattn.FlashAttn import flash_attention
+    m = torch.ones((2, 1, 1, 77), dtype=torch.bool, device=_dev())
+    o_m = flash_attention(q, k, v, mask=m)
+    o_s = FlashAttentionFunction.apply(q, k, v, None, False)
+    torch.cuda.synchronize()
+    assert float((o_m.float() - o_s.float()).abs().max()) <= 2e-3

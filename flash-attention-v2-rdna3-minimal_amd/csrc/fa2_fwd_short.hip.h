@@ -6,7 +6,7 @@
 // (fa2_fwd_kernel.hip.h) run it as a two-step software pipeline with five barriers and two dependent memory waits per workgroup and keep ~200 registers
 // for the steady state they never reach, so two workgroups share a CU and 640 of them take two rounds of latency chains (11 us; torch SDPA 10.9).
 // Here: ONE memory round trip and two barriers.  A workgroup (4 waves x 32 rows) issues the Q fragment loads and the LDS-DMA of EVERY K and V tile up
-// front, waits once, forms all scores (two 32 x 64 tiles per wave at most), takes the exact row max, exponentiates, multiplies by V and stores — no
+// front, waits once, forms all scores (four blocks of 32 keys per wave at most), takes the exact row max, exponentiates, multiplies by V and stores — no
 // running state, no rescale.  f32 scale, f32 row sums (contract 0, like every compiler-scheduled kernel).  LDS: the K tiles, the V tiles, and the
 // wave-private O images of the epilogue over the K tiles (free once every wave has its scores); registers for three (head dims <= 64) or two
 // workgroups per CU.
@@ -28,10 +28,16 @@ __host__ __device__ constexpr int short_vbase(int ntiles) {
 template <int HD>
 __host__ __device__ constexpr int short_lds_bytes(int ntiles) { return short_vbase<HD>(ntiles) + ntiles * Geo<HD, 4>::TILEB; }
 
-template <int HD, bool BF16>
+// NB = ceil(Nkv / 32): the 32-key blocks that hold a key (1 .. 4).  Blocks, k-steps of P.V (16 keys) and LDS-DMA pieces (32 tile rows) without one
+// are not in the instruction stream: a wave of this kernel is issue-bound (2.5 waves per SIMD at SDXL's 64 x 64 cross-attention: ~1 250 instructions
+// each at NB = 4), not latency-bound — Nkv = 77 runs 12 + 10 MFMAs and 48 exps per lane instead of 16 + 16 and 64.
+template <int HD, bool BF16, int NB>
 __global__ __launch_bounds__(256, (HD <= 64 ? 3 : 2)) void fwd_short_kernel(const FwdParams p) {
     using G_ = Geo<HD, 4>;
     constexpr int ROWB = G_::ROWB, TILEB = G_::TILEB, NPASS = G_::NPASS, KS_QK = HD / 16, DT = HD / 32;
+    constexpr int NT = (NB + 1) / 2;                       // KV tiles staged
+    constexpr int RPP = 256 / G_::G;                       // tile rows one staging pass of the workgroup covers (32 at head dim 64, 16 at 128)
+    constexpr int VBASE = short_vbase<HD>(NT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -40,8 +46,6 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 3 : 2)) void fwd_short_kernel(cons
     block_to_head_qblock<false>(p, (int)blockIdx.x, bh, qblk);
     const int b = bh / p.H, h = bh % p.H;
     const int qw0 = qblk * kShortRows + wave * 32, qrow = qw0 + l31;
-    const int nt = __builtin_amdgcn_readfirstlane((p.Nkv + kKvTile - 1) / kKvTile);      // 1 or 2
-    const int vbase = short_vbase<HD>(nt);
 
     // ---- Q fragments (B operand), straight from memory: lane reads 8 consecutive d of its row per k-step; columns >= D are zeros
     u32x4 qf[KS_QK];
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 3 : 2)) void fwd_short_kernel(cons
         for (int ks = 0; ks < KS_QK; ++ks) qf[ks] = (16 * ks + 8 * hi < p.D) ? *(const u32x4*)(qp + 16 * ks + 8 * hi) : (u32x4){0u, 0u, 0u, 0u};
     }
 
-    // ---- every K and V tile by LDS-DMA, now (the images of fa2_fwd_kernel.hip.h: lane l supplies the source of image slot wave * 64 + 256 i + l)
+    // ---- every K and V tile by LDS-DMA, now (the images of fa2_fwd_kernel.hip.h: lane l supplies the source of image slot wave * 64 + 256 i + l);
+    // rows >= Nkv are outside the descriptors and arrive as zeros
     {
         const uint32_t k_rowb = (uint32_t)p.ks[2] * 2u, v_rowb = (uint32_t)p.vs[2] * 2u;
         const uint16_t* kbase = (const uint16_t*)p.k + b * p.ks[0] + h * p.ks[1];
@@ -68,11 +73,12 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 3 : 2)) void fwd_short_kernel(cons
             const uint32_t kd = gk * 8 < p.D ? row * k_rowb + gk * 16 : kOobOffset;
             const uint32_t vd = gv * 8 < p.D ? row * v_rowb + gv * 16 : kOobOffset;
             char* kdst = smem + (wave * 64 + 256 * i) * 16;
-            dma16_to_lds(krs, kdst, kd, 0u);
-            dma16_to_lds(vrs, kdst + vbase, vd, 0u);
-            if (nt > 1) {
-                dma16_to_lds(krs, kdst + TILEB, kd, (uint32_t)kKvTile * k_rowb);
-                dma16_to_lds(vrs, kdst + vbase + TILEB, vd, (uint32_t)kKvTile * v_rowb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (64 * t + RPP * i < 32 * NB) {        // (compile time) the pass holds rows of a block that has a key
+                    dma16_to_lds(krs, kdst + t * TILEB, kd, (uint32_t)(t * kKvTile) * k_rowb);
+                    dma16_to_lds(vrs, kdst + VBASE + t * TILEB, vd, (uint32_t)(t * kKvTile) * v_rowb);
+                }
             }
         }
     }
@@ -83,93 +89,80 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 3 : 2)) void fwd_short_kernel(cons
     }
     __syncthreads();
 
-    // ---- S^T = K Q^T, both tiles (the second one only if there is one)
-    f32x16 s[2][2];
+    // ---- S^T = K Q^T: block j = keys [32 j, 32 j + 32) = half j & 1 of tile j >> 1
+    f32x16 s[NB];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < NB; ++j) {
+        const char* kt = smem + (j >> 1) * TILEB + (j & 1) * 32 * ROWB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[t][0][r] = 0.f; s[t][1][r] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (t < nt) {
-            const char* kt = smem + t * TILEB;
-#pragma unroll
-            for (int ks = 0; ks < KS_QK; ++ks) {
-                const int ko = G_::k_off(l31, 2 * ks + hi);
-                const u32x4 a0 = *(const u32x4*)(kt + ko);
-                const u32x4 a1 = *(const u32x4*)(kt + ko + 32 * ROWB);
-                s[t][0] = mfma16<BF16>(a0, qf[ks], s[t][0]);
-                s[t][1] = mfma16<BF16>(a1, qf[ks], s[t][1]);
+        for (int ks = 0; ks < KS_QK; ++ks) {
+            const u32x4 a = *(const u32x4*)(kt + G_::k_off(l31, 2 * ks + hi));
+            if (ks == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                s[j] = mfma16<BF16>(a, qf[ks], z);
+            } else {
+                s[j] = mfma16<BF16>(a, qf[ks], s[j]);
             }
         }
     }
-    // ---- mask the keys past Nkv (the images hold zeros there: a score of 0, not of "nothing"), exact row max, P, row sum
+    // ---- the last block's keys past Nkv (the image holds zeros there: a score of 0, not of "nothing"), exact row max, P, row sum
     const float c = p.c;
     {
-        const int lim = p.Nkv - 1 - 4 * hi;
+        const int lim = p.Nkv - 1 - 32 * (NB - 1) - 4 * hi;            // element r of the last block is key 32 (NB - 1) + 4 hi + (r & 3) + 8 (r >> 2)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvi = 64 * t + (r & 3) + 8 * (r >> 2);
-                if (kvi > lim) s[t][0][r] = -INFINITY;
-                if (kvi + 32 > lim) s[t][1][r] = -INFINITY;
-            }
+        for (int r = 0; r < 16; ++r)
+            if ((r & 3) + 8 * (r >> 2) > lim) s[NB - 1][r] = -INFINITY;
     }
-    float m = max3(s[0][0][0], s[0][1][0], s[1][0][0]);
-    m = __builtin_fmaxf(m, s[1][1][0]);
+    float m = s[0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) {
-        m = max3(m, s[0][0][r], s[0][1][r]);
-        m = max3(m, s[1][0][r], s[1][1][r]);
+    for (int j = 0; j < NB; ++j) {
+        int r = j == 0 ? 1 : 0;
+#pragma unroll
+        for (; r + 1 < 16; r += 2) m = max3(m, s[j][r], s[j][r + 1]);
+        if (r < 16) m = __builtin_fmaxf(m, s[j][r]);
     }
     m = half_swap_max(m);
     const float mc = m * c;
     float l = 0.f;
-    u32x4 pf[2][4];
+    u32x4 pf[NB][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        f32x16& s0 = s[t][0];
-        f32x16& s1 = s[t][1];
-        float rs0 = 0.f, rs1 = 0.f;
+    for (int j = 0; j < NB; ++j) {
+        float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
-            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
-            rs0 += s0[r];
-            rs1 += s1[r];
+            s[j][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], c, -mc));
+            rs += s[j][r];
         }
-        l += rs0 + rs1;
+        l += rs;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pf[t][0][i] = pack2<BF16>(s0[2 * i], s0[2 * i + 1]);
-            pf[t][1][i] = pack2<BF16>(s0[8 + 2 * i], s0[8 + 2 * i + 1]);
-            pf[t][2][i] = pack2<BF16>(s1[2 * i], s1[2 * i + 1]);
-            pf[t][3][i] = pack2<BF16>(s1[8 + 2 * i], s1[8 + 2 * i + 1]);
+            pf[j][0][i] = pack2<BF16>(s[j][2 * i], s[j][2 * i + 1]);
+            pf[j][1][i] = pack2<BF16>(s[j][8 + 2 * i], s[j][8 + 2 * i + 1]);
         }
     }
-    // ---- O^T = V^T P^T
+    // ---- O^T = V^T P^T: k-step x = keys [16 x, 16 x + 16); the last block's second k-step only if it holds a key (wave-uniform)
     f32x16 acc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     {
         const int pp = lane & 15, g1 = (lane >> 4) & 1;
+        const bool last_too = p.Nkv > 32 * (NB - 1) + 16;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t < nt) {
-                const char* vt = smem + vbase + t * TILEB;
+        for (int x = 0; x < 2 * NB; ++x) {
+            if (x < 2 * NB - 1 || last_too) {
+                const char* vt = smem + VBASE + (x >> 2) * TILEB + 16 * (x & 3) * ROWB;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const char* va = vt + G_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2) + 16 * ks * ROWB;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
-                        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
-                        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
-                        acc[dt] = mfma16<BF16>((u32x4){lo2[0], lo2[1], hi2[0], hi2[1]}, pf[t][ks], acc[dt]);
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* va = vt + G_::v_off(4 * hi + (pp >> 2), (32 * dt + 16 * g1 + 4 * (pp & 3)) * 2);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * ROWB));
+                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi4);
+                    const u32x4 a = {lo2[0], lo2[1], hi2[0], hi2[1]};
+                    if (x == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[dt] = mfma16<BF16>(a, pf[0][0], z);
+                    } else {
+                        acc[dt] = mfma16<BF16>(a, pf[x >> 1][x & 1], acc[dt]);
                     }
+                }
             }
         }
     }

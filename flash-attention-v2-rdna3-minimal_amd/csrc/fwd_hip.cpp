@@ -150,19 +150,29 @@ int launch_hd(const fa2::FwdParams& p, bool causal, int rows, bool bias, hipStre
     return causal ? launch_t<HD, true>(p, rows, bias, stream) : launch_t<HD, false>(p, rows, bias, stream);
 }
 
-// KV sweeps of at most two tiles (fa2_fwd_short.hip.h): 128-row workgroups, LDS sized by the tiles there are
+// KV sweeps of at most two tiles (fa2_fwd_short.hip.h): 128-row workgroups; one instantiation per count of 32-key blocks that hold a key
+template <int HD, int NB>
+int launch_short_nb(const fa2::FwdParams& p, hipStream_t stream) {
+    constexpr auto kern = fa2::fwd_short_kernel<HD, kBF16, NB>;
+    constexpr int lds = fa2::short_lds_bytes<HD>((NB + 1) / 2);
+    if (int rc = fa2::set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(256), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <int HD>
 int launch_short(const fa2::FwdParams& p0, hipStream_t stream) {
     fa2::FwdParams p = p0;
     p.nqblk = (p.Nq + fa2::kShortRows - 1) / fa2::kShortRows;
     if ((int64_t)p.nbh * p.nqblk > 0x7fffffffLL) return FA2_ERR_GRID;
     p.nsplit = 0;
-    const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
-    if (nt < 1 || nt > 2) return FA2_ERR_BAD_SHAPE;
-    constexpr auto kern = fa2::fwd_short_kernel<HD, kBF16>;
-    if (int rc = fa2::set_lds<kern>(fa2::short_lds_bytes<HD>(2))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.nbh * p.nqblk)), dim3(256), fa2::short_lds_bytes<HD>(nt), stream, p);
-    return (int)hipGetLastError();
+    switch ((p.Nkv + 31) / 32) {
+        case 1: return launch_short_nb<HD, 1>(p, stream);
+        case 2: return launch_short_nb<HD, 2>(p, stream);
+        case 3: return launch_short_nb<HD, 3>(p, stream);
+        case 4: return launch_short_nb<HD, 4>(p, stream);
+        default: return FA2_ERR_BAD_SHAPE;
+    }
 }
 
 template <int HD>

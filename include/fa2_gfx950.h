@@ -347,6 +347,10 @@ int fa2_fwd_prescales_q(int D, float scale);
    "kfold"     FA2_KFOLD      0 (default) | 1 — the hand-scheduled dK / dV pass (head dim 128) recomputes P from K * scale*log2(e) rounded once
                               to the I/O dtype, for the dtypes "fold" covers (round 4's default; -1.8 % backward time, but gradients 2-4x
                               the f32-scale pass's error at logits of +-30: off since round 5)
+ *   "short"     FA2_SHORT      1 (default) | 0 — non-causal calls without a bias whose KV sweep is at most two tiles (Nkv <= 128: cross-attention on a text
+ *                              prompt) at head dims <= 128 run the single-pass kernel (csrc/fa2_fwd_short.hip.h: one memory round trip, exact row
+ *                              max, f32 scale, f32 row sums — contract 0; fa2_fwd_plan: FA2_KERNEL_HIP_128, rows 128).  Option "rows" != 0 keeps the
+ *                              streaming kernels as well.  SDXL cross-attention 11.1 -> 7.4 us (profiles/r22_short_probe.txt)
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

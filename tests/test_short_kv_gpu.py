@@ -39,6 +39,9 @@ SHAPES = [
     (1, 4, 2050, 127, 64),
     (1, 9, 511, 128, 128),          # two full tiles
     (1, 1, 1, 128, 16),             # one query row
+    # every count of 32-key blocks (one instantiation each), with and without a key in the last block's second 16-key step
+    (1, 2, 200, 17, 64), (1, 2, 64, 32, 64), (1, 2, 200, 33, 40), (1, 2, 200, 49, 128), (2, 2, 300, 81, 64), (1, 2, 64, 96, 64), (1, 3, 130, 97, 128),
+    (1, 3, 130, 113, 64),
 ]
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence for ONE forward shape through the operator (developer tool, run from the repo root on the GPU box):
-#   bash tools/prof_shape.sh <tag> B H N D f16|bf16 causal(0|1)
+#   bash tools/prof_shape.sh <tag> B H N D f16|bf16 causal(0|1) [Nkv]
 # kernel trace + separate --pmc passes (never combined with other trace domains); prints per-kernel medians and per-launch counters.
-TAG=$1; B=$2; H=$3; N=$4; D=$5; DT=${6:-f16}; C=${7:-0}
+TAG=$1; B=$2; H=$3; N=$4; D=$5; DT=${6:-f16}; C=${7:-0}; NKV=${8:-$4}
 OUT=gpurun_out/prof_${TAG}
 export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
@@ -11,7 +11,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.join("$PWD", "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction
 dt = torch.float16 if "$DT" == "f16" else torch.bfloat16
-q, k, v = (torch.rand(($B, $H, $N, $D), device="cuda").to(dt) for _ in range(3))
+q = torch.rand(($B, $H, $N, $D), device="cuda").to(dt)
+k, v = (torch.rand(($B, $H, $NKV, $D), device="cuda").to(dt) for _ in range(2))
 for _ in range(int(os.environ.get("CALLS", "60"))):
     FlashAttentionFunction.apply(q, k, v, None, bool($C))
 torch.cuda.synchronize()
@@ -25,7 +26,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCL
   i=$((i+1))
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/p$i -o pmc -- python /tmp/prof_shape.py > $OUT/p$i.log 2>&1
 done
-OUT=$OUT SHAPE="B$B H$H N$N D$D $DT causal=$C" python - <<'P'
+OUT=$OUT SHAPE="B$B H$H N$N x $NKV D$D $DT causal=$C" python - <<'P'
 import csv, glob, os
 from collections import defaultdict
 out = os.environ["OUT"]

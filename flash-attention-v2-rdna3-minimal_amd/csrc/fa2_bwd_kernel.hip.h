@@ -844,12 +844,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_dkv_kernel(const BwdParam
         }
     };
 
+    // A wave whose 32 KV rows all lie past Nkv (cross-attention on a text prompt: 77 keys in a 256-row workgroup — five of eight waves) stages and
+    // syncs, nothing else: its accumulators stay zero (a whole item never stores them, a part stores the zeros).  Round 6: that pass is issue-bound
+    const bool wave_live = kvw0 < p.Nkv;
     if (tile0 < ntiles) stage_load(tile0, 0);
     __syncthreads();
     for (int tile = tile0; tile < ntiles; ++tile) {
         const int st = DBUF ? (tile - tile0) & 1 : 0;
         if (DBUF && tile + 1 < ntiles) stage_load(tile + 1, st ^ 1);
-        if (!CAUSAL || tile >= tile0_w) tile_body(tile, st, CAUSAL && tile < first_plain);
+        if ((!CAUSAL || tile >= tile0_w) && wave_live) tile_body(tile, st, CAUSAL && tile < first_plain);
         __syncthreads();
         if (!DBUF && tile + 1 < ntiles) { stage_load(tile + 1, 0); __syncthreads(); }
     }

@@ -51,7 +51,7 @@ FRONTEND_SRC = "frontend.cpp"                      # optional compiled front end
 FRONTEND_PATH = os.path.join(PKG_DIR, "rocwmma_fattn", "_fa2_frontend.so")
 GENERATORS = [os.path.join("gen", "fwd_d128_gen.py"), os.path.join("gen", "fwd_m16_gen.py"), os.path.join("gen", "fwd_m16_d256_gen.py"), os.path.join("gen", "bwd_d128_gen.py"),
               os.path.join("gen", "bwd_dq_m16_gen.py"), os.path.join("gen", "bwd_dkv_m16_gen.py")]
-HEADERS = ["fa2_launch.h", "fa2_fwd_kernel.hip.h", "fa2_fwd_short.hip.h", "fa2_fwd_d128.hip.h", "fa2_fwd_d256.hip.h", "fa2_bwd_kernel.hip.h", "fa2_bwd_d128.hip.h",
+HEADERS = ["fa2_launch.h", "fa2_fwd_kernel.hip.h", "fa2_fwd_short.hip.h", "fa2_fwd_d128.hip.h", "fa2_fwd_d256.hip.h", "fa2_bwd_kernel.hip.h", "fa2_bwd_short.hip.h", "fa2_bwd_d128.hip.h",
            os.path.join(INCLUDE, "fa2_gfx950.h"), os.path.join("gen", "isa.py"), os.path.join("gen", "sched.py")] + GENERATORS
 
 HIPCC_FLAGS = [

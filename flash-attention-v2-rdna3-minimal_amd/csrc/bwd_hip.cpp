@@ -3,6 +3,7 @@
 // (kernel_fp16.cu:878-1028).
 #include "fa2_launch.h"
 
+#include "fa2_bwd_short.hip.h"
 #include "fa2_gfx950.h"
 
 #ifndef FA2_TU_BF16
@@ -248,6 +249,31 @@ int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, 
 
 #else   // !FA2_TU_TRIM
 
+// dQ pass of KV sweeps of at most two tiles (fa2_bwd_short.hip.h): 128-row workgroups; one instantiation per count of 32-key blocks that hold a key
+template <int HD, int NB>
+int launch_short_dq_nb(const fa2::BwdParams& p, bool neg_delta, hipStream_t stream) {
+    constexpr auto kern = fa2::bwd_short_dq_kernel<HD, kBF16, NB>;
+    constexpr int lds = fa2::bwd_short_lds_bytes<HD>(NB);
+    if (int rc = fa2::set_lds<kern>(lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * p.nblk)), dim3(256), lds, stream, p, (int)neg_delta);
+    return (int)hipGetLastError();
+}
+
+template <int HD>
+int launch_short_dq(const fa2::BwdParams& p0, bool neg_delta, hipStream_t stream) {
+    fa2::BwdParams p = p0;
+    p.nblk = (p.Nq + fa2::kBwdShortRows - 1) / fa2::kBwdShortRows;
+    if ((int64_t)p.B * p.H * p.nblk > 0x7fffffffLL) return FA2_ERR_GRID;
+    p.nsplit = 0;
+    switch ((p.Nkv + 31) / 32) {
+        case 1: return launch_short_dq_nb<HD, 1>(p, neg_delta, stream);
+        case 2: return launch_short_dq_nb<HD, 2>(p, neg_delta, stream);
+        case 3: return launch_short_dq_nb<HD, 3>(p, neg_delta, stream);
+        case 4: return launch_short_dq_nb<HD, 4>(p, neg_delta, stream);
+        default: return FA2_ERR_BAD_SHAPE;
+    }
+}
+
 template <int HD>
 int launch_bwd(const fa2::BwdParams& p, bool causal, int parts, hipStream_t stream) {
     return causal ? launch_bwd_t<HD, true>(p, parts, stream) : launch_bwd_t<HD, false>(p, parts, stream);
@@ -277,6 +303,14 @@ int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipSt
         case 512: return causal ? launch_bwd_512<true>(p, parts, stream) : launch_bwd_512<false>(p, parts, stream);
         default: return FA2_ERR_HEAD_DIM;
     }
+}
+
+#if FA2_TU_BF16
+int launch_bwd_short_dq_bf16(int HD, const BwdParams& p, bool neg_delta, hipStream_t stream) {
+#else
+int launch_bwd_short_dq_f16(int HD, const BwdParams& p, bool neg_delta, hipStream_t stream) {
+#endif
+    return HD == 64 ? launch_short_dq<64>(p, neg_delta, stream) : HD == 128 ? launch_short_dq<128>(p, neg_delta, stream) : FA2_ERR_HEAD_DIM;
 }
 
 #if FA2_TU_BF16

@@ -157,6 +157,9 @@ inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan
 // HIP backward (bwd_hip.cpp): parts bit 0 = dQ pass (+ delta workspace), bit 1 = dK / dV pass(es)
 FA2_HIDDEN int launch_bwd_hip_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
+// dQ pass (+ delta, or -delta for the hand-scheduled dK / dV pass) of KV sweeps of at most two tiles, non-causal, no bias, head dims <= 128 (fa2_bwd_short.hip.h; round 6)
+FA2_HIDDEN int launch_bwd_short_dq_f16(int HD, const BwdParams& p, bool neg_delta, hipStream_t stream);
+FA2_HIDDEN int launch_bwd_short_dq_bf16(int HD, const BwdParams& p, bool neg_delta, hipStream_t stream);
 // trimmed instantiations of the same passes for head dims well below HD (bwd_hip.cpp compiled with -DFA2_TU_TRIM=1); -1 = none for this p.D
 FA2_HIDDEN int launch_bwd_hip_trim_f16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);
 FA2_HIDDEN int launch_bwd_hip_trim_bf16(int HD, const BwdParams& p, bool causal, int parts, hipStream_t stream);

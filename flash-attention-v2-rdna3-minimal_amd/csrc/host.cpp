@@ -365,10 +365,16 @@ int launch_bwd(int HD, bool bf16, const fa2::BwdParams& p, bool causal, hipStrea
     // backward passes: P is recomputed from the very scores L was formed from.  With the fold, gradients at logits of +-30 and more were 2-4x the
     // suite's tolerance (tests/test_backward_gpu.py::test_hand_scheduled_backward_on_large_logits_under_both_fold_settings).
     const bool kfold = fa2::options().kfold.load(std::memory_order_relaxed) && (bf16 ? fopt >= 2 : fopt >= 1) && std::fabs(p.c) <= 1.0f;
+    // (head dim 128 exactly keeps the hand-scheduled dQ pass where that one is available: B8 H16 N4096 x 77, whole backward, 236 us against 246)
+    const bool short_dq = !causal && (HD <= 64 || (HD == 128 && !(asm_parts & 1))) && p.Nkv <= 2 * fa2::kKvTile && p.bias_kind == FA2_BIAS_NONE &&
+                          forced_rows() == 0 && fa2::options().short_kv.load(std::memory_order_relaxed) != 0;
     for (int part = 1; part <= 2; part <<= 1) {       // the dQ pass first: it fills the delta workspace the dK / dV pass reads
         if (!(want & part)) continue;
         int rc;
-        if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, kfold, stream, (m & 128) != 0, (m & 256) != 0);     // option "asm" bits 7 / 8: the 16x16x32 dQ / dK-dV pass
+        // (round 6) the dQ pass of a non-causal sweep of at most two KV tiles — cross-attention — is the short-sweep kernel's (fa2_bwd_short.hip.h;
+        //  option "short"; option "rows" pins the streaming passes); it leaves delta in the sign the dK / dV pass that follows takes
+        if (part == 1 && short_dq) rc = bf16 ? fa2::launch_bwd_short_dq_bf16(HD, p, neg_delta, stream) : fa2::launch_bwd_short_dq_f16(HD, p, neg_delta, stream);
+        else if (asm_parts & part) rc = fa2::launch_bwd_d128(bf16, p, causal, part, neg_delta, kfold, stream, (m & 128) != 0, (m & 256) != 0);     // option "asm" bits 7 / 8: the 16x16x32 dQ / dK-dV pass
         else rc = bf16 ? fa2::launch_bwd_hip_bf16(HD, p, causal, part, stream) : fa2::launch_bwd_hip_f16(HD, p, causal, part, stream);
         if (rc) return rc;
     }

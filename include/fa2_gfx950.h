@@ -350,7 +350,8 @@ int fa2_fwd_prescales_q(int D, float scale);
  *   "short"     FA2_SHORT      1 (default) | 0 — non-causal calls without a bias whose KV sweep is at most two tiles (Nkv <= 128: cross-attention on a text
  *                              prompt) at head dims <= 128 run the single-pass kernel (csrc/fa2_fwd_short.hip.h: one memory round trip, exact row
  *                              max, f32 scale, f32 row sums — contract 0; fa2_fwd_plan: FA2_KERNEL_HIP_128, rows 128).  Option "rows" != 0 keeps the
- *                              streaming kernels as well.  SDXL cross-attention 11.1 -> 7.4 us (profiles/r22_short_probe.txt)
+ *                              streaming kernels as well.  SDXL cross-attention 11.1 -> 7.4 us (profiles/r22_short_probe.txt).  fa2_bwd* runs the dQ pass
+ *                              of such calls on the kernel's twin (csrc/fa2_bwd_short.hip.h; head dim 128 exactly keeps the hand-scheduled pass)
  *   "bwd_parts" (no variable)  3 (default) | 1 | 2 — profiling only: fa2_bwd runs just its dQ pass (1) or just its dK / dV pass (2);
  *                              the outputs of the skipped pass are not written (the dK / dV pass needs delta_ws from an earlier full call)
  * These (plus FA2_FRONTEND=py and FA2_GFX950_LIB=<path> of the Python package) are all the switches there are.

@@ -142,3 +142,64 @@ def test_short_sweeps_large_logits_and_the_switches():
     o_s = FlashAttentionFunction.apply(q, k, v, None, False)
     torch.cuda.synchronize()
     assert float((o_m.float() - o_s.float()).abs().max()) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# The dQ pass of the backward on the same class of calls (csrc/fa2_bwd_short.hip.h; host.cpp: launch_bwd): through the C-ABI against the C oracle's
+# backward (fed the kernel's own O / LSE, and the oracle's), float64 autograd, and the streaming passes of the same call (option "short" = 0).
+BWD_SHAPES = [
+    # B, H, Nq, Nkv, D
+    (2, 10, 1024, 77, 64),          # SDXL cross-attention
+    (2, 8, 1024, 77, 40),           # SD 1.5
+    (2, 4, 256, 77, 128),           # head dim 128, Nq % 32 == 0: the hand-scheduled dK / dV pass follows and takes -delta
+    (1, 3, 250, 77, 128),           # ... Nq % 32 != 0: the compiler-scheduled dK / dV pass, +delta
+    (1, 2, 100, 1, 64), (1, 2, 333, 17, 8), (1, 2, 129, 33, 80), (2, 2, 300, 49, 128), (1, 3, 257, 64, 64), (1, 2, 200, 81, 64),
+    (1, 2, 130, 97, 128), (1, 2, 130, 113, 40), (1, 5, 511, 128, 128), (1, 1, 1, 128, 16),
+]
+
+
+def _float64_grads(q, k, v, do, scale):
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.matmul(qd, kd.transpose(-1, -2)) * scale
+    o = torch.matmul(torch.softmax(s, -1), vd)
+    return torch.autograd.grad(o, (qd, kd, vd), do.double())
+
+
+@pytest.mark.parametrize("shape", BWD_SHAPES)
+@pytest.mark.parametrize("dt", [0, 1])
+def test_short_sweeps_backward(shape, dt):
+    from conftest import GRAD_TOL
+    from test_backward_gpu import _cabi_fwd_bwd, _check_vs_oracle
+    B, H, Nq, Nkv, D = shape
+    g = torch.Generator(device="cpu").manual_seed(7 + Nq + 3 * Nkv + D + dt)
+    mk = lambda n: torch.randn((B, H, n, D), generator=g).to(TORCH_DT[dt]).to(_dev())  # noqa: E731
+    q, k, v, do = mk(Nq), mk(Nkv), mk(Nkv), mk(Nq)
+    for scale in (None, -0.2):
+        o, lse, grads = _cabi_fwd_bwd(q, k, v, do, False, scale=scale)
+        o2, lse2, grads2 = _cabi_fwd_bwd(q, k, v, do, False, scale=scale)
+        assert all(torch.equal(a, b) for a, b in zip(grads, grads2))
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, False, scale=scale)
+        _check_vs_oracle(q, k, v, do, o, lse, grads, dt, False, scale=scale, independent=True)
+        truth = _float64_grads(q, k, v, do, D ** -0.5 if scale is None else scale)
+        with _fa2_lib.options(short=0):
+            _, _, grads_st = _cabi_fwd_bwd(q, k, v, do, False, scale=scale)
+        for name, a, b, t in zip("qkv", grads, grads_st, truth):
+            bar = GRAD_TOL[dt] * max(1.0, float(t.abs().max()))
+            assert float((a.double() - t).abs().max()) <= bar, (name, scale)
+            assert float((a.float() - b.float()).abs().max()) <= bar, (name, scale)       # the streaming passes of the same call
+
+
+def test_short_sweeps_backward_through_the_operator_with_strided_tensors():
+    """BNHD tensors (the reference's permute_NH flag) with gradients through the operator; the dQ written into a strided gradient."""
+    B, N, H, D, Nkv = 2, 300, 5, 64, 77
+    g = torch.Generator(device="cpu").manual_seed(12)
+    q = torch.randn((B, N, H, D), generator=g).half().to(_dev()).requires_grad_(True)
+    k = torch.randn((B, Nkv, H, D), generator=g).half().to(_dev()).requires_grad_(True)
+    v = torch.randn((B, Nkv, H, D), generator=g).half().to(_dev()).requires_grad_(True)
+    do = torch.randn((B, N, H, D), generator=g).half().to(_dev())
+    o = FlashAttentionFunction.apply(q, k, v, None, False, None, True)
+    dq, dk, dv = torch.autograd.grad(o, (q, k, v), do)
+    torch.cuda.synchronize()
+    tq, tk, tv = _float64_grads(q.detach().transpose(1, 2), k.detach().transpose(1, 2), v.detach().transpose(1, 2), do.transpose(1, 2), D ** -0.5)
+    for name, a, t in (("q", dq, tq), ("k", dk, tk), ("v", dv, tv)):
+        assert float((a.transpose(1, 2).double() - t).abs().max()) <= 2e-3 * max(1.0, float(t.abs().max())), name

@@ -4,6 +4,7 @@ backward alone (developer probe, round 6).  The floor of moving the bytes (Q, O,
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))), "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction
+from rocwmma_fattn import _fa2_lib
 import torch.nn.functional as F
 dev = torch.device("cuda", 0)
 
@@ -21,7 +22,7 @@ def t(fn, n=50):
     return sorted(ts)[2]
 
 
-for (B, H, N, Nkv, D) in ((2, 10, 4096, 77, 64), (8, 16, 4096, 77, 64), (8, 16, 4096, 77, 128), (16, 8, 4096, 77, 40), (16, 20, 1024, 77, 64)):
+for (B, H, N, Nkv, D) in ((2, 10, 4096, 77, 64), (8, 16, 4096, 77, 64), (8, 16, 4096, 77, 128), (16, 8, 4096, 77, 40), (16, 20, 1024, 77, 64), (8, 16, 4096, 77, 80), (8, 16, 4096, 128, 64)):
     q = torch.randn((B, H, N, D), device=dev).half().requires_grad_(True)
     k = torch.randn((B, H, Nkv, D), device=dev).half().requires_grad_(True)
     v = torch.randn((B, H, Nkv, D), device=dev).half().requires_grad_(True)
@@ -31,5 +32,8 @@ for (B, H, N, Nkv, D) in ((2, 10, 4096, 77, 64), (8, 16, 4096, 77, 64), (8, 16, 
         o = f()
         res[name + " fwd+bwd"] = t(lambda: torch.autograd.grad(f(), (q, k, v), do))
         res[name + " bwd"] = t(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True))
+        if name == "fa2":
+            with _fa2_lib.options(short=0):
+                res["fa2 bwd short=0"] = t(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True))
     mb = 4 * B * H * N * D * 2 / 1e6
     print("B%d H%d N%d x %d D%d: %s   | Q, O, dO, dQ = %.0f MB: %.1f us at 4.5 TB/s" % (B, H, N, Nkv, D, "  ".join("%s %.1f us" % kv for kv in res.items()), mb, mb / 4.5))

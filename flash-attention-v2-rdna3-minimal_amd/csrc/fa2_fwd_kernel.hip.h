@@ -250,6 +250,9 @@ __device__ __forceinline__ void block_to_head_qblock(const FwdParams& p, int bid
 // BIAS = 2 (round 3): the bias tile of a step goes global -> LDS by LDS-DMA, swizzled like a K tile, into a wave-private image and is decoded
 // group by group straight into the score registers — no 32 raw registers, so the 8-wave, 256-row shape (two waves per SIMD, 256 registers)
 // carries a dense per-row bias too.  Geometry: the "tile" form's (pointer, strides and Nkv multiples of 16 bytes), head dims <= 128.
+// (developer A/B, round 6: waves per SIMD the plain 128-row kernels are compiled for.  3 at head dim 64 spills 16-22 registers, 4 spills 300+, 3 at
+//  head dim 128 spills 119-257: the streaming kernel keeps ~200 registers for its steady state — which is why short sweeps got a kernel of their own,
+//  fa2_fwd_short.hip.h)
 #ifndef FA2_OCC64
 #define FA2_OCC64 2
 #endif

@@ -1,3 +1,6 @@
+"""The short-sweep forward kernel (csrc/fa2_fwd_short.hip.h) against the routing it replaced (option "short" = 0), eager operator, over grid sizes, head
+dims, dtypes and sweep lengths 32 .. 128 (developer A/B; profiles/r22_short_ab.txt).
+    python tools/short_ab.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.getcwd(), "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction

@@ -941,6 +941,7 @@ __global__ __launch_bounds__(NW * 64, (fwd_min_waves_per_simd<HD, NW, QB, BIAS>(
             const int row = wave * 32 + l31;
             const float l_tot = half_swap_sum(l_run[0]);
             const float inv_l = 1.0f / l_tot;
+            if (q0 + row >= p.Nq) return;          // (the merge never reads rows past Nq: a decode-sized call, Nq = 1, writes one row per part, not 256)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll

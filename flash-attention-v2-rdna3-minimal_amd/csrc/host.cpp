@@ -264,7 +264,9 @@ fa2::SplitPlan plan_split(const fa2::FwdParams& p, int HD, bool bf16, bool causa
     const int nt = (p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile;
     // whole rounds on the hand-scheduled persistent kernel (head dim 128; head dim 64 in fp16): the parts need a launch of their own
     const bool asm_rounds = asm_noncausal_ok(HD, bf16, p);
-    return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, asm_rounds ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus());
+    // (round 6) ... and EVERY item of a grid that covers at most half of the CUs over a long sweep — a decode-sized call: B1 H32 Nq1 Nkv8192 is 32
+    // workgroups streaming 134 MB of K / V, 147 us for 30 us of bytes (plan_tail_split, underfilled; the parts run on the 8-wave kernel: plan_fwd)
+    return fa2::plan_tail_split(items, nt, 0.9 * HD / 64.0, asm_rounds ? 14.0 : 10.0, fa2::split_ws_bytes(1, 1, HD), fa2::device_cus(), true);
 }
 
 // The whole forward call: at most two launches (+ the merge of a split).  plan_fwd decides, launch_fwd executes, fa2_fwd_plan reports.
@@ -284,7 +286,7 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             fa2::FwdParams p = p0;
             p.rows_hint = 256;
             f.split = pl;
-            f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256;
+            f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256 && pl.full_items > 0;   // (a grid of parts only: the 8-wave kernel)
             const bool fold = f.split_asm && asm_folds(bf16, p);
             const bool lsum16 = f.split_asm && fa2::fwd_asm_lsum16(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
             f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}

@@ -284,6 +284,11 @@ def test_forward_plan_names_the_kernel_and_the_contract_of_every_baseline_config
     p = _meta_plan(2, 10, 4096, 4096, 64, ws=need)
     assert (p.nsplit, p.split_items, p.kernel, p.kernel_tail) == (4, 64, K.FA2_KERNEL_ASM, 0)
     assert _meta_plan(2, 10, 4096, 4096, 64, ws=need - 1).nsplit == 0 and _meta_plan(2, 10, 4096, 4096, 64).nsplit == 0
+    # (round 6) a grid that covers at most half of the CUs over a long sweep — a decode-sized call — splits EVERY item, on the 8-wave kernel
+    need = lib.fa2_fwd_workspace_bytes(_fa2_lib.FA2_DTYPE_F16, 1, 32, 1, 8192, 128, 0)
+    p = _meta_plan(1, 32, 1, 8192, 128, ws=need)
+    assert need > 0 and (p.nsplit, p.split_items, p.kernel, p.rows) == (8, 32, K.FA2_KERNEL_HIP_256, 256), p.as_dict()
+    assert _meta_plan(1, 32, 1, 8192, 128).nsplit == 0 and lib.fa2_fwd_workspace_bytes(_fa2_lib.FA2_DTYPE_F16, 1, 32, 1, 512, 128, 0) == 0
     # a masked call: the BIAS kernels
     q = torch.empty((2, 10, 1024, 64), dtype=torch.float16, device="meta")
     assert _fa2_lib.fwd_plan(q, q, False, bias_kind=_fa2_lib.FA2_BIAS_BOOL).kernel == K.FA2_KERNEL_HIP_BIAS

@@ -101,6 +101,12 @@ SPLIT_SHAPES = [
     (3, 9, 3072, 2048, 96, 0, False),       # D = 96 on the D = 128 body, 324 items
     (3, 9, 3072, 2048, 80, 0, False),       # D = 80: the trimmed HIP kernels (no hand-scheduled body takes it: everything in one launch)
     (1, 40, 2048, 8192, 64, 0, True),       # cross-attention-like: Nkv != Nq, 320 items, BNHD
+    # (round 6) grids that cover at most half of the CUs over a long sweep: EVERY item is split (no whole items at all), the parts run on the 8-wave kernel
+    (1, 32, 1, 8192, 128, 0, False),        # decode-sized: one query row per head, 32 items x 8 parts; a part stores one row, not 256
+    (4, 8, 1, 16384, 64, 1, False),
+    (1, 32, 16, 8200, 128, 1, True),        # a few rows, ragged Nkv, BNHD
+    (1, 8, 4096, 4096, 40, 0, False),       # SD 1.5 64 x 64 at batch 1: 128 items x 2 parts
+    (1, 4, 2048, 2048, 128, 0, False),      # 32 items x 4 parts
 ]
 
 
@@ -135,7 +141,10 @@ def test_split_launches_against_oracle_dense_and_plain_call(shape):
     heads = {(0, 0), (B - 1, H - 1), (B - 1, H - 2), (B // 2, H // 2), (B - 1, max(H - 8, 0))}
     plan = _plan_ws(q, k, bnhd, need)
     assert plan.nsplit > 1 and plan.split_items > 0
-    if D in (64, 128) or (D in (40, 96) and dt == 0):       # whole items and parts inside the hand-scheduled persistent kernel (round 5: also head dims just below a body's)
+    every_item = plan.split_items == B * H * ((N + 255) // 256)     # (round 6) an underfilled grid: parts only, on the 8-wave kernel
+    if every_item:
+        assert plan.kernel == _fa2_lib.FA2_KERNEL_HIP_256 and plan.contract == 0 and plan.rows == 256
+    elif D in (64, 128) or (D in (40, 96) and dt == 0):     # whole items and parts inside the hand-scheduled persistent kernel (round 5: also head dims just below a body's)
         assert plan.kernel == _fa2_lib.FA2_KERNEL_ASM
     else:
         assert plan.kernel == _fa2_lib.FA2_KERNEL_HIP_256 and plan.contract == 0

@@ -142,6 +142,9 @@ inline bool fwd_asm_lsum16(int HD, bool bf16, const FwdParams& p, bool fold, int
 // Plans of the backward's split passes (compiler-scheduled kernels; bwd_hip.cpp): the dQ pass splits its KV sweep (head dims <= 128), the fused
 // dK / dV pass of head dims <= 64 its Q sweep.  Returns the workspace bytes fa2_bwd_ws can use (the passes run one after the other and share it).
 // Tile costs (us per 64-row tile of a 256-row workgroup, 8-wave HIP kernels): dQ pass 3 GEMMs, fused dK / dV pass 4 — 1.5x / 2x the forward's 0.9 * HD / 64.
+#ifndef FA2_BWD_DQ_UNDERFILLED
+#define FA2_BWD_DQ_UNDERFILLED 1
+#endif
 inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan* dq, SplitPlan* dkv) {
     *dq = SplitPlan();
     *dkv = SplitPlan();
@@ -150,7 +153,7 @@ inline int64_t plan_bwd_split(int HD, const BwdParams& p, bool causal, SplitPlan
     // the hand-scheduled passes (unmasked calls only: the masked backward runs the BIAS forms of the compiler-scheduled passes at every head dim)
     if (p.bias_kind == 0 && HD == 128 && p.D == 128 && (options().asm_mask.load(std::memory_order_relaxed) & 2)) return 0;
     const int64_t cus = device_cus(), bh = (int64_t)p.B * p.H, tile_bytes = (int64_t)kSplitRows * HD * 4;
-    *dq = plan_tail_split(bh * ((p.Nq + 255) / 256), (p.Nkv + kKvTile - 1) / kKvTile, 1.35 * HD / 64.0, 10.0, tile_bytes, cus);
+    *dq = plan_tail_split(bh * ((p.Nq + 255) / 256), (p.Nkv + kKvTile - 1) / kKvTile, 1.35 * HD / 64.0, 10.0, tile_bytes, cus, FA2_BWD_DQ_UNDERFILLED != 0);
     if (HD <= 64) *dkv = plan_tail_split(bh * ((p.Nkv + 255) / 256), (p.Nq + kKvTile - 1) / kKvTile, 1.8 * HD / 64.0, 10.0, 2 * tile_bytes, cus, true);
     return dq->bytes > dkv->bytes ? dq->bytes : dkv->bytes;
 }

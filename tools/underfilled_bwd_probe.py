@@ -1,4 +1,5 @@
-"""Whole backward of grids that cover at most half of the CUs, through the operator, with the split and with option split = 0 (developer probe, round 6;\nFA2_FRONTEND=py FA2_GFX950_LIB=<variant> compares builds)."""
+"""Whole backward of grids that cover at most half of the CUs, through the operator, with the split and with option split = 0 (developer probe, round 6;
+FA2_FRONTEND=py FA2_GFX950_LIB=<variant> compares builds)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.getcwd(), "flash-attention-v2-rdna3-minimal_amd"))
 from rocwmma_fattn.FlashAttn import FlashAttentionFunction

@@ -286,7 +286,11 @@ FwdPlan plan_fwd(int HD, bool bf16, const fa2::FwdParams& p0, bool causal, bool 
             fa2::FwdParams p = p0;
             p.rows_hint = 256;
             f.split = pl;
-            f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256 && pl.full_items > 0;   // (a grid of parts only: the 8-wave kernel)
+            f.split_asm = asm_noncausal_ok(HD, bf16, p) && pick_rows(p, causal) == 256 &&
+                          // (a grid of parts only — plan_split, underfilled: the persistent kernel where a part sweeps at least 24 tiles, else the 8-wave
+                          //  kernel, whose prologue is shorter.  Same box, hand-scheduled / 8-wave parts: B1 H8 N4096 D128, 2 parts of 32 tiles, 67.6 / 78.5 us,
+                          //  D40 44.5 / 48.3, bf16 D64 48.7 / 53.3; B1 H4 N2048 D128, 4 x 8 tiles, 29.2 / 27.5; B1 H32 Nq1 Nkv8192, 8 x 16, 48.4 / 44.9)
+                          (pl.full_items > 0 || ((p.Nkv + fa2::kKvTile - 1) / fa2::kKvTile) / pl.nsplit >= 24);
             const bool fold = f.split_asm && asm_folds(bf16, p);
             const bool lsum16 = f.split_asm && fa2::fwd_asm_lsum16(HD, bf16, p, fold, fa2::fwd_m16_mode(fa2::options().asm_mask.load(std::memory_order_relaxed)));
             f.main = f.split_asm ? RangePlan{FA2_KERNEL_ASM, (fold ? FA2_CONTRACT_PRESCALE_Q : 0) | (lsum16 ? FA2_CONTRACT_LSUM_P16 : 0), 256, fold}

@@ -24,7 +24,8 @@ for (B, H, Nq, Nkv, D) in ((1, 32, 1, 8192, 128), (8, 32, 1, 8192, 128), (32, 32
 from rocwmma_fattn import _fa2_lib
 print("underfilled grids, option split = 1 / 0:")
 for (B, H, Nq, Nkv, D, dt) in ((1, 32, 1, 8192, 128, torch.float16), (1, 8, 4096, 4096, 40, torch.float16), (1, 8, 4096, 4096, 128, torch.float16), (1, 8, 4096, 4096, 64, torch.bfloat16),
-                               (1, 4, 2048, 2048, 128, torch.float16), (2, 8, 1024, 1024, 80, torch.float16), (1, 16, 512, 8192, 64, torch.float16), (1, 8, 8192, 8192, 128, torch.float16)):
+                               (1, 4, 2048, 2048, 128, torch.float16), (2, 8, 1024, 1024, 80, torch.float16), (1, 16, 512, 8192, 64, torch.float16), (1, 8, 8192, 8192, 128, torch.float16),
+                               (1, 10, 4096, 4096, 64, torch.float16), (1, 12, 4096, 4096, 128, torch.float16), (1, 6, 8192, 8192, 128, torch.bfloat16), (2, 20, 1024, 1024, 64, torch.float16), (1, 14, 4096, 4096, 40, torch.float16)):
     q = torch.randn((B, H, Nq, D), device=dev).to(dt); k = torch.randn((B, H, Nkv, D), device=dev).to(dt); v = torch.randn_like(k)
     a = t(lambda: FlashAttentionFunction.apply(q, k, v, None, False))
     with _fa2_lib.options(split=0):

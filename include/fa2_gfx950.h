@@ -115,6 +115,8 @@ int fa2_fwd(int dtype,
  * work; the reference's own N sweep, bench_with_sdpa.py:201-224, saw-tooths for the same reason).  With a workspace, the items of
  * that last round are each swept by several workgroups over disjoint KV ranges and a small kernel merges the partial results
  * (non-causal launches of head dims <= 128; every other call, and any call whose workspace is NULL or too small, is exactly fa2_fwd).
+ * Round 6: a grid that covers at most half of the CUs over a long sweep — a batch-1 call, a decode-sized call (one query row x 8 192 keys x 32
+ * heads: 45 us with the workspace, 147 without) — has EVERY item split the same way, where that saves at least twice the scheme's fixed cost.
  * The reference has no counterpart (its launcher pads the grid to its 96 CUs instead, kernel_fp16.cu:808-813).
  *   fa2_fwd_workspace_bytes  bytes fa2_fwd_ws can use for this shape on the current device (0: it would not use any).  A function
  *                            of the arguments, the device's CU count and the "split" option only; never more than 64 MiB.
@@ -203,6 +205,7 @@ int fa2_bwd(int dtype, const void* q, const void* k, const void* v, const void* 
  * is split into parts that sweep disjoint tile ranges and leave f32 partial accumulators in the workspace; a small kernel sums them, applies
  * `scale` and rounds once (the split changes the f32 summation order of those rows, nothing else).  Non-causal calls; everything else, and any
  * call whose workspace is NULL or too small, is exactly fa2_bwd.  fa2_bwd_workspace_bytes: as fa2_fwd_workspace_bytes (<= 64 MiB, 0 for most shapes).
+ * Round 6: as in the forward, a pass whose grid covers at most half of the CUs splits every item.
  */
 int fa2_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                void* dq, void* dk, void* dv, float* delta_ws,
@@ -305,7 +308,7 @@ typedef struct fa2_fwd_plan_t {
     int kernel, contract, rows;                 /* main launch: FA2_KERNEL_*, FA2_CONTRACT_* bits, Q rows per workgroup */
     int heads_main;                             /* flattened heads [0, heads_main) belong to it (B*H: the only launch) */
     int kernel_tail, contract_tail, rows_tail;  /* second launch over the remaining heads (0: none) */
-    int nsplit, split_items;                    /* KV-split of the last round (0: none) */
+    int nsplit, split_items;                    /* KV-split of the last round, or of every item of an underfilled grid (0: none) */
 } fa2_fwd_plan_t;
 int fa2_fwd_plan(int dtype, int B, int H, int Nq, int Nkv, int D,
                  const int64_t q_strides[3], const int64_t k_strides[3],
